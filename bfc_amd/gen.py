@@ -1,0 +1,75 @@
+"""Deterministic synthetic read generator (SURVEY.md App. B.2 / BASELINE.md section 2).
+
+ctypes front end of ``bfc_amd/csrc/bfcgen.c``.  Produces the SoA batch form the GPU path takes
+(reads concatenated, one offset per read) and FASTQ files for the command-line / reference runs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbfcgen.so")
+_lib = None
+
+
+def build():
+    src = os.path.join(_HERE, "csrc", "bfcgen.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", _SO, src])
+
+
+def _L():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.bfcgen_n_reads.restype = C.c_uint64
+        L.bfcgen_n_reads.argtypes = [C.c_uint64, C.c_double, C.c_int]
+        L.bfcgen_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+        L.bfcgen_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.bfcgen_fastq.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_char_p]
+        _lib = L
+    return _lib
+
+
+class ReadSet:
+    """`bfcgen seed G cov L err`: genome + random-access reads."""
+
+    def __init__(self, seed, G, cov, L=150, err=0.01):
+        self.seed, self.G, self.cov, self.L, self.err = int(seed), int(G), float(cov), int(L), float(err)
+        self.n_reads = int(_L().bfcgen_n_reads(self.G, self.cov, self.L))
+        self.genome = np.empty(self.G, dtype=np.uint8)
+        _L().bfcgen_genome(self.seed, self.G, self.genome.ctypes.data)
+
+    def reads(self, r0=0, r1=None, out_seq=None, out_qual=None):
+        """Reads r0..r1 as (seq u8[n*L], qual u8[n*L], off u64[n+1])."""
+        r1 = self.n_reads if r1 is None else min(int(r1), self.n_reads)
+        n = r1 - r0
+        seq = out_seq if out_seq is not None else np.empty(n * self.L, dtype=np.uint8)
+        qual = out_qual if out_qual is not None else np.empty(n * self.L, dtype=np.uint8)
+        _L().bfcgen_reads(self.seed, self.G, self.genome.ctypes.data, self.L, self.err, r0, r1, seq.ctypes.data, qual.ctypes.data)
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(self.L)
+        return seq, qual, off
+
+    def fastq(self, fn, r0=0, r1=None):
+        r1 = self.n_reads if r1 is None else min(int(r1), self.n_reads)
+        if _L().bfcgen_fastq(self.seed, self.G, self.genome.ctypes.data, self.L, self.err, r0, r1, fn.encode()) != 0:
+            raise OSError("cannot write " + fn)
+        return fn
+
+
+# named fixtures / configs
+FIXTURES = {
+    "g1": dict(seed=1, G=100_000, cov=10),
+    "g42": dict(seed=42, G=1_000_000, cov=30),
+    "c1": dict(seed=1, G=4_600_000, cov=1),
+    "c2": dict(seed=2, G=4_600_000, cov=100),
+    "c3": dict(seed=3, G=248_000_000, cov=30),
+    "c4": dict(seed=4, G=3_100_000_000, cov=30),
+}
+
+
+def fixture(name):
+    return ReadSet(**FIXTURES[name])

@@ -1,0 +1,76 @@
+/* ref_shim.c -- TEST INFRASTRUCTURE ONLY.
+ * Thin exports around the *reference itself*, compiled in place from /root/reference by
+ * oracle/Makefile into oracle/_ref/libbfcref.so (never committed; no reference source is copied).
+ * It (1) defines the three globals bfc.c:13-15 owns, because bfc.c's main() is not linked into
+ * the library, (2) gives the static-inline k-mer functions of kmer.h external names, and
+ * (3) provides the sequential counting harness of SURVEY.md App. D.2: the loop of
+ * worker_count (count.c:72-89) calling the reference's own bfc_kmer_append / bfc_kmer_hash /
+ * bfc_bf_insert / bfc_ch_insert in file order -- proven byte-identical to `bfc -t1 -E -d`
+ * (tests/test_oracle.py re-checks that through the dump md5 goldens).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "bfc.h"
+#include "kmer.h"
+
+int bfc_verbose = 3;
+double bfc_real_time;
+bfc_kmer_t bfc_kmer_null = {{0,0,0,0}};
+
+void ref_kmer_append(int k, uint64_t x[4], int c) { bfc_kmer_append(k, x, c); }
+uint64_t ref_hash_64(uint64_t key, uint64_t mask) { return bfc_hash_64(key, mask); }
+uint64_t ref_kmer_hash(int k, const uint64_t x[4], uint64_t h[2]) { return bfc_kmer_hash(k, x, h); }
+void ref_kmer_hash_inv(int k, const uint64_t h[2], uint64_t y[2]) { bfc_kmer_hash_inv(k, h, y); }
+int ref_nt6(int c) { return seq_nt6_table[(uint8_t)c]; }
+
+typedef struct { bfc_bf_t *bf, *bf_high; bfc_ch_t *ch; uint64_t n_kmers, n_high, n_seen, hash_xor; } ref_state_t;
+
+ref_state_t *ref_state_new(int k, int bf_shift, int n_hashes, int l_pre, int filter_mode)
+{
+	ref_state_t *st = (ref_state_t*)calloc(1, sizeof(*st));
+	st->bf = bfc_bf_init(bf_shift, n_hashes);
+	if (filter_mode) st->bf_high = bfc_bf_init(bf_shift, n_hashes);
+	else st->ch = bfc_ch_init(k, l_pre);
+	return st;
+}
+void ref_state_free(ref_state_t *st) { bfc_bf_destroy(st->bf); bfc_bf_destroy(st->bf_high); bfc_ch_destroy(st->ch); free(st); }
+bfc_bf_t *ref_state_bf(ref_state_t *st) { return st->bf; }
+bfc_bf_t *ref_state_bf_high(ref_state_t *st) { return st->bf_high; }
+bfc_ch_t *ref_state_ch(ref_state_t *st) { return st->ch; }
+uint8_t *ref_bf_bits(bfc_bf_t *b) { return b->b; }
+void ref_state_stats(const ref_state_t *st, uint64_t out[4]) { out[0] = st->n_kmers; out[1] = st->n_high; out[2] = st->n_seen; out[3] = st->hash_xor; }
+
+/* one read, strictly sequential; trace (optional) gets hash,y0,y1,flags per k-mer */
+int ref_count_read(ref_state_t *st, int k, int q, int n_hashes, const char *seq, const char *qual, int len, uint64_t *trace)
+{
+	int i, l = 0, n = 0;
+	bfc_kmer_t x = bfc_kmer_null;
+	uint64_t qmer = 0, mask = (1ULL << k) - 1;
+	for (i = 0; i < len; ++i) {
+		int c = seq_nt6_table[(uint8_t)seq[i]] - 1;
+		if (c < 4) {
+			bfc_kmer_append(k, x.x, c);
+			qmer = (qmer << 1 | (qual == 0 || qual[i] - 33 >= q)) & mask;
+			if (++l >= k) {
+				uint64_t y[2], hash = bfc_kmer_hash(k, x.x, y);
+				int is_high = (qmer == mask), seen = (bfc_bf_insert(st->bf, hash) == n_hashes);
+				++st->n_kmers; st->n_high += is_high; st->n_seen += seen; st->hash_xor ^= hash * (st->n_kmers | 1);
+				if (seen) {
+					if (st->ch) bfc_ch_insert(st->ch, y, is_high, 1);
+					else if (st->bf_high) bfc_bf_insert(st->bf_high, hash);
+				}
+				if (trace) { trace[4*n] = hash; trace[4*n+1] = y[0]; trace[4*n+2] = y[1]; trace[4*n+3] = (uint64_t)(is_high | seen << 1); }
+				++n;
+			}
+		} else l = 0, qmer = 0, x = bfc_kmer_null;
+	}
+	return n;
+}
+uint64_t ref_count_batch(ref_state_t *st, int k, int q, int n_hashes, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint64_t n_reads, uint64_t *trace)
+{
+	uint64_t r, n = 0;
+	for (r = 0; r < n_reads; ++r)
+		n += ref_count_read(st, k, q, n_hashes, (const char*)seq + off[r], qual ? (const char*)qual + off[r] : 0, (int)(off[r+1] - off[r]), trace ? trace + 4 * n : 0);
+	return n;
+}
