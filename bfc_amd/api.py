@@ -1,0 +1,286 @@
+"""Python mirror of the reference's count-phase interface on top of the C ABI (libbfc_gpu.so).
+
+Names follow the reference: ``bfc_opt_init`` (bfc.c:17-40), ``bfc_opt_by_size`` (bfc.c:42-53),
+``bfc_count`` (count.c:127), and the query surface of ``bfc_ch_t`` / ``bfc_bf_t`` (htab.h, bbf.h).
+``GpuCounter`` is the device-level interface (batches of reads already in memory).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import BfcOpt, BfcgParams, BfcKmer, u64p, u32p, f32p
+
+STAT_NAMES = {0: "n_kmers", 1: "n_high", 2: "n_seen", 3: "n_keys", 4: "tab_ovf", 5: "err_pool", 6: "slow_buckets", 8: "tab_cshift", 9: "n_batches"}
+
+
+class BfcGpuError(RuntimeError):
+    pass
+
+
+def bfc_opt_init():
+    """Defaults of bfc.c:17-40."""
+    o = BfcOpt()
+    o.chunk_size = 100000000
+    o.n_threads = 1
+    o.q = 20
+    o.k = 33
+    o.l_pre = 20
+    o.bf_shift = 33
+    o.n_hashes = 4
+    o.min_frac = 0.9
+    o.min_cov = 3
+    o.win_multi_ec = 10
+    o.max_end_ext = 5
+    o.w_ec, o.w_ec_high, o.w_absent, o.w_absent_high = 1, 7, 3, 1
+    o.max_path_diff, o.max_heap = 15, 100
+    return o
+
+
+def bfc_opt_by_size(opt, size):
+    """`-s`: bfc.c:42-53."""
+    bits = math.log(size) / math.log(2)
+    opt.k = int(bits + 1.0)
+    if opt.k & 1 == 0:
+        opt.k += 1
+    opt.k = min(opt.k, 63)
+    opt.bf_shift = min(int(bits + 8.0), 37)
+    return opt
+
+
+def to_stream(seq, off):
+    """(concatenated reads, offsets) -> separator-delimited stream (one '\\n' after each read)."""
+    off = np.asarray(off, dtype=np.int64)
+    n = len(off) - 1
+    out = np.empty(len(seq) + n, dtype=np.uint8)
+    lens = np.diff(off)
+    if n and np.all(lens == lens[0]):
+        L = int(lens[0])
+        v = out.reshape(n, L + 1)
+        v[:, :L] = np.asarray(seq).reshape(n, L)
+        v[:, L] = 10
+    else:
+        pos = off[:-1] + np.arange(n)
+        mask = np.ones(len(out), dtype=bool)
+        mask[off[1:] + np.arange(n)] = False
+        out[mask] = seq
+        out[~mask] = 10
+        del pos
+    return out
+
+
+class HostTable:
+    """A host-resident ``bfc_ch_t`` (opaque, htab.h:10-23)."""
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise BfcGpuError("NULL bfc_ch_t")
+        self.L = _lib.load()
+        self.ptr = ptr
+
+    def close(self):
+        if self.ptr:
+            self.L.bfc_ch_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def k(self):
+        return self.L.bfc_ch_get_k(self.ptr)
+
+    @property
+    def l_pre(self):
+        return self.L.bfc_ch_get_lpre(self.ptr)
+
+    def get(self, y0, y1):
+        return self.L.bfc_ch_get(self.ptr, (C.c_uint64 * 2)(y0, y1))
+
+    def kmer_occ(self, x):
+        z = BfcKmer()
+        for i in range(4):
+            z.x[i] = int(x[i])
+        return self.L.bfc_ch_kmer_occ(self.ptr, C.byref(z))
+
+    def insert(self, y0, y1, is_high, forced=1):
+        return self.L.bfc_ch_insert(self.ptr, (C.c_uint64 * 2)(y0, y1), int(is_high), forced)
+
+    def count(self):
+        return int(self.L.bfc_ch_count(self.ptr))
+
+    def hist(self):
+        cnt = np.zeros(256, dtype=np.uint64)
+        high = np.zeros(64, dtype=np.uint64)
+        mode = self.L.bfc_ch_hist(self.ptr, cnt.ctypes.data_as(u64p), high.ctypes.data_as(u64p))
+        return mode, cnt, high
+
+    def dump(self, fn):
+        return self.L.bfc_ch_dump(self.ptr, fn.encode())
+
+    def export_sorted(self):
+        sizes = np.zeros(1 << self.l_pre, dtype=np.uint32)
+        n = self.L.bfc_ch_export_sorted(self.ptr, sizes.ctypes.data_as(u32p), None)
+        slots = np.zeros(int(n), dtype=np.uint64)
+        self.L.bfc_ch_export_sorted(self.ptr, sizes.ctypes.data_as(u32p), slots.ctypes.data_as(u64p))
+        return sizes, slots
+
+    @staticmethod
+    def init(k, l_pre):
+        return HostTable(_lib.load().bfc_ch_init(k, l_pre))
+
+    @staticmethod
+    def restore(fn):
+        p = _lib.load().bfc_ch_restore(fn.encode())
+        return HostTable(p) if p else None
+
+
+class HostBloom:
+    """A host-resident ``bfc_bf_t`` (bbf.h:9-12)."""
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise BfcGpuError("NULL bfc_bf_t")
+        self.L = _lib.load()
+        self.ptr = ptr
+
+    def close(self):
+        if self.ptr:
+            self.L.bfc_bf_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_shift(self):
+        return self.ptr.contents.n_shift
+
+    @property
+    def n_hashes(self):
+        return self.ptr.contents.n_hashes
+
+    def bytes(self):
+        return np.ctypeslib.as_array(self.ptr.contents.b, shape=(1 << (self.n_shift - 3),))
+
+    def get(self, h):
+        return self.L.bfc_bf_get(self.ptr, h)
+
+    def insert(self, h):
+        return self.L.bfc_bf_insert(self.ptr, h)
+
+    @staticmethod
+    def init(n_shift, n_hashes):
+        p = _lib.load().bfc_bf_init(n_shift, n_hashes)
+        return HostBloom(p) if p else None
+
+
+def bfc_count(fn, opt):
+    """count.c:127: count the k-mers of file `fn` on the GPU; returns HostTable or (filter mode) HostBloom."""
+    L = _lib.load()
+    p = L.bfc_count(fn.encode(), C.byref(opt))
+    if opt.filter_mode:
+        return HostBloom(C.cast(p, C.POINTER(_lib.BfcBf)))
+    return HostTable(p)
+
+
+class GpuCounter:
+    """Device-level counting context (bfcg_ctx_t)."""
+
+    def __init__(self, k, bf_shift, q=20, n_hashes=4, l_pre=20, filter_mode=0, device=0, max_batch_pos=1 << 24,
+                 region_shift=0, tab_cshift=0, debug_seen=False):
+        self.L = _lib.load()
+        p = BfcgParams()
+        self.L.bfcg_params_default(C.byref(p))
+        p.k, p.q, p.bf_shift, p.n_hashes, p.l_pre, p.filter_mode = k, q, bf_shift, n_hashes, l_pre, filter_mode
+        p.device, p.max_batch_pos, p.region_shift, p.tab_cshift, p.debug_seen = device, int(max_batch_pos), region_shift, tab_cshift, int(debug_seen)
+        self.params = p
+        self.bf_shift, self.k = bf_shift, k
+        self.ctx = self.L.bfcg_create(C.byref(p))
+        if not self.ctx:
+            raise BfcGpuError("bfcg_create failed: " + self.L.bfcg_last_error().decode())
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+
+    def close(self):
+        if self.ctx:
+            self.L.bfcg_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._ck(self.L.bfcg_reset(self.ctx))
+
+    def count_host(self, seq_stream, qual_stream=None):
+        seq_stream = np.ascontiguousarray(seq_stream, dtype=np.uint8)
+        q = np.ascontiguousarray(qual_stream, dtype=np.uint8) if qual_stream is not None else None
+        self._ck(self.L.bfcg_count_batch_host(self.ctx, seq_stream.ctypes.data, q.ctypes.data if q is not None else None, len(seq_stream)))
+
+    def count_dev(self, d_seq, d_qual, n_pos):
+        self._ck(self.L.bfcg_count_batch_dev(self.ctx, d_seq, d_qual, n_pos))
+
+    def dev_alloc(self, nbytes):
+        p = self.L.bfcg_dev_alloc(self.ctx, nbytes)
+        if not p:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return p
+
+    def dev_free(self, p):
+        self.L.bfcg_dev_free(self.ctx, p)
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.L.bfcg_h2d(self.ctx, dptr, arr.ctypes.data, arr.nbytes))
+
+    def sync(self):
+        self._ck(self.L.bfcg_sync(self.ctx))
+
+    def stats(self):
+        out = np.zeros(16, dtype=np.uint64)
+        self._ck(self.L.bfcg_stats(self.ctx, out.ctypes.data_as(u64p)))
+        return {STAT_NAMES[i]: int(out[i]) for i in STAT_NAMES}
+
+    def last_batch_ms(self):
+        out = np.zeros(5, dtype=np.float32)
+        self.L.bfcg_last_batch_ms(self.ctx, out.ctypes.data_as(f32p))
+        return dict(hist1=float(out[0]), scatter1=float(out[1]), level2=float(out[2]), bloom=float(out[3]), total=float(out[4]))
+
+    def bloom_bytes(self, which=0):
+        out = np.empty(1 << (self.bf_shift - 3), dtype=np.uint8)
+        self._ck(self.L.bfcg_bloom_to_host(self.ctx, which, out.ctypes.data))
+        return out
+
+    def export_bloom(self, which=0):
+        return HostBloom(self.L.bfcg_export_bloom(self.ctx, which))
+
+    def export_table(self):
+        p = self.L.bfcg_export_table(self.ctx)
+        if not p:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return HostTable(p)
+
+    def hash_positions(self, seq_stream, qual_stream=None):
+        seq_stream = np.ascontiguousarray(seq_stream, dtype=np.uint8)
+        q = np.ascontiguousarray(qual_stream, dtype=np.uint8) if qual_stream is not None else None
+        out = np.zeros((len(seq_stream), 3), dtype=np.uint64)
+        self._ck(self.L.bfcg_hash_positions(self.ctx, seq_stream.ctypes.data, q.ctypes.data if q is not None else None, len(seq_stream), out.ctypes.data_as(u64p)))
+        return out
+
+    def seen_flags(self, n_pos):
+        out = np.zeros(n_pos, dtype=np.uint8)
+        self._ck(self.L.bfcg_seen_flags(self.ctx, out.ctypes.data, n_pos))
+        return out

@@ -1,0 +1,314 @@
+/* bfc_host.c -- host side of the reference-shaped API (include/bfc_gpu.h, PART 1):
+ * the query functions correct.c calls per k-mer from its worker threads (bfc_bf_get,
+ * bfc_ch_get, bfc_ch_kmer_occ, bfc_ch_hist) plus the single-element insert / dump / restore
+ * entry points of bbf.h and htab.h.  These operate on HOST copies of what the GPU built; the
+ * counting itself (bfc_count) never runs here.
+ *
+ * The host table keeps the GPU layout: 2^l_pre regions of 2^cshift u64 slots, slot value
+ * key(50)<<14 | high(6)<<8 | count(8) exactly as htab.c:7-17, 0 = empty, home slot = low bits of
+ * key>>14, linear probing inside the region.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+#include <pthread.h>
+#include "bfc_gpu.h"
+#include "bfc_host.h"
+
+/* ------------------------------------------------------------------ k-mer hash (kmer.h:30-40,79-88) */
+
+static inline uint64_t mix_k(uint64_t v, uint64_t m)
+{
+	v = (~v + (v << 21)) & m; v ^= v >> 24;
+	v = (v + (v << 3) + (v << 8)) & m; v ^= v >> 14;
+	v = (v + (v << 2) + (v << 4)) & m; v ^= v >> 28;
+	v = (v + (v << 31)) & m;
+	return v;
+}
+static inline void kmer_y(int k, const uint64_t x[4], uint64_t y[2])
+{
+	int t = k >> 1, rev = ((x[1] >> t) & 1) > ((x[3] >> t) & 1);
+	uint64_t m = (1ULL << k) - 1, a = x[rev << 1], b = x[rev << 1 | 1];
+	uint64_t h0 = mix_k((a + b) & m, m), h1 = mix_k(h0 ^ b, m);
+	y[0] = (h0 + h1) & m; y[1] = h1;
+}
+
+/* ------------------------------------------------------------------ bloom filter (bbf.c) */
+
+bfc_bf_t *bfc_bf_init(int n_shift, int n_hashes)
+{
+	bfc_bf_t *b; void *p = 0;
+	if (n_shift + BFC_BLK_SHIFT > 64 || n_shift < BFC_BLK_SHIFT) return 0;
+	b = (bfc_bf_t*)calloc(1, sizeof(bfc_bf_t));
+	b->n_shift = n_shift; b->n_hashes = n_hashes;
+	if (posix_memalign(&p, 64, 1ULL << (n_shift - 3)) != 0) { free(b); return 0; }
+	b->b = (uint8_t*)p;
+	memset(b->b, 0, 1ULL << (n_shift - 3));
+	return b;
+}
+void bfc_bf_destroy(bfc_bf_t *b) { if (b) { free(b->b); free(b); } }
+
+static inline uint8_t *bf_walk(const bfc_bf_t *b, uint64_t hash, int *h1, int *h2)
+{
+	int x = b->n_shift - BFC_BLK_SHIFT;
+	*h1 = (int)(hash >> x) & BFC_BLK_MASK;
+	*h2 = (int)(hash >> b->n_shift) & BFC_BLK_MASK;
+	if ((*h2 & 31) == 0) *h2 = (*h2 + 1) & BFC_BLK_MASK;
+	return b->b + ((hash & ((1ULL << x) - 1)) << (BFC_BLK_SHIFT - 3));
+}
+int bfc_bf_insert(bfc_bf_t *b, uint64_t hash) /* single-k-mer host insert; atomic OR instead of the block spin lock */
+{
+	int h1, h2, i, z, cnt = 0;
+	uint8_t *p = bf_walk(b, hash, &h1, &h2);
+	for (i = 0, z = h1; i < b->n_hashes; z = (z + h2) & BFC_BLK_MASK) {
+		uint8_t u;
+		if (z < 8) continue;
+		u = (uint8_t)(1u << (z & 7));
+		cnt += (__sync_fetch_and_or(&p[z >> 3], u) & u) != 0;
+		++i;
+	}
+	return cnt;
+}
+int bfc_bf_get(const bfc_bf_t *b, uint64_t hash)
+{
+	int h1, h2, i, z, cnt = 0;
+	const uint8_t *p = bf_walk(b, hash, &h1, &h2);
+	for (i = 0, z = h1; i < b->n_hashes; z = (z + h2) & BFC_BLK_MASK) {
+		if (z < 8) continue;
+		cnt += (p[z >> 3] >> (z & 7)) & 1;
+		++i;
+	}
+	return cnt;
+}
+
+/* ------------------------------------------------------------------ count table (htab.c) */
+
+struct bfc_ch_s {
+	int k, l_pre, cshift;
+	uint64_t *slots;
+	uint64_t n_keys;
+	pthread_rwlock_t grow_lock; /* inserts share it, growth owns it */
+};
+
+static int clamp_lpre(int k, int l_pre)
+{
+	if (k * 2 - l_pre > BFC_CH_KEYBITS) l_pre = k * 2 - BFC_CH_KEYBITS;
+	if (l_pre > BFC_CH_MAXPRE) l_pre = BFC_CH_MAXPRE;
+	return l_pre;
+}
+bfc_ch_t *bfc_ch_alloc_raw(int k, int l_pre, int cshift)
+{
+	bfc_ch_t *ch = (bfc_ch_t*)calloc(1, sizeof(bfc_ch_t));
+	if (!ch) return 0;
+	ch->k = k; ch->l_pre = l_pre; ch->cshift = cshift;
+	ch->slots = (uint64_t*)calloc((size_t)1 << (l_pre + cshift), 8);
+	if (!ch->slots) { free(ch); return 0; }
+	pthread_rwlock_init(&ch->grow_lock, 0);
+	return ch;
+}
+uint64_t *bfc_ch_raw_slots(bfc_ch_t *ch) { return ch->slots; }
+void bfc_ch_raw_recount(bfc_ch_t *ch)
+{
+	uint64_t i, n = (uint64_t)1 << (ch->l_pre + ch->cshift), c = 0;
+	for (i = 0; i < n; ++i) c += ch->slots[i] != 0;
+	ch->n_keys = c;
+}
+bfc_ch_t *bfc_ch_init(int k, int l_pre)
+{
+	assert(k <= 63);
+	l_pre = clamp_lpre(k, l_pre);
+	assert(k - l_pre < BFC_CH_KEYBITS);
+	return bfc_ch_alloc_raw(k, l_pre, 2);
+}
+void bfc_ch_destroy(bfc_ch_t *ch)
+{
+	if (!ch) return;
+	pthread_rwlock_destroy(&ch->grow_lock);
+	free(ch->slots); free(ch);
+}
+int bfc_ch_get_k(const bfc_ch_t *ch) { return ch->k; }
+int bfc_ch_get_lpre(const bfc_ch_t *ch) { return ch->l_pre; }
+
+static inline uint32_t subkey(const bfc_ch_t *ch, const uint64_t x[2], uint64_t *key) /* htab.c:45-58 */
+{
+	if (ch->k <= 32) {
+		int t = ch->k * 2 - ch->l_pre;
+		uint64_t z = x[0] << ch->k | x[1];
+		*key = (z & ((1ULL << t) - 1)) << 14 | 1;
+		return (uint32_t)(z >> t);
+	} else {
+		int t = ch->k - ch->l_pre;
+		int shift = t + ch->k < BFC_CH_KEYBITS ? ch->k : BFC_CH_KEYBITS - t;
+		*key = ((x[0] & ((1ULL << t) - 1)) << shift ^ x[1]) << 14 | 1;
+		return (uint32_t)(x[0] >> t);
+	}
+}
+
+static void grow(bfc_ch_t *ch) /* caller holds the write lock */
+{
+	int nc = ch->cshift + 1;
+	uint64_t n = (uint64_t)1 << (ch->l_pre + ch->cshift), i;
+	uint64_t *ns = (uint64_t*)calloc((size_t)1 << (ch->l_pre + nc), 8);
+	uint32_t cmask = (1u << nc) - 1;
+	for (i = 0; i < n; ++i) {
+		uint64_t v = ch->slots[i], *reg;
+		uint32_t pos;
+		if (!v) continue;
+		reg = ns + ((i >> ch->cshift) << nc);
+		for (pos = (uint32_t)(v >> 14) & cmask; reg[pos]; pos = (pos + 1) & cmask);
+		reg[pos] = v;
+	}
+	free(ch->slots);
+	ch->slots = ns; ch->cshift = nc;
+}
+
+/* returns 1 new, 0 updated, -1 region full */
+static int upsert(bfc_ch_t *ch, uint32_t sub, uint64_t key, int is_high)
+{
+	uint32_t cmask = (1u << ch->cshift) - 1, pos = (uint32_t)(key >> 14) & cmask, probe;
+	uint64_t *reg = ch->slots + ((uint64_t)sub << ch->cshift);
+	uint64_t fresh = key | (uint64_t)(is_high != 0) << 8;
+	for (probe = 0; probe <= cmask; ++probe, pos = (pos + 1) & cmask) {
+		uint64_t cur = __atomic_load_n(&reg[pos], __ATOMIC_RELAXED);
+		if (cur == 0) {
+			if (__atomic_compare_exchange_n(&reg[pos], &cur, fresh, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return 1;
+		}
+		if (cur >> 14 == key >> 14) {
+			for (;;) {
+				uint64_t nv = cur;
+				if ((nv & 0xff) != 0xff) ++nv;                                   /* htab.c:77 */
+				if (is_high && (nv >> 8 & 0x3f) != 0x3f) nv += 1 << 8;             /* htab.c:78 */
+				if (nv == cur) return 0;
+				if (__atomic_compare_exchange_n(&reg[pos], &cur, nv, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return 0;
+			}
+		}
+	}
+	return -1;
+}
+
+int bfc_ch_insert(bfc_ch_t *ch, const uint64_t x[2], int is_high, int forced)
+{
+	uint64_t key;
+	uint32_t sub = subkey(ch, x, &key);
+	(void)forced; /* lock-free upsert never has to give up (htab.c:67-72 returns -1 only on lock contention) */
+	for (;;) {
+		int r;
+		pthread_rwlock_rdlock(&ch->grow_lock);
+		r = upsert(ch, sub, key, is_high);
+		pthread_rwlock_unlock(&ch->grow_lock);
+		if (r >= 0) { if (r) __sync_fetch_and_add(&ch->n_keys, 1); return 0; }
+		pthread_rwlock_wrlock(&ch->grow_lock);
+		grow(ch);
+		pthread_rwlock_unlock(&ch->grow_lock);
+	}
+}
+
+int bfc_ch_get(const bfc_ch_t *ch, const uint64_t x[2])
+{
+	uint64_t key;
+	uint32_t sub = subkey(ch, x, &key);
+	uint32_t cmask = (1u << ch->cshift) - 1, pos = (uint32_t)(key >> 14) & cmask, probe;
+	const uint64_t *reg = ch->slots + ((uint64_t)sub << ch->cshift);
+	for (probe = 0; probe <= cmask; ++probe, pos = (pos + 1) & cmask) {
+		uint64_t cur = reg[pos];
+		if (cur == 0) return -1;
+		if (cur >> 14 == key >> 14) return (int)(cur & 0x3fff);
+	}
+	return -1;
+}
+int bfc_ch_kmer_occ(const bfc_ch_t *ch, const bfc_kmer_t *z)
+{
+	uint64_t y[2];
+	kmer_y(ch->k, z->x, y);
+	return bfc_ch_get(ch, y);
+}
+uint64_t bfc_ch_count(const bfc_ch_t *ch) { return ch->n_keys; }
+
+int bfc_ch_hist(const bfc_ch_t *ch, uint64_t cnt[256], uint64_t high[64])
+{
+	uint64_t i, n = (uint64_t)1 << (ch->l_pre + ch->cshift), max = 0;
+	int max_i = -1;
+	memset(cnt, 0, 256 * 8); memset(high, 0, 64 * 8);
+	for (i = 0; i < n; ++i) {
+		uint64_t v = ch->slots[i];
+		if (v) { ++cnt[v & 0xff]; ++high[v >> 8 & 0x3f]; }
+	}
+	for (i = 3; i < 256; ++i) if (cnt[i] > max) { max = cnt[i]; max_i = (int)i; }
+	return max_i;
+}
+
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : x > y; }
+
+uint64_t bfc_ch_export_sorted(const bfc_ch_t *ch, uint32_t *sizes, uint64_t *slots)
+{
+	uint64_t s, n_sub = (uint64_t)1 << ch->l_pre, n = 0;
+	uint32_t c = 1u << ch->cshift, j;
+	for (s = 0; s < n_sub; ++s) {
+		const uint64_t *reg = ch->slots + (s << ch->cshift);
+		uint64_t n0 = n;
+		for (j = 0; j < c; ++j) if (reg[j]) { if (slots) slots[n] = reg[j]; ++n; }
+		if (sizes) sizes[s] = (uint32_t)(n - n0);
+		if (slots && n - n0 > 1) qsort(slots + n0, n - n0, 8, cmp_u64);
+	}
+	return n;
+}
+
+/* dump in the reference's format (htab.c:129-149): u32 k, u32 l_pre, then per sub-table
+ * u32 n_buckets, u32 size and the occupied slots.  n_buckets follows khash's growth rule
+ * (smallest power of two >= 4 whose 0.75 load the size stays below), so the reference's
+ * bfc_ch_restore (htab.c:151-176) rebuilds the same sets.  Slot ORDER inside a sub-table is this
+ * implementation's, not khash's: parity level L1, not L2. */
+int bfc_ch_dump(const bfc_ch_t *ch, const char *fn)
+{
+	FILE *fp;
+	uint32_t t[2], c = 1u << ch->cshift, j;
+	uint64_t s, n_sub = (uint64_t)1 << ch->l_pre;
+	if ((fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout) == 0) return -1;
+	t[0] = (uint32_t)ch->k; t[1] = (uint32_t)ch->l_pre;
+	fwrite(t, 4, 2, fp);
+	for (s = 0; s < n_sub; ++s) {
+		const uint64_t *reg = ch->slots + (s << ch->cshift);
+		uint32_t size = 0, nb = 0;
+		for (j = 0; j < c; ++j) size += reg[j] != 0;
+		if (size) for (nb = 4; size >= (nb >> 2) + (nb >> 1); nb <<= 1);
+		t[0] = nb; t[1] = size;
+		fwrite(t, 4, 2, fp);
+		for (j = 0; j < c; ++j) if (reg[j]) fwrite(&reg[j], 8, 1, fp);
+	}
+	fprintf(stderr, "[M::%s] dumpped the hash table to file '%s'.\n", __func__, fn);
+	if (fp != stdout) fclose(fp);
+	return 0;
+}
+
+bfc_ch_t *bfc_ch_restore(const char *fn)
+{
+	FILE *fp;
+	uint32_t t[2];
+	uint64_t s, n_sub;
+	bfc_ch_t *ch;
+	if ((fp = fopen(fn, "rb")) == 0) return 0;
+	if (fread(t, 4, 2, fp) != 2) { fclose(fp); return 0; }
+	ch = bfc_ch_init((int)t[0], (int)t[1]);
+	assert((int)t[1] == ch->l_pre);
+	n_sub = (uint64_t)1 << ch->l_pre;
+	for (s = 0; s < n_sub; ++s) {
+		uint32_t j;
+		if (fread(t, 4, 2, fp) != 2) { fclose(fp); bfc_ch_destroy(ch); return 0; }
+		for (j = 0; j < t[1]; ++j) {
+			uint64_t v;
+			if (fread(&v, 8, 1, fp) != 1) { fclose(fp); bfc_ch_destroy(ch); return 0; }
+			for (;;) { /* place the stored slot value (key + counters) verbatim */
+				uint32_t cmask = (1u << ch->cshift) - 1, pos = (uint32_t)(v >> 14) & cmask, probe;
+				uint64_t *reg = ch->slots + (s << ch->cshift);
+				for (probe = 0; probe <= cmask && reg[pos]; ++probe, pos = (pos + 1) & cmask);
+				if (probe <= cmask) { reg[pos] = v; ++ch->n_keys; break; }
+				grow(ch);
+			}
+		}
+	}
+	fclose(fp);
+	fprintf(stderr, "[M::%s] restored the hash table from file '%s'.\n", __func__, fn);
+	return ch;
+}

@@ -1,0 +1,14 @@
+/* bfc_host.h -- internal: raw access to the host-side count table for the exporter */
+#ifndef BFC_HOST_H
+#define BFC_HOST_H
+#include "bfc_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+bfc_ch_t *bfc_ch_alloc_raw(int k, int l_pre_clamped, int cshift);
+uint64_t *bfc_ch_raw_slots(bfc_ch_t *ch);
+void bfc_ch_raw_recount(bfc_ch_t *ch);
+#ifdef __cplusplus
+}
+#endif
+#endif

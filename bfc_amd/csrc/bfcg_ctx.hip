@@ -1,0 +1,289 @@
+// bfcg_ctx.hip -- host side of the device-level API (include/bfc_gpu.h, PART 2):
+// owns the HBM-resident state (bloom filter(s), count table, batch scratch) and drives the
+// kernels of bfcg_kernels.hip batch by batch on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include "bfc_gpu.h"
+#include "bfcg_internal.h"
+#include "bfc_host.h"
+
+using namespace bfcg;
+
+static thread_local char g_err[512] = "";
+static int set_err(const char *fmt, ...)
+{
+	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+	fprintf(stderr, "[E::bfcg] %s\n", g_err);
+	return -1;
+}
+#define HIPCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define HIPCKN(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return NULL; } } while (0)
+
+struct bfcg_ctx {
+	bfcg_params_t prm;
+	KParams P;
+	BatchBufs B;
+	hipStream_t st;
+	hipEvent_t ev[5];
+	uint8_t *d_seq, *d_qual;     // staging for host batches
+	unsigned long long *h_stats; // pinned mirror
+	uint64_t n_batches;
+	float last_ms[5];
+	int rw;                      // u64 words per record
+	uint64_t bloom_bytes;
+};
+
+extern "C" const char *bfcg_last_error(void) { return g_err; }
+
+extern "C" void bfcg_params_default(bfcg_params_t *p)
+{
+	memset(p, 0, sizeof(*p));
+	p->k = 33; p->q = 20; p->bf_shift = 33; p->n_hashes = 4; p->l_pre = 20; // bfc.c:17-26
+	p->max_batch_pos = 1ULL << 27;
+}
+
+static int clamp_lpre(int k, int l_pre) // htab.c:24-26
+{
+	if (k * 2 - l_pre > BFC_CH_KEYBITS) l_pre = k * 2 - BFC_CH_KEYBITS;
+	if (l_pre > BFC_CH_MAXPRE) l_pre = BFC_CH_MAXPRE;
+	return l_pre;
+}
+
+extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("no HIP device available: the counting path has no CPU fallback"); return NULL; }
+	if (prm->device < 0 || prm->device >= ndev) { set_err("device %d out of range (%d devices)", prm->device, ndev); return NULL; }
+	if (prm->k < 1 || prm->k > 63) { set_err("k=%d outside [1,63] (bfc.h:8, htab.c:23)", prm->k); return NULL; }
+	if (prm->bf_shift < 9 + 0 || prm->bf_shift > 37) { set_err("bf_shift=%d outside [9,37] (bbf.c:9, bfc.h:9)", prm->bf_shift); return NULL; }
+	if (prm->n_hashes < 1 || prm->n_hashes > 12) { set_err("n_hashes=%d outside [1,12]", prm->n_hashes); return NULL; }
+	if (prm->max_batch_pos == 0 || prm->max_batch_pos >= (1ULL << 32)) { set_err("max_batch_pos must be in [1, 2^32)"); return NULL; }
+	HIPCKN(hipSetDevice(prm->device));
+
+	bfcg_ctx_t *c = (bfcg_ctx_t *)calloc(1, sizeof(bfcg_ctx_t));
+	c->prm = *prm;
+	KParams &P = c->P;
+	P.k = prm->k; P.q = prm->q; P.bf_shift = prm->bf_shift; P.n_hashes = prm->n_hashes; P.filter_mode = prm->filter_mode;
+	P.l_pre = clamp_lpre(prm->k, prm->l_pre);
+	P.R = prm->region_shift > 0 ? prm->region_shift : 10;
+	if (P.R > 10) P.R = 10;
+	if (P.R > P.bf_shift - 9) P.R = P.bf_shift - 9;
+	P.F = P.bf_shift - 9 - P.R;
+	if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
+	else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
+	if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
+	// LDS budget of the bloom kernel: 160 KiB per workgroup
+	{
+		size_t region = (size_t)64 << P.R, left = 160 * 1024 - 64 - region;
+		uint32_t fs = 1024; while ((size_t)fs * 2 * 8 + (size_t)fs * 2 * 3 <= left && fs < 8192) fs <<= 1; // list = 3/4 fs entries * 4 B
+		P.fs_cap = fs; P.list_cap = fs - fs / 4;
+	}
+	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
+	c->rw = P.k <= 47 ? 2 : 3;
+	c->bloom_bytes = 1ULL << (P.bf_shift - 3);
+
+	BatchBufs &B = c->B;
+	B.max_kmers = prm->max_batch_pos;
+	const int nb1 = 1 << P.F1, nfine = 1 << P.F;
+	HIPCKN(hipStreamCreate(&c->st));
+	for (int i = 0; i < 5; ++i) HIPCKN(hipEventCreate(&c->ev[i]));
+	HIPCKN(hipMalloc(&B.cnt1, sizeof(uint32_t) * (nb1 + 1) * 3)); B.start1 = B.cnt1 + nb1 + 1; B.cursor1 = B.start1 + nb1 + 1;
+	HIPCKN(hipMalloc(&B.cnt2, sizeof(uint32_t) * (nfine + 1) * 3)); B.start2 = B.cnt2 + nfine + 1; B.cursor2 = B.start2 + nfine + 1;
+	HIPCKN(hipMalloc(&B.recs1, B.max_kmers * c->rw * 8));
+	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, B.max_kmers * c->rw * 8));
+	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
+	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
+	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
+	HIPCKN(hipMalloc(&B.stats, sizeof(unsigned long long) * ST_N));
+	B.tab_ovf_cap = 1u << 20;
+	HIPCKN(hipMalloc(&B.tab_ovf, (uint64_t)B.tab_ovf_cap * 24));
+	// global first-setter pool for regions whose LDS table overflows: worst case every bucket overflows
+	// with cap = pow2 >= 2*n_hashes*n  =>  <= 4*n_hashes*max_kmers entries (+1024 per bucket)
+	B.pool_cap = 4ULL * P.n_hashes * B.max_kmers + 1024ULL * nfine;
+	if (B.pool_cap > (1ULL << 31)) B.pool_cap = 1ULL << 31; // 16 GiB ceiling; exhaustion is reported, never silent
+	HIPCKN(hipMalloc(&B.pool, (B.pool_cap + 1) * 8));
+	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
+	HIPCKN(hipMalloc(&c->d_seq, prm->max_batch_pos));
+	HIPCKN(hipMalloc(&c->d_qual, prm->max_batch_pos));
+	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N));
+	HIPCKN(set_bloom_lds_attr(P));
+	if (bfcg_reset(c) != 0) { bfcg_destroy(c); return NULL; }
+	return c;
+}
+
+extern "C" void bfcg_destroy(bfcg_ctx_t *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->prm.device);
+	(void)hipStreamSynchronize(c->st);
+	(void)hipFree(c->B.cnt1); (void)hipFree(c->B.cnt2); (void)hipFree(c->B.recs1); (void)hipFree(c->B.recs2);
+	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats);
+	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out);
+	(void)hipFree(c->d_seq); (void)hipFree(c->d_qual); (void)hipHostFree(c->h_stats);
+	for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
+	(void)hipStreamDestroy(c->st);
+	free(c);
+}
+
+extern "C" int bfcg_reset(bfcg_ctx_t *c)
+{
+	HIPCK(hipSetDevice(c->prm.device));
+	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
+	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
+	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
+	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N, c->st));
+	c->n_batches = 0;
+	return 0;
+}
+
+extern "C" int bfcg_sync(bfcg_ctx_t *c) { HIPCK(hipStreamSynchronize(c->st)); return 0; }
+
+// grow the table by one doubling and replay parked k-mers until none is left
+static int table_maintain(bfcg_ctx_t *c)
+{
+	KParams &P = c->P; BatchBufs &B = c->B;
+	for (;;) {
+		uint64_t slots = 1ULL << (P.l_pre + P.tab_cshift);
+		uint64_t ovf = c->h_stats[ST_TAB_OVF], keys = c->h_stats[ST_KEYS];
+		if (ovf == 0 && keys * 2 <= slots) return 0;
+		if (ovf > B.tab_ovf_cap) return set_err("count table overflow list exhausted (%llu parked k-mers)", (unsigned long long)ovf);
+		if (P.l_pre + P.tab_cshift + 1 > 36) return set_err("count table cannot grow beyond 2^36 slots");
+		int old_cshift = P.tab_cshift;
+		unsigned long long *nt = 0;
+		P.tab_cshift = old_cshift + 1;
+		HIPCK(hipMalloc(&nt, 8ULL << (P.l_pre + P.tab_cshift)));
+		HIPCK(hipMemsetAsync(nt, 0, 8ULL << (P.l_pre + P.tab_cshift), c->st));
+		run_table_rehash(P, B.table, old_cshift, nt, c->st);
+		HIPCK(hipStreamSynchronize(c->st));
+		HIPCK(hipFree(B.table));
+		B.table = nt;
+		if (ovf) {
+			uint64_t *tmp = 0;
+			HIPCK(hipMalloc(&tmp, ovf * 24));
+			HIPCK(hipMemcpyAsync(tmp, B.tab_ovf, ovf * 24, hipMemcpyDeviceToDevice, c->st));
+			HIPCK(hipMemsetAsync(&B.stats[ST_TAB_OVF], 0, 8, c->st));
+			run_table_replay(P, B.table, tmp, ovf, B.stats, B.tab_ovf, B.tab_ovf_cap, c->st);
+			HIPCK(hipMemcpyAsync(c->h_stats, B.stats, sizeof(unsigned long long) * ST_N, hipMemcpyDeviceToHost, c->st));
+			HIPCK(hipStreamSynchronize(c->st));
+			HIPCK(hipFree(tmp));
+		} else c->h_stats[ST_TAB_OVF] = 0;
+	}
+}
+
+extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
+{
+	if (n_pos == 0) return 0;
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	HIPCK(hipSetDevice(c->prm.device));
+	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
+	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
+	run_batch(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, c->st, c->ev);
+	HIPCK(hipGetLastError());
+	HIPCK(hipMemcpyAsync(c->h_stats, c->B.stats, sizeof(unsigned long long) * ST_N, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	++c->n_batches;
+	for (int i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
+	HIPCK(hipEventElapsedTime(&c->last_ms[4], c->ev[0], c->ev[4]));
+	if (c->h_stats[ST_ERR_POOL]) return set_err("first-setter pool exhausted in %llu bloom regions: batch too large for max_batch_pos", (unsigned long long)c->h_stats[ST_ERR_POOL]);
+	if (c->B.table) return table_maintain(c);
+	return 0;
+}
+
+extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)
+{
+	if (n_pos == 0) return 0;
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	HIPCK(hipSetDevice(c->prm.device));
+	HIPCK(hipMemcpyAsync(c->d_seq, h_seq, n_pos, hipMemcpyHostToDevice, c->st));
+	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual, h_qual, n_pos, hipMemcpyHostToDevice, c->st));
+	return bfcg_count_batch_dev(c, c->d_seq, h_qual ? c->d_qual : NULL, n_pos);
+}
+
+extern "C" void *bfcg_dev_alloc(bfcg_ctx_t *c, uint64_t bytes)
+{
+	void *p = 0;
+	if (hipSetDevice(c->prm.device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { set_err("hipMalloc(%llu) failed", (unsigned long long)bytes); return NULL; }
+	return p;
+}
+extern "C" void bfcg_dev_free(bfcg_ctx_t *c, void *p) { (void)c; (void)hipFree(p); }
+extern "C" int bfcg_h2d(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes)
+{ HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->st)); HIPCK(hipStreamSynchronize(c->st)); return 0; }
+extern "C" int bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes)
+{ HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->st)); HIPCK(hipStreamSynchronize(c->st)); return 0; }
+
+extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
+{
+	HIPCK(hipMemcpyAsync(c->h_stats, c->B.stats, sizeof(unsigned long long) * ST_N, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	for (int i = 0; i < BFCG_ST_N; ++i) out[i] = c->h_stats[i];
+	out[BFCG_ST_TAB_CSHIFT] = (uint64_t)c->P.tab_cshift;
+	out[BFCG_ST_BATCHES] = c->n_batches;
+	return 0;
+}
+
+extern "C" int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[5]) { for (int i = 0; i < 5; ++i) out[i] = c->last_ms[i]; return 0; }
+
+extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)
+{
+	unsigned long long *src = which ? c->B.bloom_hi : c->B.bloom;
+	if (!src) return set_err("bloom filter %d does not exist in this mode", which);
+	HIPCK(hipMemcpyAsync(dst, src, c->bloom_bytes, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which)
+{
+	bfc_bf_t *b = bfc_bf_init(c->P.bf_shift, c->P.n_hashes);
+	if (!b) return NULL;
+	if (bfcg_bloom_to_host(c, which, b->b) != 0) { bfc_bf_destroy(b); return NULL; }
+	return b;
+}
+
+extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
+{
+	if (!c->B.table) { set_err("no count table in filter mode"); return NULL; }
+	bfc_ch_t *ch = bfc_ch_alloc_raw(c->P.k, c->P.l_pre, c->P.tab_cshift);
+	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
+	if (hipMemcpyAsync(bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+	    hipStreamSynchronize(c->st) != hipSuccess) { set_err("D2H copy of the count table failed"); bfc_ch_destroy(ch); return NULL; }
+	bfc_ch_raw_recount(ch);
+	return ch;
+}
+
+extern "C" int bfcg_hash_positions(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos, uint64_t *out)
+{
+	if (n_pos > c->prm.max_batch_pos) return set_err("too many positions");
+	uint64_t *d_out = 0;
+	HIPCK(hipSetDevice(c->prm.device));
+	HIPCK(hipMalloc(&d_out, n_pos * 24));
+	HIPCK(hipMemcpyAsync(c->d_seq, h_seq, n_pos, hipMemcpyHostToDevice, c->st));
+	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual, h_qual, n_pos, hipMemcpyHostToDevice, c->st));
+	run_hash_only(c->P, c->d_seq, h_qual ? c->d_qual : NULL, (int64_t)n_pos, d_out, c->st);
+	HIPCK(hipGetLastError());
+	HIPCK(hipMemcpyAsync(out, d_out, n_pos * 24, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	HIPCK(hipFree(d_out));
+	return 0;
+}
+
+extern "C" int bfcg_seen_flags(bfcg_ctx_t *c, uint8_t *dst, uint64_t n_pos)
+{
+	if (!c->B.seen_out) return set_err("context was created without debug_seen");
+	HIPCK(hipMemcpyAsync(dst, c->B.seen_out, n_pos, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+// pinned host memory for the ingest double buffers (bfc_count.c)
+extern "C" void *bfcg_host_alloc(uint64_t bytes)
+{
+	void *p = 0;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc(%llu) failed", (unsigned long long)bytes); return NULL; }
+	return p;
+}
+extern "C" void bfcg_host_free(void *p) { if (p) (void)hipHostFree(p); }

@@ -1,0 +1,122 @@
+// kmer_dev.h -- device-side k-mer math for gfx950 (wave64).
+//
+// The reference rolls four k-bit planes per read, one base at a time (kmer.h:10-17,
+// count.c:81-88).  On the GPU every lane owns ONE end position of the batch's byte stream
+// instead: a workgroup turns its tile of ASCII bases into four packed bit-planes in LDS with
+// wave ballots (bit i of a word = position i, LSB first), and a lane obtains the planes of the
+// k-mer ending at position e as the k-bit WINDOW [e-k+1, e] of those bit streams:
+//     x2 = ~W(low-bit plane)  & m      (kmer.h:15: oldest base at bit 0, complemented)
+//     x3 = ~W(high-bit plane) & m      (kmer.h:16)
+//     x0 = bitreverse_k(W(low))        (kmer.h:13: newest base at bit 0)
+//     x1 = bitreverse_k(W(high))       (kmer.h:14)
+// A k-mer exists at e iff the window of the "not ACGT" plane is zero (count.c:83,86-87: l >= k),
+// and it is high quality iff the window of the "qual-33 >= q" plane is all ones (count.c:85-86).
+// No rolling state, no warm-up, perfectly coalesced lane->position mapping.
+//
+// W = uint32_t serves k <= 32 (all arithmetic of bfc_hash_64 is mod 2^k, so 32-bit registers
+// are exact), W = uint64_t serves k <= 63.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bfcg {
+
+template <typename W> __device__ __forceinline__ W kmask(int k)
+{
+	return k >= (int)(8 * sizeof(W)) ? ~W(0) : (W(1) << k) - 1;
+}
+
+// kmer.h:30-40 -- Thomas Wang mix, every sum reduced to k bits
+template <typename W> __device__ __forceinline__ W mix_k(W v, W m)
+{
+	v = (~v + (v << 21)) & m;
+	v ^= v >> 24;
+	v = (v + (v << 3) + (v << 8)) & m;
+	v ^= v >> 14;
+	v = (v + (v << 2) + (v << 4)) & m;
+	v ^= v >> 28;
+	v = (v + (v << 31)) & m;
+	return v;
+}
+
+__device__ __forceinline__ uint32_t brev_w(uint32_t v) { return __brev(v); }
+__device__ __forceinline__ uint64_t brev_w(uint64_t v) { return __brevll(v); }
+
+// k-bit window starting at bit `bit` of a packed LSB-first plane (plane must have 2 spare words)
+template <typename W> __device__ __forceinline__ W window(const uint32_t *plane, int bit, W m);
+template <> __device__ __forceinline__ uint32_t window<uint32_t>(const uint32_t *plane, int bit, uint32_t m)
+{
+	int wi = bit >> 5, s = bit & 31;
+	return __builtin_amdgcn_alignbit(plane[wi + 1], plane[wi], s) & m;
+}
+template <> __device__ __forceinline__ uint64_t window<uint64_t>(const uint32_t *plane, int bit, uint64_t m)
+{
+	int wi = bit >> 5, s = bit & 31;
+	uint32_t a = plane[wi], b = plane[wi + 1], c = plane[wi + 2];
+	uint32_t lo = __builtin_amdgcn_alignbit(b, a, s), hi = __builtin_amdgcn_alignbit(c, b, s);
+	return (((uint64_t)hi << 32) | lo) & m;
+}
+
+// kmer.h:79-88 from the two forward windows.  Outputs y0=(h0+h1)&m, y1=h1.
+template <typename W> __device__ __forceinline__ void kmer_hash_from_windows(int k, W w_lo, W w_hi, W m, W &y0, W &y1)
+{
+	const int nb = 8 * (int)sizeof(W);
+	W x0 = brev_w(w_lo) >> (nb - k), x1 = brev_w(w_hi) >> (nb - k);
+	W x2 = ~w_lo & m, x3 = ~w_hi & m;
+	int t = k >> 1;
+	bool rev = ((x1 >> t) & 1) > ((x3 >> t) & 1); // the middle base always differs between strands (odd k)
+	W a = rev ? x2 : x0, b = rev ? x3 : x1;
+	W h0 = mix_k<W>((a + b) & m, m);
+	W h1 = mix_k<W>(h0 ^ b, m);
+	y0 = (h0 + h1) & m;
+	y1 = h1;
+}
+
+// the bloom hash as a function of y (kmer.h:85-86 solved for h0): hash = (h0^h1)<<k | (h0+h1)&m
+template <typename W> __device__ __forceinline__ uint64_t bloom_hash(int k, W y0, W y1, W m)
+{
+	W h0 = (y0 - y1) & m;
+	return ((uint64_t)(h0 ^ y1) << k) | (uint64_t)y0;
+}
+
+// htab.c:45-58 -- sub-table index and slot key (count field preset to 1)
+__device__ __forceinline__ uint32_t ch_subkey(int k, int l_pre, uint64_t y0, uint64_t y1, uint64_t &key)
+{
+	if (k <= 32) {
+		int t = 2 * k - l_pre;
+		uint64_t z = (y0 << k) | y1;
+		key = ((z & ((1ULL << t) - 1)) << 14) | 1;
+		return (uint32_t)(z >> t);
+	} else {
+		int t = k - l_pre;
+		int sh = (t + k < 50) ? k : 50 - t;
+		key = ((((y0 & ((1ULL << t) - 1)) << sh) ^ y1) << 14) | 1;
+		return (uint32_t)(y0 >> t);
+	}
+}
+
+// bbf.c:27-41 -- block id and the n_hashes bit positions (8..511) inside the 512-bit block
+struct BloomAddr {
+	uint64_t blk;
+	uint32_t h1, h2;
+};
+__device__ __forceinline__ BloomAddr bloom_addr(uint64_t hash, int bf_shift)
+{
+	BloomAddr a;
+	int x = bf_shift - 9;
+	a.blk = hash & ((1ULL << x) - 1);
+	a.h1 = (uint32_t)(hash >> x) & 511u;
+	a.h2 = (uint32_t)(hash >> bf_shift) & 511u;
+	if ((a.h2 & 31u) == 0) a.h2 = (a.h2 + 1) & 511u;
+	return a;
+}
+// next position of the walk z = h1, h1+h2, ... (mod 512) that is not in the lock byte (z >= 8)
+__device__ __forceinline__ uint32_t bloom_next(uint32_t &z, uint32_t h2)
+{
+	while (z < 8) z = (z + h2) & 511u;
+	uint32_t r = z;
+	z = (z + h2) & 511u;
+	return r;
+}
+
+} // namespace bfcg

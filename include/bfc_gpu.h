@@ -1,0 +1,142 @@
+/* bfc_gpu.h -- C ABI of libbfc_gpu.so: MI355X-native k-mer counting for BFC.
+ *
+ * PART 1 is the drop-in boundary: exactly the symbols the reference's count.o + bbf.o + htab.o
+ * export, with the reference's argument meaning and error behaviour, so that an unmodified
+ * correct.c / bfc.c link against this library instead.  Each declaration cites
+ * the reference interface it replaces (paths relative to lh3/bfc r181).
+ *
+ * PART 2 is the device-level interface underneath (context, batches already resident in HBM,
+ * export), used by bench.py, the parity tests and multi-GPU orchestration.
+ *
+ * Plain C, plain pointers and sizes.  All counting work runs in HIP kernels on gfx950; there is
+ * no CPU fallback: without a usable GPU every entry point that has to count fails loudly
+ * ("[E::bfcg] ..." on stderr, then abort() for the reference-shaped entry points that have no
+ * error channel, or a negative return code for the bfcg_* ones).
+ */
+#ifndef BFC_GPU_H
+#define BFC_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ============================================================ PART 1: reference-shaped API */
+
+/* k-mer as four k-bit planes -- replaces kmer.h:6-8 */
+typedef struct { uint64_t x[4]; } bfc_kmer_t;
+
+/* blocked bloom filter -- replaces bbf.h:9-12.  The layout is public: correct.c:490 reads
+ * bf->n_hashes directly.  `b` is host memory (2^(n_shift-3) bytes, 64-byte aligned). */
+#define BFC_BLK_SHIFT 9
+#define BFC_BLK_MASK  ((1 << BFC_BLK_SHIFT) - 1)
+typedef struct { int n_shift, n_hashes; uint8_t *b; } bfc_bf_t;
+
+bfc_bf_t *bfc_bf_init(int n_shift, int n_hashes);      /* bbf.h:14, bbf.c:5   NULL if n_shift outside [9,55] */
+void      bfc_bf_destroy(bfc_bf_t *b);                 /* bbf.h:15, bbf.c:19 */
+int       bfc_bf_insert(bfc_bf_t *b, uint64_t hash);   /* bbf.h:16, bbf.c:25  returns # of bits already set */
+int       bfc_bf_get(const bfc_bf_t *b, uint64_t hash);/* bbf.h:17, bbf.c:47  thread-safe, read-only */
+
+/* k-mer count table -- replaces htab.h:10-23 (opaque) */
+#define BFC_CH_KEYBITS 50
+#define BFC_CH_MAXPRE  24
+struct bfc_ch_s;
+typedef struct bfc_ch_s bfc_ch_t;
+
+bfc_ch_t *bfc_ch_init(int k, int l_pre);                                               /* htab.c:19  */
+void      bfc_ch_destroy(bfc_ch_t *ch);                                                /* htab.c:36  */
+int       bfc_ch_insert(bfc_ch_t *ch, const uint64_t x[2], int is_high, int forced);   /* htab.c:60  0, or -1 if !forced and busy */
+int       bfc_ch_get(const bfc_ch_t *ch, const uint64_t x[2]);                         /* htab.c:84  -1 | high<<8|count; thread-safe */
+uint64_t  bfc_ch_count(const bfc_ch_t *ch);                                            /* htab.c:101 */
+int       bfc_ch_hist(const bfc_ch_t *ch, uint64_t cnt[256], uint64_t high[64]);       /* htab.c:110 returns the mode (i>=3) or -1 */
+int       bfc_ch_dump(const bfc_ch_t *ch, const char *fn);                             /* htab.c:129 0 | -1 */
+bfc_ch_t *bfc_ch_restore(const char *fn);                                              /* htab.c:151 NULL on failure */
+int       bfc_ch_get_k(const bfc_ch_t *ch);                                            /* htab.c:178 */
+int       bfc_ch_kmer_occ(const bfc_ch_t *ch, const bfc_kmer_t *z);                    /* htab.c:94  */
+
+/* options -- replaces bfc.h:15-33; field order and types are the ABI */
+typedef struct {
+	int chunk_size;
+	int n_threads, no_mt_io;
+	int q, k;
+	int filter_mode, refine_ec, no_qual;
+	float min_frac;
+	int l_pre, bf_shift, n_hashes;
+	int discard;
+	int max_end_ext;
+	int win_multi_ec;
+	int min_cov;
+	int w_ec, w_ec_high, w_absent, w_absent_high;
+	int max_path_diff, max_heap;
+} bfc_opt_t;
+
+/* the count phase -- replaces bfc.h:39 / count.c:127.  Returns a bfc_ch_t* (table mode) or the
+ * bfc_bf_t* holding k-mers seen at least twice (opt->filter_mode); the caller frees it with
+ * bfc_ch_destroy / bfc_bf_destroy (bfc.c:146,149).  fn may be "-" (stdin) or gzip'd. */
+void *bfc_count(const char *fn, const bfc_opt_t *opt);
+
+/* ============================================================ PART 2: device-level API */
+
+typedef struct bfcg_ctx bfcg_ctx_t;
+
+typedef struct {
+	int k, q, bf_shift, n_hashes, l_pre, filter_mode;  /* as bfc_opt_t */
+	int device;                 /* HIP device ordinal */
+	uint64_t max_batch_pos;     /* capacity: positions (bases + separators) per batch, < 2^32 */
+	int region_shift;           /* log2 bloom blocks per LDS region; 0 = default */
+	int tab_cshift;             /* initial log2 slots per sub-table; 0 = default */
+	int debug_seen;             /* allocate the per-position seen-flag buffer (tests) */
+} bfcg_params_t;
+
+void bfcg_params_default(bfcg_params_t *p);
+/* NULL on failure (message on stderr); never falls back to the CPU */
+bfcg_ctx_t *bfcg_create(const bfcg_params_t *p);
+void bfcg_destroy(bfcg_ctx_t *c);
+const char *bfcg_last_error(void);
+/* clear both bloom filters and the table */
+int bfcg_reset(bfcg_ctx_t *c);
+
+/* A batch is a byte stream: reads concatenated, each followed by ONE separator byte (any byte
+ * that is not ACGTacgt, e.g. '\n'); `qual` is the aligned Phred+33 stream or NULL (FASTA:
+ * every base counts as high quality, count.c:85).  Batches must be submitted in file order.
+ * _dev: the streams are already resident in HBM.  _host: pageable/pinned host memory, copied
+ * asynchronously.  Both return 0 or a negative error. */
+int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos);
+int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos);
+int bfcg_sync(bfcg_ctx_t *c);
+
+/* device memory helpers so that callers (bench.py) can stage inputs without another runtime */
+void *bfcg_dev_alloc(bfcg_ctx_t *c, uint64_t bytes);
+void  bfcg_dev_free(bfcg_ctx_t *c, void *p);
+int   bfcg_h2d(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes);
+int   bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes);
+void *bfcg_host_alloc(uint64_t bytes);   /* pinned host memory */
+void  bfcg_host_free(void *p);
+
+enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS,
+       BFCG_ST_TAB_CSHIFT = 8, BFCG_ST_BATCHES, BFCG_ST_N = 16 };
+int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
+
+/* per-stage GPU time of the last batch, HIP events on the context's stream (ms):
+ * [0] hist1 [1] scatter1 [2] hist2+scatter2 [3] bloom+table [4] total */
+int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[5]);
+
+/* results */
+int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *dst);   /* 2^(bf_shift-3) bytes */
+bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which);   /* host bfc_bf_t (caller: bfc_bf_destroy) */
+bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (caller: bfc_ch_destroy) */
+
+/* L1 form of a host table: sizes[2^l_pre]; slots (may be NULL) = per sub-table sorted */
+int      bfc_ch_get_lpre(const bfc_ch_t *ch);
+uint64_t bfc_ch_export_sorted(const bfc_ch_t *ch, uint32_t *sizes, uint64_t *slots);
+
+/* unit-test hooks: K1 only.  out = 3 u64 per position: y0, y1, flags (bit0 k-mer ends here, bit1 high) */
+int bfcg_hash_positions(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos, uint64_t *out);
+/* per-position seen flags of the last batch (debug_seen): 0 none, 1 not seen, 2 seen */
+int bfcg_seen_flags(bfcg_ctx_t *c, uint8_t *dst, uint64_t n_pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

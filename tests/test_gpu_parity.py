@@ -1,0 +1,181 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libbfc_gpu.so), against the
+CPU oracle on the same seeded inputs.  Bit-exact is the bar: this is integer/byte work.
+
+Parity levels:  L0 bloom bitmap memcmp-equal;  L1 per sub-table sorted slot lists
+equal (=> every bfc_ch_get / bfc_ch_hist / bfc_ch_count answer equal).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from bfc_amd import gen
+
+pytestmark = pytest.mark.gpu
+
+GOLD_G1 = {  # SURVEY B.3, captured from `bfc -t1`
+    (31, 26): dict(n_kmers=798319, n_high=584697, n_seen=486855, pop=1234155, fnv=0x3d61f9259600f794, distinct=99561, mode=4,
+                   l1="237be10261b07ef0677f8136b0a327b6"),
+    (33, 30): dict(n_kmers=784910, n_high=563486, n_seen=465683, pop=1276151, fnv=0x9df9ca3dbf6002bb, distinct=99119, mode=4,
+                   l1="896ce4092ccc51498b446e7d7775f10c"),
+}
+
+
+def _trace_to_positions(trace, seq, off, k, L_plus_sep=None):
+    """Oracle trace (one row per k-mer, file order) -> per-position arrays on the separator-delimited stream."""
+    lib = oracle.lib()
+    n_reads = len(off) - 1
+    n_pos = len(seq) + n_reads
+    y0 = np.zeros(n_pos, dtype=np.uint64); y1 = np.zeros(n_pos, dtype=np.uint64); fl = np.zeros(n_pos, dtype=np.uint8)
+    # end positions of k-mers in the stream: recompute validity per read on the CPU side
+    codes = np.full(256, 4, dtype=np.uint8)
+    for ch, c in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        codes[ch] = c
+    row = 0
+    for r in range(n_reads):
+        s = seq[int(off[r]):int(off[r + 1])]
+        valid = codes[s] < 4
+        run = 0
+        base = int(off[r]) + r
+        for i in range(len(s)):
+            run = run + 1 if valid[i] else 0
+            if run >= k:
+                y0[base + i] = trace[row, 1]; y1[base + i] = trace[row, 2]; fl[base + i] = 1 | (int(trace[row, 3]) << 1)
+                row += 1
+    assert row == len(trace)
+    return y0, y1, fl  # fl: bit0 k-mer, bit1 is_high, bit2 seen
+
+
+@pytest.mark.parametrize("k", [21, 31, 32, 33, 47, 51, 63])
+def test_k1_hash_positions(gpu_lib, g1, k):
+    """K1 (window k-mer extraction + strand-canonical hash + quality flag) vs count.c:72-89 / kmer.h:79-88."""
+    rs, (seq, qual, off) = g1
+    n = 300
+    seq, qual, off = seq[:n * rs.L].copy(), qual[:n * rs.L].copy(), off[:n + 1]
+    seq[5] = ord("n"); seq[rs.L * 3 + 40] = ord("a"); seq[rs.L * 3 + 41] = ord("t")  # lower case and a second break
+    oc = oracle.Counter(k, 26)
+    tr = oc.count(seq, qual, off, trace=True)
+    y0, y1, fl = _trace_to_positions(tr, seq, off, k)
+    g = gpu_lib.GpuCounter(k, 26, max_batch_pos=1 << 20)
+    s_seq, s_qual = gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off)
+    out = g.hash_positions(s_seq, s_qual)
+    assert np.array_equal(out[:, 2] & 1, fl & 1), "k-mer positions differ"
+    assert np.array_equal(out[:, 0], y0) and np.array_equal(out[:, 1], y1), "hash words differ"
+    assert np.array_equal((out[:, 2] >> 1) & 1, (fl >> 1) & 1), "is_high differs"
+    # FASTA: no qualities => every k-mer is high quality (count.c:85)
+    out2 = g.hash_positions(s_seq, None)
+    assert np.array_equal(out2[:, 2] & 1, out2[:, 2] >> 1)
+    g.close()
+
+
+def _gpu_count(gpu_lib, k, b, seq, qual, off, n_batches=1, **kw):
+    n_reads = len(off) - 1
+    L = int(off[1] - off[0])
+    per = (n_reads + n_batches - 1) // n_batches
+    g = gpu_lib.GpuCounter(k, b, max_batch_pos=per * (L + 1) + 64, **kw)
+    for i in range(0, n_reads, per):
+        j = min(n_reads, i + per)
+        o = off[i:j + 1] - off[i]
+        s = gpu_lib.to_stream(seq[int(off[i]):int(off[j])], o)
+        q = gpu_lib.to_stream(qual[int(off[i]):int(off[j])], o) if qual is not None else None
+        g.count_host(s, q)
+    return g
+
+
+@pytest.mark.parametrize("k,b", [(31, 26), (33, 30)])
+@pytest.mark.parametrize("n_batches", [1, 7])
+def test_g1_goldens(gpu_lib, g1, k, b, n_batches):
+    """Fixture g1 against the goldens captured from the compiled reference (`bfc -t1`), any batching."""
+    rs, (seq, qual, off) = g1
+    gold = GOLD_G1[(k, b)]
+    g = _gpu_count(gpu_lib, k, b, seq, qual, off, n_batches)
+    st = g.stats()
+    assert st["n_kmers"] == gold["n_kmers"] and st["n_high"] == gold["n_high"]
+    bits = g.bloom_bytes()
+    assert int(oracle.lib().orc_popcount_bytes(bits.ctypes.data, len(bits))) == gold["pop"]
+    assert int(oracle.lib().orc_fnv1a64(bits.ctypes.data, len(bits))) == gold["fnv"]   # L0
+    assert st["n_seen"] == gold["n_seen"]
+    t = g.export_table()
+    assert t.count() == gold["distinct"] == st["n_keys"]
+    mode, cnt, high = t.hist()
+    assert mode == gold["mode"]
+    sizes, slots = t.export_sorted()
+    assert oracle.l1_digest(sizes, slots) == gold["l1"]                                    # L1
+    g.close()
+
+
+@pytest.mark.parametrize("k,b,nh", [(31, 26, 4), (21, 22, 4), (33, 24, 3), (47, 26, 5), (51, 26, 4), (63, 28, 4), (32, 25, 4)])
+def test_vs_oracle_full(gpu_lib, g1, k, b, nh):
+    """Bloom bitmap (L0), per-k-mer seen flags, and the whole table (L1) vs the oracle, incl. the k>32 key
+    branch, the lossy k>=38 keys, l_pre clamping (k>=37 -> 24), even k, other n_hashes."""
+    rs, (seq, qual, off) = g1
+    n = 3000
+    seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
+    oc = oracle.Counter(k, b, n_hashes=nh)
+    tr = oc.count(seq, qual, off, trace=True)
+    g = _gpu_count(gpu_lib, k, b, seq, qual, off, 1, n_hashes=nh, debug_seen=True)
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    fl = g.seen_flags(len(seq) + n)
+    assert np.array_equal(fl[fl > 0] == 2, (tr[:, 3] >> 1) & 1 == 1), "seen flags differ from the sequential semantics"
+    ost = oc.stats(); st = g.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    t = g.export_table()
+    sizes, slots = t.export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    omode, ocnt, ohigh = oc.table_hist()
+    mode, cnt, high = t.hist()
+    assert mode == omode and np.array_equal(cnt, ocnt) and np.array_equal(high, ohigh)
+    # point queries through bfc_ch_get (htab.c:84-92): present and absent keys
+    for row in tr[:200]:
+        assert t.get(int(row[1]), int(row[2])) == oc.table_get(int(row[1]), int(row[2]))
+    assert t.get(1, 2) == oc.table_get(1, 2)
+    g.close()
+
+
+def test_tiny_bloom_forces_slow_path(gpu_lib, g1):
+    """A 2^14-bit bloom filter: one region, thousands of k-mers per block => LDS first-setter table overflows
+    and the HBM-pool path runs; results must not change."""
+    rs, (seq, qual, off) = g1
+    n = 2000
+    seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
+    for b in (14, 18):
+        oc = oracle.Counter(31, b)
+        oc.count(seq, qual, off)
+        g = _gpu_count(gpu_lib, 31, b, seq, qual, off, 1)
+        assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+        assert g.stats()["n_seen"] == oc.stats()["n_seen"]
+        sizes, slots = g.export_table().export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+        if b == 14:
+            assert g.stats()["slow_buckets"] > 0
+        g.close()
+
+
+def test_table_growth(gpu_lib, g1):
+    """Start with 2 slots per sub-table: overflow parking, growth and replay must keep L1."""
+    rs, (seq, qual, off) = g1
+    oc = oracle.Counter(31, 26, l_pre=10)
+    oc.count(seq, qual, off)
+    g = _gpu_count(gpu_lib, 31, 26, seq, qual, off, 3, l_pre=10, tab_cshift=1)
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    assert g.stats()["tab_cshift"] > 1
+    g.close()
+
+
+def test_filter_mode(gpu_lib, g1):
+    """-1 mode (count.c:148-154,67-68): both bloom filters vs the goldens of SURVEY B.3 (g1, k=51, b=26)."""
+    rs, (seq, qual, off) = g1
+    g = _gpu_count(gpu_lib, 51, 26, seq, qual, off, 2, filter_mode=1)
+    st = g.stats()
+    assert st["n_kmers"] == 664405 and st["n_seen"] == 301877
+    L = oracle.lib()
+    for which, (pop, fnv) in enumerate([(1434180, 0xd25fc72cd1ffffda), (364980, 0xafeb3dee4fc349c5)]):
+        bits = g.bloom_bytes(which)
+        assert int(L.orc_popcount_bytes(bits.ctypes.data, len(bits))) == pop
+        assert int(L.orc_fnv1a64(bits.ctypes.data, len(bits))) == fnv
+    g.close()
