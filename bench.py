@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the k-mer counting hot path (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (config c2 of BASELINE.json, the configuration the metric is quoted on): synthetic
+E. coli-sized genome (4.6 Mbp, seed 2) at 100x, 150 bp reads with 1 % substitutions, k=31, default
+1 GiB bloom filter (-b 33, -H 4), l_pre 20 -- 3.07 M reads, 368 M k-mers per GPU.  A *step* is one
+full count of that read set: reset of bloom filter + table, then every batch through
+hash -> scatter -> bloom regions -> count table, inputs already resident in HBM.
+
+One JSON line on stdout (rank 0).  `roofline` prices the bloom-region kernel (the kernel the
+north star names) at SURVEY 8(d)'s algorithmic 128 B per k-mer against 8 TB/s, from HIP-event
+time on the library's stream; `cpu_baseline` times the *reference binary* (oracle/_ref/bfc-ref,
+built in place from /root/reference) on a bounded sample of the same reads on this box's host
+cores.  The oracle is used nowhere in the timed path.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, BF_SHIFT, N_HASHES, L_PRE, Q = 31, 33, 4, 20, 20
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BLOOM_BYTES_PER_KMER = 128   # one 64-byte block read + write per k-mer (bbf.c:31)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(rs, n_cores):
+    """Reference `bfc -E -k31 -t<cores>` on a bounded read sample, net of its fixed setup."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "bfc-ref")
+    if not os.path.exists(ref):
+        return None
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    out = {}
+
+    def run(fq, t):
+        t0 = time.time()
+        r = subprocess.run([ref, "-E", "-k", str(K), "-b", str(BF_SHIFT), "-t", str(t), fq], capture_output=True, text=True)
+        m = re.search(r"Real time: ([0-9.]+) sec", r.stderr)
+        return float(m.group(1)) if m else time.time() - t0
+
+    one = os.path.join(shm, "bfc_bench_one.fq")
+    rs.fastq(one, 0, 1)
+    for label, t, n_reads in (("t1", 1, 60000), ("tN", n_cores, 1500000)):
+        fq = os.path.join(shm, "bfc_bench_%s.fq" % label)
+        n_reads = min(n_reads, rs.n_reads)
+        rs.fastq(fq, 0, n_reads)
+        seq, _, off = rs.reads(0, n_reads)
+        import numpy as np
+        kmers = count_kmers(seq, rs.L, K)
+        setup = run(one, t)
+        wall = run(fq, t)
+        net = max(wall - setup, 1e-3)
+        out[label] = dict(threads=t, reads=n_reads, kmers=int(kmers), wall_s=round(wall, 3), setup_s=round(setup, 3), mkmers_per_s=round(kmers / net / 1e6, 3))
+        os.unlink(fq)
+    os.unlink(one)
+    best = max(out.values(), key=lambda d: d["mkmers_per_s"])
+    return {"value": best["mkmers_per_s"], "unit": "M k-mers/s", "cores": best["threads"], "kind": "reference",
+            "sample": "oracle/_ref/bfc-ref -E -k31 -b33 -t%d on the first %d reads of the same synthetic set (%d k-mers), "
+                      "wall %.2fs minus %.2fs setup (1-read run)" % (best["threads"], best["reads"], best["kmers"], best["wall_s"], best["setup_s"]),
+            "t1_mkmers_per_s": out["t1"]["mkmers_per_s"], "detail": out}
+
+
+def count_kmers(seq, L, k):
+    """Number of bfc_kmer_insert calls: sum over ACGT runs of max(0, len-k+1) (vectorised, fixed-length reads)."""
+    import numpy as np
+    n = len(seq) // L
+    s = seq.reshape(n, L)
+    bad = ~np.isin(s, np.frombuffer(b"ACGTacgt", dtype=np.uint8))
+    total = n * (L - k + 1)
+    rows = np.nonzero(bad.any(axis=1))[0]
+    for r in rows:  # ~1 % of reads carry an N
+        run = 0; c = 0
+        for v in bad[r]:
+            run = 0 if v else run + 1
+            c += run >= k
+        total += c - (L - k + 1)
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-reads", type=int, default=int(os.environ.get("BFC_BENCH_BATCH_READS", 1 << 19)))
+    ap.add_argument("--cov", type=float, default=100.0, help="coverage of the 4.6 Mbp genome (100 = config c2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import numpy as np
+    import bfc_amd
+    from bfc_amd import gen, build
+    if rank == 0:
+        build.build()
+    if dist:
+        dist.barrier()
+
+    # ---- synthetic input (c2), one independent read set per rank (weak scaling: per-GPU work is fixed)
+    t0 = time.time()
+    rs = gen.ReadSet(seed=2 + rank, G=4_600_000, cov=args.cov, L=150, err=0.01)
+    seq, qual, off = rs.reads()
+    n_reads = rs.n_reads
+    n_kmers = count_kmers(seq, rs.L, K)
+    s_seq, s_qual = bfc_amd.to_stream(seq, off), bfc_amd.to_stream(qual, off)
+    stride = rs.L + 1
+    batch_reads = min(args.batch_reads, n_reads)
+    g = bfc_amd.GpuCounter(K, BF_SHIFT, q=Q, n_hashes=N_HASHES, l_pre=L_PRE, device=local, max_batch_pos=batch_reads * stride)
+    d_seq = g.dev_alloc(len(s_seq)); d_qual = g.dev_alloc(len(s_qual))
+    g.h2d(d_seq, s_seq); g.h2d(d_qual, s_qual)
+    del seq, qual
+    log("[bench] rank %d: %d reads, %d k-mers, input staged in HBM in %.1fs" % (rank, n_reads, n_kmers, time.time() - t0))
+
+    stage = dict(hist1=0.0, scatter1=0.0, level2=0.0, bloom=0.0, total=0.0)
+    n_launch = 0
+
+    def step(acc):
+        nonlocal n_launch
+        g.reset()
+        for r0 in range(0, n_reads, batch_reads):
+            r1 = min(n_reads, r0 + batch_reads)
+            g.count_dev(d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
+            if acc:
+                ms = g.last_batch_ms()
+                for kk in stage:
+                    stage[kk] += ms[kk]
+                n_launch += 1
+
+    def fence():
+        g.sync()
+        if dist:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        tk = torch.tensor([float(n_kmers)], device="cuda", dtype=torch.float64); dist.all_reduce(tk); total_kmers = float(tk.item())
+    else:
+        total_kmers = float(n_kmers)
+    st = g.stats()
+    assert st["n_kmers"] == n_kmers, "GPU k-mer count %d != host count %d" % (st["n_kmers"], n_kmers)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_kmers * args.steps / dt / 1e6
+        kmers_per_launch = n_kmers * args.steps / max(n_launch, 1)
+        bloom_ms = stage["bloom"] / max(n_launch, 1)
+        achieved = BLOOM_BYTES_PER_KMER * kmers_per_launch / (bloom_ms * 1e-3) / 1e9
+        res = {
+            "metric": "M k-mers/s counted (bloom+htab) on 150 bp reads", "value": round(value, 2), "unit": "M k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "c2: E. coli 100x 150 bp synthetic (bfcgen seed 2+rank, G=4.6M, 1%% subst.), k=31, -b33 -H4, l_pre 20, "
+                                   "bloom-insert + htab build; 1 step = reset + full count of %d reads / %d k-mers per GPU" % (n_reads, n_kmers),
+                       "batch_reads": batch_reads, "batches_per_step": (n_reads + batch_reads - 1) // batch_reads,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent read shards, one per GPU (no exchange yet)" % world,
+                       "n_seen": st["n_seen"], "n_distinct": st["n_keys"], "slow_buckets": st["slow_buckets"], "tab_cshift": st["tab_cshift"],
+                       "stage_ms_per_step": {kk: round(v / args.steps, 3) for kk, v in stage.items()}},
+            "roofline": {"bound": "hbm", "kernel": "k_bloom (bloom regions in LDS + exact seen + table upsert)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kmers_per_launch": int(kmers_per_launch), "avg_launch_ms": round(bloom_ms, 4),
+                         "algorithmic_bytes_per_kmer": BLOOM_BYTES_PER_KMER,
+                         "pipeline_frac": round(BLOOM_BYTES_PER_KMER * n_kmers * args.steps / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline(rs, os.cpu_count() or 1)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                log("[bench] cpu_baseline failed:", e)
+                cb = None
+            res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    g.dev_free(d_seq); g.dev_free(d_qual); g.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,18 +69,31 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	KParams &P = c->P;
 	P.k = prm->k; P.q = prm->q; P.bf_shift = prm->bf_shift; P.n_hashes = prm->n_hashes; P.filter_mode = prm->filter_mode;
 	P.l_pre = clamp_lpre(prm->k, prm->l_pre);
-	P.R = prm->region_shift > 0 ? prm->region_shift : 10;
-	if (P.R > 10) P.R = 10;
-	if (P.R > P.bf_shift - 9) P.R = P.bf_shift - 9;
-	P.F = P.bf_shift - 9 - P.R;
-	if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
-	else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
-	if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
-	// LDS budget of the bloom kernel: 160 KiB per workgroup
+	// geometry of the bloom kernel; environment overrides are tuning knobs, not semantics
 	{
-		size_t region = (size_t)64 << P.R, left = 160 * 1024 - 64 - region;
-		uint32_t fs = 1024; while ((size_t)fs * 2 * 8 + (size_t)fs * 2 * 3 <= left && fs < 8192) fs <<= 1; // list = 3/4 fs entries * 4 B
-		P.fs_cap = fs; P.list_cap = fs - fs / 4;
+		const char *e;
+		P.R = prm->region_shift > 0 ? prm->region_shift : ((e = getenv("BFCG_R")) ? atoi(e) : 9);
+		if (P.R > 10) P.R = 10;
+		if (P.R < 4) P.R = 4;
+		if (P.R > P.bf_shift - 9) P.R = P.bf_shift - 9;
+		P.F = P.bf_shift - 9 - P.R;
+		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
+		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
+		if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
+		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 512;
+		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 512;
+		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
+		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 512;
+		// LDS budget: half a CU (2 workgroups resident) unless the region alone needs more
+		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)(80 * 1024 - 128);
+		if (budget > 160 * 1024 - 128) budget = 160 * 1024 - 128;
+		if (region + 24 * 1024 > budget) budget = 160 * 1024 - 128;
+		size_t left = budget - region - (size_t)P.ag_cap * (P.k > 32 ? 20 : 12);
+		uint32_t fs = 512; while ((size_t)fs * 2 * 10 <= left && fs < 16384) fs <<= 1; // 8 B per entry + 2 B of list per entry
+		if ((e = getenv("BFCG_FS")) != 0) fs = (uint32_t)atoi(e);
+		P.fs_cap = fs;
+		P.list_cap = (uint32_t)((left - (size_t)fs * 8) / 4);
+		if (P.list_cap > (1u << 20) - 1) P.list_cap = (1u << 20) - 1;
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
 	c->rw = P.k <= 47 ? 2 : 3;
@@ -91,14 +104,23 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	const int nb1 = 1 << P.F1, nfine = 1 << P.F;
 	HIPCKN(hipStreamCreate(&c->st));
 	for (int i = 0; i < 5; ++i) HIPCKN(hipEventCreate(&c->ev[i]));
-	HIPCKN(hipMalloc(&B.cnt1, sizeof(uint32_t) * (nb1 + 1) * 3)); B.start1 = B.cnt1 + nb1 + 1; B.cursor1 = B.start1 + nb1 + 1;
-	HIPCKN(hipMalloc(&B.cnt2, sizeof(uint32_t) * (nfine + 1) * 3)); B.start2 = B.cnt2 + nfine + 1; B.cursor2 = B.start2 + nfine + 1;
+	{
+		const uint64_t tiles1 = (prm->max_batch_pos + BFCG_TILE1 - 1) / BFCG_TILE1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
+		const uint64_t rows2 = B.max_kmers / BFCG_TILE2 + nb1 + 1;
+		HIPCKN(hipMalloc(&B.rows1, sizeof(uint32_t) * tiles1 * nb1));
+		HIPCKN(hipMalloc(&B.chunk1, sizeof(uint32_t) * chunks1 * nb1));
+		HIPCKN(hipMalloc(&B.start1, sizeof(uint32_t) * (nb1 + 1) * 2)); B.row_base = B.start1 + nb1 + 1;
+		if (P.F2 > 0) {
+			HIPCKN(hipMalloc(&B.rows2, sizeof(uint32_t) * rows2 * (1u << P.F2)));
+			HIPCKN(hipMalloc(&B.start2, sizeof(uint32_t) * (nfine + 1)));
+		}
+	}
 	HIPCKN(hipMalloc(&B.recs1, B.max_kmers * c->rw * 8));
 	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, B.max_kmers * c->rw * 8));
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
 	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
-	HIPCKN(hipMalloc(&B.stats, sizeof(unsigned long long) * ST_N));
+	HIPCKN(hipMalloc(&B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1))); // last row: unslotted words
 	B.tab_ovf_cap = 1u << 20;
 	HIPCKN(hipMalloc(&B.tab_ovf, (uint64_t)B.tab_ovf_cap * 24));
 	// global first-setter pool for regions whose LDS table overflows: worst case every bucket overflows
@@ -109,7 +131,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
 	HIPCKN(hipMalloc(&c->d_seq, prm->max_batch_pos));
 	HIPCKN(hipMalloc(&c->d_qual, prm->max_batch_pos));
-	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N));
+	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 2)));
 	HIPCKN(set_bloom_lds_attr(P));
 	if (bfcg_reset(c) != 0) { bfcg_destroy(c); return NULL; }
 	return c;
@@ -120,7 +142,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	if (!c) return;
 	(void)hipSetDevice(c->prm.device);
 	(void)hipStreamSynchronize(c->st);
-	(void)hipFree(c->B.cnt1); (void)hipFree(c->B.cnt2); (void)hipFree(c->B.recs1); (void)hipFree(c->B.recs2);
+	(void)hipFree(c->B.rows1); (void)hipFree(c->B.chunk1); (void)hipFree(c->B.start1); (void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs1); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out);
 	(void)hipFree(c->d_seq); (void)hipFree(c->d_qual); (void)hipHostFree(c->h_stats);
@@ -135,8 +157,23 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
 	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
 	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
-	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N, c->st));
+	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
 	c->n_batches = 0;
+	return 0;
+}
+
+// bring the slotted counters to the host and fold them into h_stats[0..ST_N)
+static int fetch_stats(bfcg_ctx_t *c)
+{
+	unsigned long long *raw = c->h_stats + ST_N;
+	HIPCK(hipMemcpyAsync(raw, c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	for (int i = 0; i < ST_N; ++i) {
+		unsigned long long s = 0;
+		for (int j = 0; j < ST_SLOTS; ++j) s += raw[(size_t)j * ST_N + i];
+		c->h_stats[i] = s;
+	}
+	c->h_stats[ST_TAB_OVF] = raw[(size_t)ST_SLOTS * ST_N]; // the overflow list index is a single word
 	return 0;
 }
 
@@ -165,10 +202,9 @@ static int table_maintain(bfcg_ctx_t *c)
 			uint64_t *tmp = 0;
 			HIPCK(hipMalloc(&tmp, ovf * 24));
 			HIPCK(hipMemcpyAsync(tmp, B.tab_ovf, ovf * 24, hipMemcpyDeviceToDevice, c->st));
-			HIPCK(hipMemsetAsync(&B.stats[ST_TAB_OVF], 0, 8, c->st));
+			HIPCK(hipMemsetAsync(&B.stats[(size_t)ST_SLOTS * ST_N], 0, 8, c->st));
 			run_table_replay(P, B.table, tmp, ovf, B.stats, B.tab_ovf, B.tab_ovf_cap, c->st);
-			HIPCK(hipMemcpyAsync(c->h_stats, B.stats, sizeof(unsigned long long) * ST_N, hipMemcpyDeviceToHost, c->st));
-			HIPCK(hipStreamSynchronize(c->st));
+			if (fetch_stats(c) != 0) return -1;
 			HIPCK(hipFree(tmp));
 		} else c->h_stats[ST_TAB_OVF] = 0;
 	}
@@ -183,8 +219,7 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
 	run_batch(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, c->st, c->ev);
 	HIPCK(hipGetLastError());
-	HIPCK(hipMemcpyAsync(c->h_stats, c->B.stats, sizeof(unsigned long long) * ST_N, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
+	if (fetch_stats(c) != 0) return -1;
 	++c->n_batches;
 	for (int i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
 	HIPCK(hipEventElapsedTime(&c->last_ms[4], c->ev[0], c->ev[4]));
@@ -217,8 +252,7 @@ extern "C" int bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t byte
 
 extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
 {
-	HIPCK(hipMemcpyAsync(c->h_stats, c->B.stats, sizeof(unsigned long long) * ST_N, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
+	if (fetch_stats(c) != 0) return -1;
 	for (int i = 0; i < BFCG_ST_N; ++i) out[i] = c->h_stats[i];
 	out[BFCG_ST_TAB_CSHIFT] = (uint64_t)c->P.tab_cshift;
 	out[BFCG_ST_BATCHES] = c->n_batches;

@@ -1,12 +1,18 @@
 // bfcg_internal.h -- shared between the kernels (bfcg_kernels.hip) and the host context (bfcg_ctx.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#define BFCG_TILE1 4096
+#define BFCG_TILE2 2048
+#define BFCG_SCAN_CH 64
 #include <stdint.h>
 
 namespace bfcg {
 
 // statistics block in device memory (u64 counters)
 enum { ST_KMERS = 0, ST_HIGH, ST_SEEN, ST_KEYS, ST_TAB_OVF, ST_ERR_POOL, ST_SLOW_BUCKETS, ST_N = 16 };
+// counters are replicated ST_SLOTS times (one 128-byte row each) and summed on the host: a single hot
+// address costs ~12 ns per atomic chip-wide (MI355X_MICROARCH.md, row fanin)
+enum { ST_SLOTS = 256 };
 
 struct KParams {
 	int k, q, bf_shift, n_hashes, l_pre, filter_mode;
@@ -14,11 +20,15 @@ struct KParams {
 	int F, F1, F2;  // fine-bucket bits = bf_shift-9-R, split over two scatter levels (F2 == 0: one level)
 	int tab_cshift; // log2(slots per sub-table region)
 	uint32_t fs_cap, list_cap; // LDS first-setter table entries (pow2), unresolved-list entries
+	uint32_t ag_cap;            // LDS aggregation table entries (pow2)
+	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
+	int bloom_bt;               // threads per workgroup of the bloom kernel (256/512/1024)
 };
 
 struct BatchBufs {
-	uint32_t *cnt1, *start1, *cursor1;  // level-1 histogram / starts / cursors (2^F1 + 1)
-	uint32_t *cnt2, *start2, *cursor2;  // fine ...                             (2^F + 1)
+	uint32_t *rows1, *chunk1;           // level-1 histogram rows [tiles][2^F1] -> offsets; chunk sums
+	uint32_t *start1, *row_base;        // level-1 bucket starts (2^F1+1); first level-2 row per bucket (2^F1+1)
+	uint32_t *rows2, *start2;           // level-2 histogram rows [rows][2^F2] -> offsets; fine starts (2^F+1)
 	uint64_t *recs1, *recs2;            // record buffers, max_kmers * RW words each
 	uint64_t max_kmers;
 	unsigned long long *bloom, *bloom_hi, *table;

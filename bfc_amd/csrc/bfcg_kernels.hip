@@ -27,27 +27,75 @@ using namespace bfcg;
 
 // planes: [0] low base bit, [1] high base bit, [2] not-ACGT, [3] quality >= q
 // Covers positions [t0-64, t0+TILE); PLANE_WORDS = (TILE+64)/32 + 2 spare words per plane.
+// Fast path (16-byte aligned streams): every lane loads 16 bases + 16 qualities with one
+// dwordx4 each and writes four 16-bit plane pieces -- one load round per tile instead of a
+// latency-bound byte loop.  A=0 C=1 G=2 T=3 (bseq.c:9-26 minus one, count.c:82): with
+// u = ch & 0xDF, x = (u>>1)&3 gives A0 C1 G3 T2 and x^(x>>1) the code.
+__device__ __forceinline__ void bases16(uint32_t w, int sh, uint32_t &m0, uint32_t &m1, uint32_t &mn)
+{
+#pragma unroll
+	for (int b = 0; b < 4; ++b) {
+		uint32_t u = (w >> (8 * b)) & 0xDFu;
+		uint32_t x = (u >> 1) & 3u, code = x ^ (x >> 1);
+		bool ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+		m0 |= (code & 1u) << (sh + b); m1 |= (code >> 1) << (sh + b); mn |= (ok ? 0u : 1u) << (sh + b);
+	}
+}
+__device__ __forceinline__ void quals16(uint32_t w, int sh, int q, uint32_t &mq)
+{
+#pragma unroll
+	for (int b = 0; b < 4; ++b) mq |= (uint32_t)((int)((w >> (8 * b)) & 0xffu) - 33 >= q) << (sh + b);
+}
+
 template <int TILE, int BT>
 __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                              int64_t n_pos, int64_t t0, int q, uint32_t *planes)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
-	const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-	constexpr int NCH = (TILE + 64) / 64;
-	for (int c = wave; c < NCH; c += BT / WAVE) {
-		int64_t pos = t0 - 64 + (int64_t)c * 64 + lane;
-		bool in = pos >= 0 && pos < n_pos;
-		uint32_t ch = in ? seq[pos] : (uint32_t)'\n';
-		uint32_t u = ch & 0xDFu; // fold case
-		// A=0 C=1 G=2 T=3 (bseq.c:9-26 minus one, count.c:82); anything else is a break
-		uint32_t code = (u == 'A') ? 0u : (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 4u;
-		bool hq = qual ? (in && ((int)qual[pos] - 33 >= q)) : true; // count.c:85
-		uint64_t b0 = __ballot(code & 1u), b1 = __ballot((code >> 1) & 1u), bn = __ballot(code >> 2), bq = __ballot(hq);
-		if (lane == 0) {
-			planes[0 * PW + 2 * c] = (uint32_t)b0; planes[0 * PW + 2 * c + 1] = (uint32_t)(b0 >> 32);
-			planes[1 * PW + 2 * c] = (uint32_t)b1; planes[1 * PW + 2 * c + 1] = (uint32_t)(b1 >> 32);
-			planes[2 * PW + 2 * c] = (uint32_t)bn; planes[2 * PW + 2 * c + 1] = (uint32_t)(bn >> 32);
-			planes[3 * PW + 2 * c] = (uint32_t)bq; planes[3 * PW + 2 * c + 1] = (uint32_t)(bq >> 32);
+	const bool aligned = ((((uintptr_t)seq) | ((uintptr_t)qual)) & 15) == 0;
+	if (aligned) {
+		constexpr int NC16 = (TILE + 64) / 16;
+		unsigned short *p16 = reinterpret_cast<unsigned short *>(planes);
+		for (int c = threadIdx.x; c < NC16; c += BT) {
+			const int64_t pos = t0 - 64 + (int64_t)c * 16;
+			uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
+			if (pos >= 0 && pos + 16 <= n_pos) {
+				uint4 s = *reinterpret_cast<const uint4 *>(seq + pos);
+				bases16(s.x, 0, m0, m1, mn); bases16(s.y, 4, m0, m1, mn); bases16(s.z, 8, m0, m1, mn); bases16(s.w, 12, m0, m1, mn);
+				if (qual) {
+					uint4 v = *reinterpret_cast<const uint4 *>(qual + pos);
+					quals16(v.x, 0, q, mq); quals16(v.y, 4, q, mq); quals16(v.z, 8, q, mq); quals16(v.w, 12, q, mq);
+				} else mq = 0xffffu;
+			} else { // ragged ends of the batch
+				for (int b = 0; b < 16; ++b) {
+					const int64_t pb = pos + b;
+					const bool in = pb >= 0 && pb < n_pos;
+					uint32_t w = in ? seq[pb] : (uint32_t)'\n', t0m = 0, t1m = 0, tnm = 0;
+					bases16(w | 0x0a0a0a00u, 0, t0m, t1m, tnm);
+					m0 |= (t0m & 1u) << b; m1 |= (t1m & 1u) << b; mn |= (tnm & 1u) << b;
+					mq |= (uint32_t)(qual ? (in && ((int)qual[pb] - 33 >= q)) : 1) << b;
+				}
+			}
+			p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
+			p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
+		}
+	} else {
+		const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+		constexpr int NCH = (TILE + 64) / 64;
+		for (int c = wave; c < NCH; c += BT / WAVE) {
+			int64_t pos = t0 - 64 + (int64_t)c * 64 + lane;
+			bool in = pos >= 0 && pos < n_pos;
+			uint32_t ch = in ? seq[pos] : (uint32_t)'\n';
+			uint32_t u = ch & 0xDFu; // fold case
+			uint32_t code = (u == 'A') ? 0u : (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 4u;
+			bool hq = qual ? (in && ((int)qual[pos] - 33 >= q)) : true; // count.c:85
+			uint64_t b0 = __ballot(code & 1u), b1 = __ballot((code >> 1) & 1u), bn = __ballot(code >> 2), bq = __ballot(hq);
+			if (lane == 0) {
+				planes[0 * PW + 2 * c] = (uint32_t)b0; planes[0 * PW + 2 * c + 1] = (uint32_t)(b0 >> 32);
+				planes[1 * PW + 2 * c] = (uint32_t)b1; planes[1 * PW + 2 * c + 1] = (uint32_t)(b1 >> 32);
+				planes[2 * PW + 2 * c] = (uint32_t)bn; planes[2 * PW + 2 * c + 1] = (uint32_t)(bn >> 32);
+				planes[3 * PW + 2 * c] = (uint32_t)bq; planes[3 * PW + 2 * c + 1] = (uint32_t)(bq >> 32);
+			}
 		}
 	}
 	if (threadIdx.x < 8) planes[(threadIdx.x >> 1) * PW + PW - 2 + (threadIdx.x & 1)] = 0;
@@ -102,24 +150,29 @@ template <typename W> __device__ __forceinline__ uint32_t fine_id(const KParams 
 }
 
 // ------------------------------------------------------------------------------------------
-// pass A: level-1 histogram straight from the bases.  Persistent workgroups, LDS counters,
-// one global atomicAdd per (workgroup, non-empty bucket).
+// The partition is free of global atomics: every tile writes its histogram row, a small scan
+// turns the (tiles x buckets) matrix into absolute output offsets, and the scatter pass reads its
+// row back.  (A first version reserved space with one atomicAdd per tile and bucket on 128 cursor
+// words: 6.6 of 9.4 ms per step went into those atomics.)  Ranks inside a (tile, bucket) cell
+// still come from LDS atomics -- the order inside a bucket is irrelevant because every record
+// carries its file-order index.
 
+// pass A: level-1 histogram rows straight from the bases
 template <typename W, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_hist1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
-                                              int64_t n_pos, uint32_t *__restrict__ cnt1, unsigned long long *__restrict__ stats)
+                                              int64_t n_pos, uint32_t *__restrict__ rows1, unsigned long long *__restrict__ stats)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	__shared__ uint32_t planes[4 * PW];
 	__shared__ uint32_t hist[512];
 	const int nb1 = 1 << P.F1;
-	for (int i = threadIdx.x; i < nb1; i += BT) hist[i] = 0;
 	const W m = kmask<W>(P.k);
 	const int shift2 = P.F2;
 	uint32_t n_k = 0, n_h = 0;
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
 	for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		__syncthreads();
+		for (int i = threadIdx.x; i < nb1; i += BT) hist[i] = 0;
 		build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
 		__syncthreads();
 #pragma unroll 4
@@ -132,156 +185,186 @@ __global__ __launch_bounds__(BT) void k_hist1(KParams P, const uint8_t *__restri
 				++n_k; n_h += hi;
 			}
 		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < nb1; i += BT) rows1[tile * nb1 + i] = hist[i];
 	}
-	__syncthreads();
-	for (int i = threadIdx.x; i < nb1; i += BT)
-		if (hist[i]) atomicAdd(&cnt1[i], hist[i]);
 	// statistics: k-mers, high-quality k-mers
 	for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
-	if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[ST_KMERS], (unsigned long long)n_k); atomicAdd(&stats[ST_HIGH], (unsigned long long)n_h); }
+	if ((threadIdx.x & 63) == 0) {
+		unsigned long long *sl = stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+		atomicAdd(&sl[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl[ST_HIGH], (unsigned long long)n_h);
+	}
 }
 
-// exclusive prefix sum of n counts (n <= 2^18) by one workgroup; also zeroes the cursors
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, int n)
+// column scan of the level-1 matrix rows1[T][NB] in three small steps (chunks of SCAN_CH rows)
+#define SCAN_CH BFCG_SCAN_CH
+__global__ __launch_bounds__(256) void k_colsum(const uint32_t *__restrict__ rows, int T, int NB, uint32_t *__restrict__ chunk)
 {
-	__shared__ uint32_t part[1024];
-	const int per = (n + 1023) / 1024;
-	uint32_t s = 0;
-	for (int i = 0; i < per; ++i) { int j = threadIdx.x * per + i; if (j < n) s += cnt[j]; }
-	part[threadIdx.x] = s;
+	const int r0 = blockIdx.x * SCAN_CH, r1 = min(T, r0 + SCAN_CH);
+	for (int b = threadIdx.x; b < NB; b += 256) {
+		uint32_t s = 0;
+#pragma unroll 16
+		for (int r = r0; r < r1; ++r) s += rows[(size_t)r * NB + b];
+		chunk[(size_t)blockIdx.x * NB + b] = s;
+	}
+}
+// one workgroup: bucket totals -> start[NB+1]; chunk sums -> chunk offsets (in place);
+// row_base[NB+1] = first level-2 histogram row of each bucket (ceil(total/tile2) rows per bucket)
+__global__ __launch_bounds__(512) void k_scan_top(uint32_t *__restrict__ chunk, int n_chunks, int NB, uint32_t *__restrict__ start,
+                                                  uint32_t *__restrict__ row_base, int tile2)
+{
+	__shared__ uint32_t tot[512], rws[512];
+	const int b = threadIdx.x;
+	uint32_t total = 0;
+	if (b < NB) {
+#pragma unroll 16
+		for (int c = 0; c < n_chunks; ++c) total += chunk[(size_t)c * NB + b];
+	}
+	tot[b] = b < NB ? total : 0;
+	rws[b] = b < NB ? (total + tile2 - 1) / tile2 : 0;
 	__syncthreads();
-	for (int o = 1; o < 1024; o <<= 1) {
-		uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+	for (int o = 1; o < 512; o <<= 1) {
+		uint32_t v = b >= o ? tot[b - o] : 0, w = b >= o ? rws[b - o] : 0;
 		__syncthreads();
-		part[threadIdx.x] += v;
+		tot[b] += v; rws[b] += w;
 		__syncthreads();
 	}
-	uint32_t run = part[threadIdx.x] - s;
-	for (int i = 0; i < per; ++i) {
-		int j = threadIdx.x * per + i;
-		if (j < n) { start[j] = run; run += cnt[j]; if (cursor) cursor[j] = 0; }
+	if (b < NB) {
+		uint32_t run = tot[b] - total; // exclusive
+		start[b] = run;
+		row_base[b] = rws[b] - (total + tile2 - 1) / tile2;
+#pragma unroll 16
+		for (int c = 0; c < n_chunks; ++c) { uint32_t v = chunk[(size_t)c * NB + b]; chunk[(size_t)c * NB + b] = run; run += v; }
 	}
-	if (threadIdx.x == 1023) start[n] = part[1023];
+	if (b == NB - 1) { start[NB] = tot[b]; row_base[NB] = rws[b]; }
+}
+__global__ __launch_bounds__(256) void k_apply(uint32_t *__restrict__ rows, int T, int NB, const uint32_t *__restrict__ chunk)
+{
+	const int r0 = blockIdx.x * SCAN_CH, r1 = min(T, r0 + SCAN_CH);
+	for (int b = threadIdx.x; b < NB; b += 256) {
+		uint32_t run = chunk[(size_t)blockIdx.x * NB + b];
+#pragma unroll 16
+		for (int r = r0; r < r1; ++r) { uint32_t v = rows[(size_t)r * NB + b]; rows[(size_t)r * NB + b] = run; run += v; }
+	}
 }
 
-// ------------------------------------------------------------------------------------------
-// pass B: K1 again, records scattered to level-1 buckets.
-// Per tile: LDS counters give every record its rank inside (tile, bucket); one global atomicAdd
-// per (tile, non-empty bucket) reserves a contiguous run in the bucket; records are then stored
-// straight from registers (runs are contiguous, so the L2 merges the 16-byte stores).
-
+// pass B: K1 again, records stored straight from registers to rows1[tile][bucket] + rank
 template <typename W, int RW, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
-                                                 int64_t n_pos, const uint32_t *__restrict__ start1, uint32_t *__restrict__ cursor1,
-                                                 uint64_t *__restrict__ out)
+                                                 int64_t n_pos, const uint32_t *__restrict__ rows1, uint64_t *__restrict__ out)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	constexpr int S = TILE / BT;
 	__shared__ uint32_t planes[4 * PW];
-	__shared__ uint32_t cnt[512];
+	__shared__ uint32_t cnt[512], base[512];
 	const int nb1 = 1 << P.F1;
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
 	for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		__syncthreads();
-		for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0;
+		for (int i = threadIdx.x; i < nb1; i += BT) { cnt[i] = 0; base[i] = rows1[tile * nb1 + i]; }
 		build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
 		__syncthreads();
-		W ry0[S], ry1[S];
-		uint32_t rbr[S]; // bucket<<20 | rank<<1 | is_high ; 0xffffffff = no k-mer
-#pragma unroll
+#pragma unroll 4
 		for (int j = 0; j < S; ++j) {
 			int r = j * BT + threadIdx.x;
-			bool hi;
-			rbr[j] = 0xffffffffu;
-			if (kmer_at<W, TILE>(planes, r, P.k, m, ry0[j], ry1[j], hi)) {
-				uint32_t b = fine_id<W>(P, ry0[j], ry1[j]) >> P.F2;
-				uint32_t rank = atomicAdd(&cnt[b], 1u);
-				rbr[j] = (b << 20) | (rank << 1) | (uint32_t)hi;
-			}
-		}
-		__syncthreads();
-		for (int i = threadIdx.x; i < nb1; i += BT) {
-			uint32_t c = cnt[i];
-			cnt[i] = c ? start1[i] + atomicAdd(&cursor1[i], c) : 0;
-		}
-		__syncthreads();
-#pragma unroll
-		for (int j = 0; j < S; ++j) {
-			if (rbr[j] != 0xffffffffu) {
-				uint32_t b = rbr[j] >> 20, rank = (rbr[j] >> 1) & 0x7ffffu;
-				uint64_t dst = (uint64_t)cnt[b] + rank;
-				uint32_t idx = (uint32_t)(tile * TILE + j * BT + threadIdx.x); // end position = file order
-				Rec<RW>::pack(out + dst * RW, (uint64_t)ry0[j], (uint64_t)ry1[j], idx, rbr[j] & 1u);
+			W y0, y1; bool hi;
+			if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
+				uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
+				uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
+				uint32_t idx = (uint32_t)(tile * TILE + r); // end position = file order
+				Rec<RW>::pack(out + dst * RW, (uint64_t)y0, (uint64_t)y1, idx, hi);
 			}
 		}
 	}
 }
 
 // ------------------------------------------------------------------------------------------
-// level 2: histogram / scatter of one level-1 bucket (blockIdx.y) into its 2^F2 fine buckets
-
-template <typename W, int RW, int BT>
-__global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
-                                              uint32_t *__restrict__ cnt2)
-{
-	__shared__ uint32_t hist[512];
-	const int nb2 = 1 << P.F2, b1 = blockIdx.y;
-	const uint32_t s = start1[b1], e = start1[b1 + 1];
-	if (s == e) return;
-	for (int i = threadIdx.x; i < nb2; i += BT) hist[i] = 0;
-	__syncthreads();
-	for (uint64_t i = (uint64_t)s + blockIdx.x * BT + threadIdx.x; i < e; i += (uint64_t)gridDim.x * BT) {
-		uint64_t y0, y1; uint32_t idx; bool hi;
-		Rec<RW>::unpack(in + i * RW, y0, y1, idx, hi);
-		atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
-	}
-	__syncthreads();
-	for (int i = threadIdx.x; i < nb2; i += BT)
-		if (hist[i]) atomicAdd(&cnt2[((uint32_t)b1 << P.F2) + i], hist[i]);
-}
+// level 2: one level-1 bucket (blockIdx.y) into its 2^F2 fine buckets, tiles of TILE records.
+// Histogram rows of bucket b1 live at rows2[row_base[b1] + tile][2^F2].
 
 template <typename W, int RW, int TILE, int BT>
-__global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
-                                                 const uint32_t *__restrict__ start2, uint32_t *__restrict__ cursor2,
-                                                 uint64_t *__restrict__ out)
+__global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
+                                              const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2)
 {
-	constexpr int S = TILE / BT;
-	__shared__ uint32_t cnt[512];
+	__shared__ uint32_t hist[512];
 	const int nb2 = 1 << P.F2, b1 = blockIdx.y;
 	const uint32_t s = start1[b1], e = start1[b1 + 1];
 	const uint32_t n_tiles = (e - s + TILE - 1) / TILE;
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		__syncthreads();
-		for (int i = threadIdx.x; i < nb2; i += BT) cnt[i] = 0;
+		for (int i = threadIdx.x; i < nb2; i += BT) hist[i] = 0;
 		__syncthreads();
-		uint64_t w[S][RW];
-		uint32_t rbr[S];
 #pragma unroll
-		for (int j = 0; j < S; ++j) {
+		for (int j = 0; j < TILE / BT; ++j) {
 			uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
-			rbr[j] = 0xffffffffu;
 			if (i < e) {
 				uint64_t y0, y1; uint32_t idx; bool hi;
-#pragma unroll
-				for (int t = 0; t < RW; ++t) w[j][t] = in[i * RW + t];
-				Rec<RW>::unpack(w[j], y0, y1, idx, hi);
-				uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
-				rbr[j] = (b << 20) | atomicAdd(&cnt[b], 1u);
+				Rec<RW>::unpack(in + i * RW, y0, y1, idx, hi);
+				atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
 			}
 		}
 		__syncthreads();
-		for (int i = threadIdx.x; i < nb2; i += BT) {
-			uint32_t c = cnt[i], f = ((uint32_t)b1 << P.F2) + i;
-			cnt[i] = c ? start2[f] + atomicAdd(&cursor2[f], c) : 0;
-		}
+		uint32_t *row = rows2 + ((size_t)row_base[b1] + tile) * nb2;
+		for (int i = threadIdx.x; i < nb2; i += BT) row[i] = hist[i];
+	}
+}
+
+// one workgroup per level-1 bucket: column totals -> fine starts; rows -> absolute offsets in place
+__global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__restrict__ start1, const uint32_t *__restrict__ row_base,
+                                               uint32_t *__restrict__ rows2, uint32_t *__restrict__ start2)
+{
+	__shared__ uint32_t tot[512];
+	const int nb2 = 1 << P.F2, b1 = blockIdx.x, c = threadIdx.x;
+	const uint32_t r0 = row_base[b1], r1 = row_base[b1 + 1];
+	uint32_t total = 0;
+	if (c < nb2) {
+#pragma unroll 16
+		for (uint32_t r = r0; r < r1; ++r) total += rows2[(size_t)r * nb2 + c];
+	}
+	tot[c] = c < nb2 ? total : 0;
+	__syncthreads();
+	for (int o = 1; o < 512; o <<= 1) {
+		uint32_t v = c >= o ? tot[c - o] : 0;
+		__syncthreads();
+		tot[c] += v;
+		__syncthreads();
+	}
+	if (c < nb2) {
+		uint32_t run = start1[b1] + tot[c] - total;
+		start2[((size_t)b1 << P.F2) + c] = run;
+#pragma unroll 16
+		for (uint32_t r = r0; r < r1; ++r) { uint32_t v = rows2[(size_t)r * nb2 + c]; rows2[(size_t)r * nb2 + c] = run; run += v; }
+	}
+	if (b1 == (int)gridDim.x - 1 && c == 0) start2[(size_t)gridDim.x << P.F2] = start1[gridDim.x];
+}
+
+template <typename W, int RW, int TILE, int BT>
+__global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
+                                                 const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ rows2,
+                                                 uint64_t *__restrict__ out)
+{
+	__shared__ uint32_t cnt[512], base[512];
+	const int nb2 = 1 << P.F2, b1 = blockIdx.y;
+	const uint32_t s = start1[b1], e = start1[b1 + 1];
+	const uint32_t n_tiles = (e - s + TILE - 1) / TILE;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		__syncthreads();
+		const uint32_t *row = rows2 + ((size_t)row_base[b1] + tile) * nb2;
+		for (int i = threadIdx.x; i < nb2; i += BT) { cnt[i] = 0; base[i] = row[i]; }
 		__syncthreads();
 #pragma unroll
-		for (int j = 0; j < S; ++j) {
-			if (rbr[j] != 0xffffffffu) {
-				uint64_t dst = (uint64_t)cnt[rbr[j] >> 20] + (rbr[j] & 0xfffffu);
+		for (int j = 0; j < TILE / BT; ++j) {
+			uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
+			if (i < e) {
+				uint64_t w[RW], y0, y1; uint32_t idx; bool hi;
 #pragma unroll
-				for (int t = 0; t < RW; ++t) out[dst * RW + t] = w[j][t];
+				for (int t = 0; t < RW; ++t) w[t] = in[i * RW + t];
+				Rec<RW>::unpack(w, y0, y1, idx, hi);
+				uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
+				uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
+#pragma unroll
+				for (int t = 0; t < RW; ++t) out[dst * RW + t] = w[t];
 			}
 		}
 	}
@@ -291,27 +374,30 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
 // count table in HBM: 2^l_pre regions of 2^tab_cshift u64 slots, slot = key(50)<<14|high(6)<<8|count(8)
 // exactly as htab.c:7-17 stores it; empty = 0.  Home slot = low bits of key>>14 (as khash does),
 // linear probing confined to the region.  Saturating counters by CAS (htab.c:74-79).
+// An upsert carries (c, h) = number of bfc_ch_insert calls and how many of them were high quality:
+// count = min(255, #calls), high = min(63, #high calls) whatever the order (the first call stores
+// count 1 and high = is_high, htab.c:73-75), so pre-aggregated increments are exact.
 
-__device__ __forceinline__ void table_upsert(const KParams &P, unsigned long long *__restrict__ tab, uint64_t y0, uint64_t y1, bool hi,
-                                             unsigned long long *__restrict__ stats, uint64_t *__restrict__ ovf, uint32_t ovf_cap)
+__device__ __forceinline__ void table_upsert(const KParams &P, unsigned long long *__restrict__ tab, uint64_t y0, uint64_t y1,
+                                             uint32_t c, uint32_t h, unsigned long long *__restrict__ stats,
+                                             uint64_t *__restrict__ ovf, uint32_t ovf_cap, unsigned long long *__restrict__ ovf_cnt)
 {
 	uint64_t key;
 	uint32_t sub = ch_subkey(P.k, P.l_pre, y0, y1, key);
 	const uint32_t cmask = (1u << P.tab_cshift) - 1;
 	unsigned long long *reg = tab + ((uint64_t)sub << P.tab_cshift);
 	uint32_t pos = (uint32_t)(key >> 14) & cmask;
-	const unsigned long long fresh = key | ((uint64_t)hi << 8);
+	const unsigned long long fresh = (key & ~0x3fffULL) | (c < 255 ? c : 255) | ((uint64_t)(h < 63 ? h : 63) << 8);
 	for (uint32_t probe = 0; probe <= cmask; ++probe, pos = (pos + 1) & cmask) {
 		unsigned long long cur = __hip_atomic_load(&reg[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (cur == 0) {
 			cur = atomicCAS(&reg[pos], 0ULL, fresh);
-			if (cur == 0) { atomicAdd(&stats[ST_KEYS], 1ULL); return; }
+			if (cur == 0) { atomicAdd(&stats[ST_KEYS], 1ULL); return; } // stats already points at this workgroup's slot
 		}
 		if ((cur >> 14) == (key >> 14)) {
 			for (;;) {
-				unsigned long long nv = cur;
-				if ((nv & 0xff) != 0xff) ++nv;
-				if (hi && ((nv >> 8) & 0x3f) != 0x3f) nv += 1 << 8;
+				uint32_t nc = (uint32_t)(cur & 0xff) + c, nh = (uint32_t)((cur >> 8) & 0x3f) + h;
+				unsigned long long nv = (cur & ~0x3fffULL) | (nc < 255 ? nc : 255) | ((uint64_t)(nh < 63 ? nh : 63) << 8);
 				if (nv == cur) return;
 				unsigned long long old = atomicCAS(&reg[pos], cur, nv);
 				if (old == cur) return;
@@ -320,15 +406,16 @@ __device__ __forceinline__ void table_upsert(const KParams &P, unsigned long lon
 		}
 	}
 	// region full: park the k-mer; the host grows the table and replays (counts commute)
-	unsigned long long o = atomicAdd(&stats[ST_TAB_OVF], 1ULL);
-	if (o < ovf_cap) { ovf[3 * o] = y0; ovf[3 * o + 1] = y1; ovf[3 * o + 2] = hi; }
+	unsigned long long o = atomicAdd(ovf_cnt, 1ULL); // one chip-wide list index (rare path)
+	if (o < ovf_cap) { ovf[3 * o] = y0; ovf[3 * o + 1] = y1; ovf[3 * o + 2] = (uint64_t)c | ((uint64_t)h << 32); }
 }
 
 __global__ void k_table_replay(KParams P, unsigned long long *tab, const uint64_t *__restrict__ src, uint64_t n,
-                               unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap)
+                               unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, unsigned long long *ovf_cnt)
 {
+	stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		table_upsert(P, tab, src[3 * i], src[3 * i + 1], src[3 * i + 2] != 0, stats, ovf, ovf_cap);
+		table_upsert(P, tab, src[3 * i], src[3 * i + 1], (uint32_t)src[3 * i + 2], (uint32_t)(src[3 * i + 2] >> 32), stats, ovf, ovf_cap, ovf_cnt);
 }
 
 // grow: re-insert every occupied slot of the old table (cshift_old) into the new one (P.tab_cshift)
@@ -370,7 +457,7 @@ __device__ __forceinline__ bool fs_insert(unsigned long long *tab, uint32_t cap_
 	}
 	return false;
 }
-// returns the first setter's index, or 0xffffffff... if the bit has no entry (it was set before the batch)
+// true and the first setter's index if the bit has an entry (<=> it was clear before the batch)
 template <bool GLOBAL>
 __device__ __forceinline__ bool fs_lookup(const unsigned long long *tab, uint32_t cap_mask, uint32_t bitoff, uint32_t &first)
 {
@@ -390,16 +477,19 @@ struct BloomArgs {
 	unsigned long long *bloom_hi;  // second bloom filter (filter mode) or NULL
 	unsigned long long *table;     // count table or NULL
 	unsigned long long *stats;
-	uint64_t *tab_ovf; uint32_t tab_ovf_cap;
+	uint64_t *tab_ovf; uint32_t tab_ovf_cap; unsigned long long *ovf_cnt;
 	unsigned long long *pool; unsigned long long pool_cap; // global first-setter pool (entries)
 	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
 };
 
-template <typename W, int RW>
-__device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, uint64_t y0, uint64_t y1, bool hi, uint64_t hash)
+// what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
+template <typename W>
+__device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A, uint64_t y0, uint64_t y1, uint32_t c, uint32_t h)
 {
-	if (A.table) table_upsert(P, A.table, y0, y1, hi, A.stats, A.tab_ovf, A.tab_ovf_cap);
+	if (P.ablate & 1) return;
+	if (A.table) table_upsert(P, A.table, y0, y1, c, h, A.stats, A.tab_ovf, A.tab_ovf_cap, A.ovf_cnt);
 	else if (A.bloom_hi) { // count.c:67-68: second filter keeps k-mers seen at least twice (order independent)
+		uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, kmask<W>(P.k));
 		BloomAddr a = bloom_addr(hash, P.bf_shift);
 		unsigned int *blk = reinterpret_cast<unsigned int *>(A.bloom_hi) + a.blk * 16;
 		uint32_t z = a.h1;
@@ -407,20 +497,76 @@ __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, 
 	}
 }
 
-// LDS layout (dynamic): region 2^R*64 B | fs table FS_CAP*8 B | list LIST_CAP*4 B
+// LDS aggregation of seen k-mers: every occurrence of a k-mer lands in the same fine bucket, so a
+// small LDS table keyed by the k-mer folds the batch's occurrences into ONE table update.
+// id0 claims the slot by CAS; for k > 32 a second word id1 completes the identity.  A reader that
+// finds id0 equal but id1 not yet published cannot decide and simply takes the direct path
+// (always exact: updates commute).  cnt = occurrences | high-quality occurrences << 16.
+struct AggView { unsigned long long *id0, *id1; unsigned int *cnt; uint32_t mask; };
+
+template <typename W>
+__device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint64_t y0, uint64_t y1, bool hi)
+{
+	const bool two = sizeof(W) == 8;
+	const unsigned long long a = two ? y0 : ((y0 << P.k) | y1);
+	if (a == FS_EMPTY) return false;
+	uint32_t p = (uint32_t)((a * 0x9E3779B97F4A7C15ULL) >> 40) & G.mask;
+	for (int probe = 0; probe < 12; ++probe, p = (p + 1) & G.mask) {
+		unsigned long long cur = G.id0[p];
+		if (cur == FS_EMPTY) {
+			cur = atomicCAS(&G.id0[p], FS_EMPTY, a);
+			if (cur == FS_EMPTY) { // claimed
+				if (two) atomicExch(&G.id1[p], (unsigned long long)y1);
+				atomicAdd(&G.cnt[p], 1u | ((uint32_t)hi << 16));
+				return true;
+			}
+		}
+		if (cur == a) {
+			if (two) {
+				unsigned long long b = *(volatile unsigned long long *)&G.id1[p];
+				if (b == FS_EMPTY) return false; // identity not published yet
+				if (b != y1) continue;           // another k-mer sharing y0
+			}
+			unsigned int c = *(volatile unsigned int *)&G.cnt[p];
+			unsigned int inc = ((c & 0xffffu) < 4096u ? 1u : 0u) | ((hi && (c >> 16) < 4096u) ? (1u << 16) : 0u); // both saturate far below
+			if (inc) atomicAdd(&G.cnt[p], inc);
+			return true;
+		}
+	}
+	return false;
+}
+
+template <typename W>
+__device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, const AggView &G, uint64_t y0, uint64_t y1, bool hi)
+{
+	if (P.ablate & 2) return;
+	if (!agg_add<W>(P, G, y0, y1, hi)) commit_seen<W>(P, A, y0, y1, 1u, (uint32_t)hi);
+}
+
+// LDS layout (dynamic): region 2^R*64 B | fs table fs_cap*8 B | agg id0 ag_cap*8 [| id1 ag_cap*8] | agg cnt ag_cap*4 | list list_cap*4
 template <typename W, int RW, int BT>
 __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 {
+	if (P.ablate & 8) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ uint32_t s_list_n, s_fs_n, s_ovf, s_pool_off;
+	__shared__ uint32_t s_list_n, s_fs_n, s_ovf, s_pool_off, s_seen, s_pad[3];
 	const uint32_t f = blockIdx.x;
 	const uint32_t rs = A.start[f], n = A.start[f + 1] - rs;
 	if (n == 0) return;
+	A.stats += (size_t)(f & (ST_SLOTS - 1)) * ST_N; // statistics are slotted: no chip-wide single-address atomics
 	const int region_blocks = 1 << P.R;                 // P.R already clamped to bf_shift-9
 	const uint32_t region_dw = region_blocks * 16;
-	unsigned int *region = reinterpret_cast<unsigned int *>(smem);
-	unsigned long long *fs = reinterpret_cast<unsigned long long *>(smem + (size_t)region_dw * 4);
-	uint32_t *list = reinterpret_cast<uint32_t *>(smem + (size_t)region_dw * 4 + (size_t)P.fs_cap * 8);
+	constexpr bool two = sizeof(W) == 8;
+	unsigned char *sp = smem;
+	unsigned int *region = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
+	unsigned long long *fs = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.fs_cap * 8;
+	AggView G;
+	G.id0 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8;
+	G.id1 = G.id0;
+	if (two) { G.id1 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8; }
+	G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4;
+	G.mask = P.ag_cap - 1;
+	uint32_t *list = reinterpret_cast<uint32_t *>(sp);
 	const uint32_t fs_mask = P.fs_cap - 1;
 	const uint64_t *recs = A.recs + (uint64_t)rs * RW;
 	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
@@ -428,42 +574,70 @@ __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 	const uint32_t rmask = region_blocks - 1;
 	const int nh = P.n_hashes;
 
-	{ // stage the region (16-byte loads), clear the first-setter table
+	{ // stage the region (16-byte loads), clear the LDS tables
 		const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS_EMPTY;
-		if (threadIdx.x == 0) { s_list_n = 0; s_fs_n = 0; s_ovf = (n >= (1u << 20)) ? 1u : 0u; }
+		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) { G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[i] = 0; }
+		if (threadIdx.x == 0) { s_list_n = 0; s_fs_n = 0; s_seen = 0; s_ovf = (n >= (1u << 20)) ? 1u : 0u; }
 	}
-	__syncthreads();
 
 	uint32_t n_seen = 0;
 	const uint32_t fs_limit = (P.fs_cap >> 1) + (P.fs_cap >> 2); // keep probing short; racing inserts overshoot by < BT
 	volatile uint32_t *v_ovf = &s_ovf, *v_fs_n = &s_fs_n;
-	// ---- pass 1: classify every k-mer against the pre-batch region
-	for (uint32_t i = threadIdx.x; i < n; i += BT) {
-		uint64_t y0, y1; uint32_t idx; bool hi;
-		Rec<RW>::unpack(recs + (uint64_t)i * RW, y0, y1, idx, hi);
-		uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, m);
-		BloomAddr a = bloom_addr(hash, P.bf_shift);
-		const uint32_t bl = (uint32_t)a.blk & rmask;
-		uint32_t z = a.h1, um = 0;
-		for (int j = 0; j < nh; ++j) {
-			uint32_t b = bloom_next(z, a.h2);
-			if (!((region[bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) um |= 1u << j;
+	// ---- pass 1: classify every k-mer against the pre-batch region.  Records are fetched PF per thread
+	// and one round ahead, so their HBM latency overlaps the LDS work of the previous round.
+	constexpr int PF = 4;
+	uint64_t nxt[PF][RW];
+#pragma unroll
+	for (int u = 0; u < PF; ++u) {
+		uint32_t i = threadIdx.x + u * BT;
+		if (i < n) {
+#pragma unroll
+			for (int t = 0; t < RW; ++t) nxt[u][t] = recs[(uint64_t)i * RW + t];
 		}
-		if (um == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
-			++n_seen;
-			if (A.seen_out) A.seen_out[idx] = 2;
-			emit_seen<W, RW>(P, A, y0, y1, hi, hash);
-		} else if (!*v_ovf) {
-			uint32_t li = atomicAdd(&s_list_n, 1u);
-			if (li < P.list_cap) list[li] = i | (um << 20); else *v_ovf = 1;
-			z = a.h1;
+	}
+	__syncthreads(); // region staged, tables cleared
+	for (uint32_t base = 0; base < n; base += BT * PF) {
+		uint64_t cur[PF][RW];
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+#pragma unroll
+			for (int t = 0; t < RW; ++t) cur[u][t] = nxt[u][t];
+			uint32_t i2 = base + BT * PF + threadIdx.x + u * BT;
+			if (i2 < n) {
+#pragma unroll
+				for (int t = 0; t < RW; ++t) nxt[u][t] = recs[(uint64_t)i2 * RW + t];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+			const uint32_t i = base + threadIdx.x + u * BT;
+			if (i >= n) continue;
+			uint64_t y0, y1; uint32_t idx; bool hi;
+			Rec<RW>::unpack(cur[u], y0, y1, idx, hi);
+			uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, m);
+			BloomAddr a = bloom_addr(hash, P.bf_shift);
+			const uint32_t bl = (uint32_t)a.blk & rmask;
+			uint32_t z = a.h1, um = 0;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, a.h2);
-				if ((um >> j) & 1u) {
-					if (*v_fs_n >= fs_limit || !fs_insert<false>(fs, fs_mask, bl * 512 + b, idx, &s_fs_n)) { *v_ovf = 1; break; }
+				if (!((region[bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) um |= 1u << j;
+			}
+			if (um == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
+				++n_seen;
+				if (A.seen_out) A.seen_out[idx] = 2;
+				emit_seen<W>(P, A, G, y0, y1, hi);
+			} else if (!*v_ovf) {
+				uint32_t li = atomicAdd(&s_list_n, 1u);
+				if (li < P.list_cap) list[li] = i | (um << 20); else *v_ovf = 1;
+				z = a.h1;
+				for (int j = 0; j < nh; ++j) {
+					uint32_t b = bloom_next(z, a.h2);
+					if ((um >> j) & 1u) {
+						if (*v_fs_n >= fs_limit || !fs_insert<false>(fs, fs_mask, bl * 512 + b, idx, &s_fs_n)) { *v_ovf = 1; break; }
+					}
 				}
 			}
 		}
@@ -493,7 +667,7 @@ __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 				}
 			}
 			if (A.seen_out) A.seen_out[idx] = first ? 1 : 2;
-			if (!first) { ++n_seen; emit_seen<W, RW>(P, A, y0, y1, hi, hash); }
+			if (!first) { ++n_seen; emit_seen<W>(P, A, G, y0, y1, hi); }
 		}
 	} else {
 		// ---- slow path: first-setter table in HBM (slice of the pool), sized by the region's bit count
@@ -544,7 +718,7 @@ __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 			}
 			if (unresolved) {
 				if (A.seen_out) A.seen_out[idx] = first ? 1 : 2;
-				if (!first) { ++n_seen; emit_seen<W, RW>(P, A, y0, y1, hi, hash); }
+				if (!first) { ++n_seen; emit_seen<W>(P, A, G, y0, y1, hi); }
 			}
 		}
 	}
@@ -554,8 +728,20 @@ __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 		const uint4 *src = reinterpret_cast<const uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 	}
+	// ---- flush the aggregated k-mers: one table update per distinct seen k-mer of this bucket
+	for (uint32_t p = threadIdx.x; p < P.ag_cap; p += BT) {
+		unsigned long long a = G.id0[p];
+		if (a == FS_EMPTY) continue;
+		unsigned int c = G.cnt[p];
+		uint64_t y0, y1;
+		if (two) { y0 = a; y1 = G.id1[p]; } else { y0 = a >> P.k; y1 = a & (uint64_t)m; }
+		commit_seen<W>(P, A, y0, y1, c & 0xffffu, c >> 16);
+	}
 	for (int o = 32; o; o >>= 1) n_seen += __shfl_down(n_seen, o);
-	if ((threadIdx.x & 63) == 0 && n_seen) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)n_seen);
+	if ((threadIdx.x & 63) == 0 && n_seen) atomicAdd(&s_seen, n_seen);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_seen) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)s_seen);
+	(void)s_pad;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -590,40 +776,41 @@ namespace bfcg {
 
 static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap); }
 
-#define TILE1 4096
+#define TILE1 BFCG_TILE1
 #define BT1 256
-#define TILE2 2048
+#define TILE2 BFCG_TILE2
 #define BT2 256
-#define BTB 1024
 
 template <typename W, int RW>
 static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev)
 {
 	const int nb1 = 1 << P.F1, nfine = 1 << P.F;
 	const int64_t tiles1 = (n_pos + TILE1 - 1) / TILE1;
-	hipMemsetAsync(B.cnt1, 0, sizeof(uint32_t) * (nb1 + 1), st);
+	const int n_chunks = (int)((tiles1 + SCAN_CH - 1) / SCAN_CH);
 	if (ev) hipEventRecord(ev[0], st);
-	hipLaunchKernelGGL((k_hist1<W, TILE1, BT1>), dim3(grid_for(tiles1, 2048)), dim3(BT1), 0, st, P, seq, qual, n_pos, B.cnt1, B.stats);
-	hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, B.cnt1, B.start1, B.cursor1, nb1);
+	hipLaunchKernelGGL((k_hist1<W, TILE1, BT1>), dim3(grid_for(tiles1, 1 << 20)), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.stats);
+	hipLaunchKernelGGL(k_colsum, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(512), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
+	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(grid_for(tiles1, 8192)), dim3(BT1), 0, st, P, seq, qual, n_pos, B.start1, B.cursor1, B.recs1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(grid_for(tiles1, 1 << 20)), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.recs1);
 	if (ev) hipEventRecord(ev[2], st);
 	const uint64_t *fine_recs = B.recs1; const uint32_t *fine_start = B.start1;
 	if (P.F2 > 0) {
-		hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (nfine + 1), st);
-		int gx = (int)((B.max_kmers / nb1) / (BT2 * 8) + 1); if (gx > 64) gx = 64;
-		hipLaunchKernelGGL((k_hist2<W, RW, BT2>), dim3(gx, nb1), dim3(BT2), 0, st, P, B.recs1, B.start1, B.cnt2);
-		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, B.cnt2, B.start2, B.cursor2, nfine);
-		int gx2 = (int)((B.max_kmers / nb1) / TILE2 + 1); if (gx2 > 256) gx2 = 256;
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(gx2, nb1), dim3(BT2), 0, st, P, B.recs1, B.start1, B.start2, B.cursor2, B.recs2);
+		int gx = (int)((B.max_kmers / nb1) / TILE2 + 1); if (gx > 1024) gx = 1024;
+		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(gx, nb1), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2);
+		hipLaunchKernelGGL(k_scan2, dim3(nb1), dim3(512), 0, st, P, B.start1, B.row_base, B.rows2, B.start2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(gx, nb1), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2, B.recs2);
 		fine_recs = B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
 	BloomArgs A;
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
-	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
-	size_t lds = ((size_t)64 << P.R) + (size_t)P.fs_cap * 8 + (size_t)P.list_cap * 4;
-	hipLaunchKernelGGL((k_bloom<W, RW, BTB>), dim3(nfine), dim3(BTB), lds, st, P, A);
+	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
+	size_t lds = (size_t)bloom_lds_bytes(P);
+	if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024>), dim3(nfine), dim3(1024), lds, st, P, A);
+	else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512>), dim3(nfine), dim3(512), lds, st, P, A);
+	else hipLaunchKernelGGL((k_bloom<W, RW, 256>), dim3(nfine), dim3(256), lds, st, P, A);
 	if (ev) hipEventRecord(ev[4], st);
 }
 
@@ -634,16 +821,24 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 	else run_batch_t<uint64_t, 3>(P, B, seq, qual, n_pos, st, ev);
 }
 
-int bloom_lds_bytes(const KParams &P) { return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 8 + (size_t)P.list_cap * 4); }
+int bloom_lds_bytes(const KParams &P)
+{
+	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 8 + (size_t)P.ag_cap * (P.k > 32 ? 20 : 12) + (size_t)P.list_cap * 4);
+}
 
+template <typename W, int RW> static hipError_t set_attr_t(int lds)
+{
+	hipError_t e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
 hipError_t set_bloom_lds_attr(const KParams &P)
 {
 	int lds = bloom_lds_bytes(P);
-	hipError_t e;
-	e = hipFuncSetAttribute((const void *)k_bloom<uint32_t, 2, BTB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<uint64_t, 2, BTB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<uint64_t, 3, BTB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-	return e;
+	if (P.k <= 32) return set_attr_t<uint32_t, 2>(lds);
+	if (P.k <= 47) return set_attr_t<uint64_t, 2>(lds);
+	return set_attr_t<uint64_t, 3>(lds);
 }
 
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st)
@@ -656,7 +851,7 @@ void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, in
 void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
 {
 	int g = (int)((n + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
-	hipLaunchKernelGGL(k_table_replay, dim3(g), dim3(256), 0, st, P, tab, src, n, stats, ovf, ovf_cap);
+	hipLaunchKernelGGL(k_table_replay, dim3(g), dim3(256), 0, st, P, tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N);
 }
 void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab, hipStream_t st)
 {

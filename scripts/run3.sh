@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
+{
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -5
+for cfg in "BFCG_R=9 BFCG_BT=512" "BFCG_R=9 BFCG_BT=1024" "BFCG_R=10 BFCG_BT=1024 BFCG_LDS=163000" "BFCG_R=8 BFCG_BT=256 BFCG_LDS=40000" "BFCG_R=8 BFCG_BT=512"; do
+  for br in 524288 1048576 3100000; do
+    echo "== $cfg batch_reads=$br"
+    env $cfg python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch-reads $br 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d['config']['slow_buckets'], d['roofline']['frac'])"
+  done
+done
+} > gpurun_out/run3.log 2>&1
+cat gpurun_out/run3.log

@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
+{
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+for cfg in "BFCG_ABLATE=0" "BFCG_ABLATE=24" "BFCG_ABLATE=40" "BFCG_ABLATE=56" ; do
+  for br in 524288 ; do
+    echo "== $cfg batch_reads=$br"
+    env $cfg python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch-reads $br 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d['config']['slow_buckets'], d['roofline']['frac'])"
+  done
+done
+} > gpurun_out/run5.log 2>&1
+cat gpurun_out/run5.log
