@@ -129,7 +129,7 @@ def main():
     del seq, qual
     log("[bench] rank %d: %d reads, %d k-mers, input staged in HBM in %.1fs" % (rank, n_reads, n_kmers, time.time() - t0))
 
-    stage = dict(hist1=0.0, scatter1=0.0, level2=0.0, bloom=0.0, total=0.0)
+    stage = dict(hist1=0.0, scatter1=0.0, level2=0.0, bloom=0.0, commit=0.0, total=0.0)
     n_launch = 0
 
     def step(acc):
@@ -183,7 +183,7 @@ def main():
                                    "bloom-insert + htab build; 1 step = reset + full count of %d reads / %d k-mers per GPU" % (n_reads, n_kmers),
                        "batch_reads": batch_reads, "batches_per_step": (n_reads + batch_reads - 1) // batch_reads,
                        "parallelism": "1 GPU" if world == 1 else "%d independent read shards, one per GPU (no exchange yet)" % world,
-                       "n_seen": st["n_seen"], "n_distinct": st["n_keys"], "slow_buckets": st["slow_buckets"], "tab_cshift": st["tab_cshift"],
+                       "phase_cycles": st.get("phase_cycles"), "n_seen": st["n_seen"], "n_distinct": st["n_keys"], "slow_buckets": st["slow_buckets"], "tab_cshift": st["tab_cshift"],
                        "stage_ms_per_step": {kk: round(v / args.steps, 3) for kk, v in stage.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_bloom (bloom regions in LDS + exact seen + table upsert)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -252,12 +252,14 @@ class GpuCounter:
     def stats(self):
         out = np.zeros(16, dtype=np.uint64)
         self._ck(self.L.bfcg_stats(self.ctx, out.ctypes.data_as(u64p)))
-        return {STAT_NAMES[i]: int(out[i]) for i in STAT_NAMES}
+        d = {STAT_NAMES[i]: int(out[i]) for i in STAT_NAMES}
+        d["phase_cycles"] = [int(out[i]) for i in range(10, 15)]  # BFCG_ABLATE&64: k_bloom stage/pass1/pass2/writeback/handover
+        return d
 
     def last_batch_ms(self):
-        out = np.zeros(5, dtype=np.float32)
+        out = np.zeros(6, dtype=np.float32)
         self.L.bfcg_last_batch_ms(self.ctx, out.ctypes.data_as(f32p))
-        return dict(hist1=float(out[0]), scatter1=float(out[1]), level2=float(out[2]), bloom=float(out[3]), total=float(out[4]))
+        return dict(hist1=float(out[0]), scatter1=float(out[1]), level2=float(out[2]), bloom=float(out[3]), commit=float(out[4]), total=float(out[5]))
 
     def bloom_bytes(self, which=0):
         out = np.empty(1 << (self.bf_shift - 3), dtype=np.uint8)

@@ -28,11 +28,11 @@ struct bfcg_ctx {
 	KParams P;
 	BatchBufs B;
 	hipStream_t st;
-	hipEvent_t ev[5];
+	hipEvent_t ev[6];
 	uint8_t *d_seq, *d_qual;     // staging for host batches
 	unsigned long long *h_stats; // pinned mirror
 	uint64_t n_batches;
-	float last_ms[5];
+	float last_ms[6];
 	int rw;                      // u64 words per record
 	uint64_t bloom_bytes;
 };
@@ -83,11 +83,12 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 512;
 		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 512;
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
+		P.bloom_pf = (e = getenv("BFCG_PF")) ? atoi(e) : 4;
 		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 512;
 		// LDS budget: half a CU (2 workgroups resident) unless the region alone needs more
-		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)(80 * 1024 - 128);
-		if (budget > 160 * 1024 - 128) budget = 160 * 1024 - 128;
-		if (region + 24 * 1024 > budget) budget = 160 * 1024 - 128;
+		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)(80 * 1024 - 1024);
+		if (budget > 160 * 1024 - 1024) budget = 160 * 1024 - 1024;
+		if (region + 24 * 1024 > budget) budget = 160 * 1024 - 1024;
 		size_t left = budget - region - (size_t)P.ag_cap * (P.k > 32 ? 20 : 12);
 		uint32_t fs = 512; while ((size_t)fs * 2 * 10 <= left && fs < 16384) fs <<= 1; // 8 B per entry + 2 B of list per entry
 		if ((e = getenv("BFCG_FS")) != 0) fs = (uint32_t)atoi(e);
@@ -103,7 +104,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	B.max_kmers = prm->max_batch_pos;
 	const int nb1 = 1 << P.F1, nfine = 1 << P.F;
 	HIPCKN(hipStreamCreate(&c->st));
-	for (int i = 0; i < 5; ++i) HIPCKN(hipEventCreate(&c->ev[i]));
+	for (int i = 0; i < 6; ++i) HIPCKN(hipEventCreate(&c->ev[i]));
 	{
 		const uint64_t tiles1 = (prm->max_batch_pos + BFCG_TILE1 - 1) / BFCG_TILE1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
 		const uint64_t rows2 = B.max_kmers / BFCG_TILE2 + nb1 + 1;
@@ -129,6 +130,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	if (B.pool_cap > (1ULL << 31)) B.pool_cap = 1ULL << 31; // 16 GiB ceiling; exhaustion is reported, never silent
 	HIPCKN(hipMalloc(&B.pool, (B.pool_cap + 1) * 8));
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
+	if (!getenv("BFCG_INLINE_COMMIT")) {
+		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * 24));
+		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
+	}
 	HIPCKN(hipMalloc(&c->d_seq, prm->max_batch_pos));
 	HIPCKN(hipMalloc(&c->d_qual, prm->max_batch_pos));
 	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 2)));
@@ -144,9 +149,9 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipStreamSynchronize(c->st);
 	(void)hipFree(c->B.rows1); (void)hipFree(c->B.chunk1); (void)hipFree(c->B.start1); (void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs1); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats);
-	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out);
+	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipFree(c->d_seq); (void)hipFree(c->d_qual); (void)hipHostFree(c->h_stats);
-	for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
 	(void)hipStreamDestroy(c->st);
 	free(c);
 }
@@ -221,8 +226,8 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 	HIPCK(hipGetLastError());
 	if (fetch_stats(c) != 0) return -1;
 	++c->n_batches;
-	for (int i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
-	HIPCK(hipEventElapsedTime(&c->last_ms[4], c->ev[0], c->ev[4]));
+	for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
+	HIPCK(hipEventElapsedTime(&c->last_ms[5], c->ev[0], c->ev[5]));
 	if (c->h_stats[ST_ERR_POOL]) return set_err("first-setter pool exhausted in %llu bloom regions: batch too large for max_batch_pos", (unsigned long long)c->h_stats[ST_ERR_POOL]);
 	if (c->B.table) return table_maintain(c);
 	return 0;
@@ -259,7 +264,7 @@ extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
 	return 0;
 }
 
-extern "C" int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[5]) { for (int i = 0; i < 5; ++i) out[i] = c->last_ms[i]; return 0; }
+extern "C" int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[6]) { for (int i = 0; i < 6; ++i) out[i] = c->last_ms[i]; return 0; }
 
 extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)
 {

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #define BFCG_TILE1 4096
-#define BFCG_TILE2 2048
+#define BFCG_TILE2 8192
 #define BFCG_SCAN_CH 64
 #include <stdint.h>
 
@@ -22,6 +22,7 @@ struct KParams {
 	uint32_t fs_cap, list_cap; // LDS first-setter table entries (pow2), unresolved-list entries
 	uint32_t ag_cap;            // LDS aggregation table entries (pow2)
 	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
+	int bloom_pf;               // records per thread kept in registers by the bloom kernel (2/4)
 	int bloom_bt;               // threads per workgroup of the bloom kernel (256/512/1024)
 };
 
@@ -36,6 +37,7 @@ struct BatchBufs {
 	uint64_t *tab_ovf; uint32_t tab_ovf_cap;
 	unsigned long long *pool; unsigned long long pool_cap;
 	uint8_t *seen_out;
+	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
 };
 
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev);

@@ -443,15 +443,15 @@ __global__ void k_table_rehash(KParams P, const unsigned long long *__restrict__
 // first-setter table: entry = bit offset inside the region (high 32) | k-mer index (low 32);
 // atomicMin keeps, per bit, the earliest k-mer (file order) that finds the bit clear.
 template <bool GLOBAL>
-__device__ __forceinline__ bool fs_insert(unsigned long long *tab, uint32_t cap_mask, uint32_t bitoff, uint32_t idx, uint32_t *n_used)
+__device__ __forceinline__ bool fs_insert(unsigned long long *tab, uint32_t cap_mask, uint32_t bitoff, uint32_t idx, uint32_t max_probe)
 {
 	const unsigned long long e = ((unsigned long long)bitoff << 32) | idx;
 	uint32_t p = ((bitoff * 0x9E3779B1u) >> 12 ^ bitoff) & cap_mask; // low bits of a multiplicative hash are weak: fold the high half in
-	for (uint32_t probe = 0; probe <= cap_mask; ++probe, p = (p + 1) & cap_mask) {
+	for (uint32_t probe = 0; probe <= max_probe; ++probe, p = (p + 1) & cap_mask) {
 		unsigned long long cur = GLOBAL ? __hip_atomic_load(&tab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[p];
 		if (cur == FS_EMPTY) {
 			cur = atomicCAS(&tab[p], FS_EMPTY, e);
-			if (cur == FS_EMPTY) { if (n_used) atomicAdd(n_used, 1u); return true; }
+			if (cur == FS_EMPTY) return true;
 		}
 		if ((uint32_t)(cur >> 32) == bitoff) { if (e < cur) atomicMin(&tab[p], e); return true; }
 	}
@@ -480,6 +480,8 @@ struct BloomArgs {
 	uint64_t *tab_ovf; uint32_t tab_ovf_cap; unsigned long long *ovf_cnt;
 	unsigned long long *pool; unsigned long long pool_cap; // global first-setter pool (entries)
 	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
+	uint64_t *agg_out;             // aggregated seen k-mers: [n_fine][ag_cap][3] (y0, y1, count|high<<16), or NULL = commit inline
+	uint32_t *agg_cnt;             // entries per fine bucket
 };
 
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
@@ -543,16 +545,36 @@ __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, 
 	if (!agg_add<W>(P, G, y0, y1, hi)) commit_seen<W>(P, A, y0, y1, 1u, (uint32_t)hi);
 }
 
+// one k-mer record of the bloom kernel, decoded
+struct KRec { uint64_t y0, y1; uint32_t idx, bl, h1, h2; bool hi; };
+
+template <typename W, int RW>
+__device__ __forceinline__ KRec decode_rec(const KParams &P, const uint64_t *w, W m, uint32_t rmask)
+{
+	KRec r;
+	Rec<RW>::unpack(w, r.y0, r.y1, r.idx, r.hi);
+	BloomAddr a = bloom_addr(bloom_hash<W>(P.k, (W)r.y0, (W)r.y1, m), P.bf_shift);
+	r.bl = (uint32_t)a.blk & rmask; r.h1 = a.h1; r.h2 = a.h2;
+	return r;
+}
+
 // LDS layout (dynamic): region 2^R*64 B | fs table fs_cap*8 B | agg id0 ag_cap*8 [| id1 ag_cap*8] | agg cnt ag_cap*4 | list list_cap*4
-template <typename W, int RW, int BT>
-__global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
+//
+// Latency structure (measured with SQ_WAIT_ANY: a workgroup used to wait 63 % of its life): every
+// exposed HBM round trip counts because only two workgroups fit a CU.  Hence (i) the region and the
+// first PF records per thread are requested together; (ii) k-mers with clear bits stay in the
+// registers of the thread that classified them (no list, no second read) -- only records beyond the
+// first round use the LDS list; (iii) the aggregated seen k-mers are not upserted here: they are
+// streamed to `agg_out` (fire and forget) and k_commit applies them at full occupancy.
+template <typename W, int RW, int BT, int PF>
+__global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ uint32_t s_list_n, s_fs_n, s_ovf, s_pool_off, s_seen, s_pad[3];
+	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_seen, s_agg_n, s_pad[3];
 	const uint32_t f = blockIdx.x;
 	const uint32_t rs = A.start[f], n = A.start[f + 1] - rs;
-	if (n == 0) return;
+	if (n == 0) { if (threadIdx.x == 0 && A.agg_cnt) A.agg_cnt[f] = 0; return; }
 	A.stats += (size_t)(f & (ST_SLOTS - 1)) * ST_N; // statistics are slotted: no chip-wide single-address atomics
 	const int region_blocks = 1 << P.R;                 // P.R already clamped to bf_shift-9
 	const uint32_t region_dw = region_blocks * 16;
@@ -574,101 +596,107 @@ __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 	const uint32_t rmask = region_blocks - 1;
 	const int nh = P.n_hashes;
 
+	const bool timing = (P.ablate & 64) && threadIdx.x == 0;
+	long long tq[6] = {0, 0, 0, 0, 0, 0};
+	if (timing) tq[0] = clock64();
+	uint64_t r0w[PF][RW];      // round-0 records stay in registers until pass 2
+	uint32_t r0um[PF];
+#pragma unroll
+	for (int u = 0; u < PF; ++u) {
+		uint32_t i = threadIdx.x + u * BT;
+		r0um[u] = 0;
+		if (i < n) {
+#pragma unroll
+			for (int t = 0; t < RW; ++t) r0w[u][t] = recs[(uint64_t)i * RW + t];
+		}
+	}
 	{ // stage the region (16-byte loads), clear the LDS tables
 		const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS_EMPTY;
 		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) { G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[i] = 0; }
-		if (threadIdx.x == 0) { s_list_n = 0; s_fs_n = 0; s_seen = 0; s_ovf = (n >= (1u << 20)) ? 1u : 0u; }
+		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = (n >= (1u << 20)) ? 1u : 0u; }
 	}
+	__syncthreads();
+	if (timing) tq[1] = clock64();
 
 	uint32_t n_seen = 0;
-	const uint32_t fs_limit = (P.fs_cap >> 1) + (P.fs_cap >> 2); // keep probing short; racing inserts overshoot by < BT
-	volatile uint32_t *v_ovf = &s_ovf, *v_fs_n = &s_fs_n;
-	// ---- pass 1: classify every k-mer against the pre-batch region.  Records are fetched PF per thread
-	// and one round ahead, so their HBM latency overlaps the LDS work of the previous round.
-	constexpr int PF = 4;
-	uint64_t nxt[PF][RW];
+	volatile uint32_t *v_ovf = &s_ovf; // set when the LDS list or the LDS first-setter table (48 probes) cannot take a k-mer
+
+	// classify one k-mer against the pre-batch region; returns the mask of its clear bits
+	auto classify = [&](const KRec &r) -> uint32_t {
+		uint32_t z = r.h1, um = 0;
+		for (int j = 0; j < nh; ++j) {
+			uint32_t b = bloom_next(z, r.h2);
+			if (!((region[r.bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) um |= 1u << j;
+		}
+		if (um == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
+			++n_seen;
+			if (A.seen_out) A.seen_out[r.idx] = 2;
+			emit_seen<W>(P, A, G, r.y0, r.y1, r.hi);
+		} else if (!*v_ovf) {
+			z = r.h1;
+			for (int j = 0; j < nh; ++j) {
+				uint32_t b = bloom_next(z, r.h2);
+				if (((um >> j) & 1u) && !fs_insert<false>(fs, fs_mask, r.bl * 512 + b, r.idx, 48)) { *v_ovf = 1; break; }
+			}
+		}
+		return um;
+	};
+	// decide a k-mer with clear bits: seen iff an earlier k-mer of the batch sets each of them; set the bits
+	auto resolve = [&](const KRec &r, uint32_t um) {
+		uint32_t z = r.h1; bool first = false;
+		for (int j = 0; j < nh; ++j) {
+			uint32_t b = bloom_next(z, r.h2);
+			if ((um >> j) & 1u) {
+				uint32_t fi = 0xffffffffu;
+				fs_lookup<false>(fs, fs_mask, r.bl * 512 + b, fi);
+				first |= (fi == r.idx);
+				atomicOr(&region[r.bl * 16 + (b >> 5)], 1u << (b & 31));
+			}
+		}
+		if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
+		if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi); }
+	};
+
+	// ---- pass 1, round 0 (registers)
 #pragma unroll
 	for (int u = 0; u < PF; ++u) {
-		uint32_t i = threadIdx.x + u * BT;
-		if (i < n) {
-#pragma unroll
-			for (int t = 0; t < RW; ++t) nxt[u][t] = recs[(uint64_t)i * RW + t];
-		}
+		const uint32_t i = threadIdx.x + u * BT;
+		if (i < n) r0um[u] = classify(decode_rec<W, RW>(P, r0w[u], m, rmask));
 	}
-	__syncthreads(); // region staged, tables cleared
-	for (uint32_t base = 0; base < n; base += BT * PF) {
-		uint64_t cur[PF][RW];
+	// ---- pass 1, further rounds (buckets larger than BT*PF): LDS list of record indices
+	for (uint32_t i = threadIdx.x + BT * PF; i < n; i += BT) {
+		uint64_t w[RW];
 #pragma unroll
-		for (int u = 0; u < PF; ++u) {
-#pragma unroll
-			for (int t = 0; t < RW; ++t) cur[u][t] = nxt[u][t];
-			uint32_t i2 = base + BT * PF + threadIdx.x + u * BT;
-			if (i2 < n) {
-#pragma unroll
-				for (int t = 0; t < RW; ++t) nxt[u][t] = recs[(uint64_t)i2 * RW + t];
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < PF; ++u) {
-			const uint32_t i = base + threadIdx.x + u * BT;
-			if (i >= n) continue;
-			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(cur[u], y0, y1, idx, hi);
-			uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, m);
-			BloomAddr a = bloom_addr(hash, P.bf_shift);
-			const uint32_t bl = (uint32_t)a.blk & rmask;
-			uint32_t z = a.h1, um = 0;
-			for (int j = 0; j < nh; ++j) {
-				uint32_t b = bloom_next(z, a.h2);
-				if (!((region[bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) um |= 1u << j;
-			}
-			if (um == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
-				++n_seen;
-				if (A.seen_out) A.seen_out[idx] = 2;
-				emit_seen<W>(P, A, G, y0, y1, hi);
-			} else if (!*v_ovf) {
-				uint32_t li = atomicAdd(&s_list_n, 1u);
-				if (li < P.list_cap) list[li] = i | (um << 20); else *v_ovf = 1;
-				z = a.h1;
-				for (int j = 0; j < nh; ++j) {
-					uint32_t b = bloom_next(z, a.h2);
-					if ((um >> j) & 1u) {
-						if (*v_fs_n >= fs_limit || !fs_insert<false>(fs, fs_mask, bl * 512 + b, idx, &s_fs_n)) { *v_ovf = 1; break; }
-					}
-				}
-			}
+		for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
+		uint32_t um = classify(decode_rec<W, RW>(P, w, m, rmask));
+		if (um && !*v_ovf) {
+			uint32_t li = atomicAdd(&s_list_n, 1u);
+			if (li < P.list_cap) list[li] = i | (um << 20); else *v_ovf = 1;
 		}
 	}
 	__syncthreads();
+	if (timing) tq[2] = clock64();
 
 	bool dirty = true;
 	if (!s_ovf) {
-		dirty = s_list_n != 0;
-		// ---- pass 2 (fast): k-mers with clear bits; seen iff an earlier k-mer of the batch sets each of them
+		// ---- pass 2 (fast)
+		uint32_t any = 0;
+#pragma unroll
+		for (int u = 0; u < PF; ++u)
+			if (r0um[u]) { any = 1; resolve(decode_rec<W, RW>(P, r0w[u], m, rmask), r0um[u]); }
 		const uint32_t ln = s_list_n;
 		for (uint32_t li = threadIdx.x; li < ln; li += BT) {
 			uint32_t i = list[li] & 0xfffffu, um = list[li] >> 20;
-			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(recs + (uint64_t)i * RW, y0, y1, idx, hi);
-			uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, m);
-			BloomAddr a = bloom_addr(hash, P.bf_shift);
-			const uint32_t bl = (uint32_t)a.blk & rmask;
-			uint32_t z = a.h1; bool first = false;
-			for (int j = 0; j < nh; ++j) {
-				uint32_t b = bloom_next(z, a.h2);
-				if ((um >> j) & 1u) {
-					uint32_t fi = 0xffffffffu;
-					fs_lookup<false>(fs, fs_mask, bl * 512 + b, fi);
-					first |= (fi == idx);
-					atomicOr(&region[bl * 16 + (b >> 5)], 1u << (b & 31));
-				}
-			}
-			if (A.seen_out) A.seen_out[idx] = first ? 1 : 2;
-			if (!first) { ++n_seen; emit_seen<W>(P, A, G, y0, y1, hi); }
+			uint64_t w[RW];
+#pragma unroll
+			for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
+			resolve(decode_rec<W, RW>(P, w, m, rmask), um);
+			any = 1;
 		}
+		dirty = __syncthreads_or((int)any) != 0;
 	} else {
 		// ---- slow path: first-setter table in HBM (slice of the pool), sized by the region's bit count
 		uint64_t want = (uint64_t)n * nh * 2;
@@ -689,59 +717,93 @@ __global__ __launch_bounds__(BT) void k_bloom(KParams P, BloomArgs A)
 		__syncthreads();
 		const uint32_t gmask = cap - 1;
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(recs + (uint64_t)i * RW, y0, y1, idx, hi);
-			uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, m);
-			BloomAddr a = bloom_addr(hash, P.bf_shift);
-			const uint32_t bl = (uint32_t)a.blk & rmask;
-			uint32_t z = a.h1;
+			uint64_t w[RW];
+#pragma unroll
+			for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
+			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			uint32_t z = r.h1;
 			for (int j = 0; j < nh; ++j) {
-				uint32_t b = bloom_next(z, a.h2);
-				if (!((region[bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) fs_insert<true>(gfs, gmask, bl * 512 + b, idx, nullptr);
+				uint32_t b = bloom_next(z, r.h2);
+				if (!((region[r.bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) fs_insert<true>(gfs, gmask, r.bl * 512 + b, r.idx, gmask);
 			}
 		}
 		__threadfence();
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(recs + (uint64_t)i * RW, y0, y1, idx, hi);
-			uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, m);
-			BloomAddr a = bloom_addr(hash, P.bf_shift);
-			const uint32_t bl = (uint32_t)a.blk & rmask;
-			uint32_t z = a.h1; bool first = false, unresolved = false;
+			uint64_t w[RW];
+#pragma unroll
+			for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
+			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			uint32_t z = r.h1; bool first = false, unresolved = false;
 			for (int j = 0; j < nh; ++j) {
-				uint32_t b = bloom_next(z, a.h2), fi;
-				if (fs_lookup<true>(gfs, gmask, bl * 512 + b, fi)) { // has an entry <=> was clear before the batch
-					unresolved = true; first |= (fi == idx);
-					atomicOr(&region[bl * 16 + (b >> 5)], 1u << (b & 31));
+				uint32_t b = bloom_next(z, r.h2), fi;
+				if (fs_lookup<true>(gfs, gmask, r.bl * 512 + b, fi)) { // has an entry <=> was clear before the batch
+					unresolved = true; first |= (fi == r.idx);
+					atomicOr(&region[r.bl * 16 + (b >> 5)], 1u << (b & 31));
 				}
 			}
 			if (unresolved) {
-				if (A.seen_out) A.seen_out[idx] = first ? 1 : 2;
-				if (!first) { ++n_seen; emit_seen<W>(P, A, G, y0, y1, hi); }
+				if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
+				if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi); }
 			}
 		}
+		__syncthreads();
 	}
-	__syncthreads();
+	if (timing) tq[3] = clock64();
 	if (dirty) { // write the region back
 		uint4 *dst = reinterpret_cast<uint4 *>(g_region);
 		const uint4 *src = reinterpret_cast<const uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 	}
-	// ---- flush the aggregated k-mers: one table update per distinct seen k-mer of this bucket
-	for (uint32_t p = threadIdx.x; p < P.ag_cap; p += BT) {
-		unsigned long long a = G.id0[p];
-		if (a == FS_EMPTY) continue;
-		unsigned int c = G.cnt[p];
-		uint64_t y0, y1;
-		if (two) { y0 = a; y1 = G.id1[p]; } else { y0 = a >> P.k; y1 = a & (uint64_t)m; }
-		commit_seen<W>(P, A, y0, y1, c & 0xffffu, c >> 16);
+	if (timing) tq[4] = clock64();
+	// ---- hand the aggregated k-mers over: compacted into this bucket's slice of agg_out (k_commit applies them)
+	for (uint32_t p0 = 0; p0 < P.ag_cap; p0 += BT) {
+		const uint32_t p = p0 + threadIdx.x;
+		unsigned long long a = p < P.ag_cap ? G.id0[p] : FS_EMPTY;
+		const bool used = a != FS_EMPTY;
+		const unsigned long long vote = __ballot(used);
+		const int lane = threadIdx.x & 63;
+		uint32_t o0 = 0;
+		if (vote) {
+			if (lane == __ffsll((long long)vote) - 1) o0 = atomicAdd(&s_agg_n, (uint32_t)__popcll(vote));
+			o0 = __shfl(o0, __ffsll((long long)vote) - 1);
+		}
+		if (used) {
+			const uint32_t o = o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1));
+			unsigned int c = G.cnt[p];
+			uint64_t y0, y1;
+			if (two) { y0 = a; y1 = G.id1[p]; } else { y0 = a >> P.k; y1 = a & (uint64_t)m; }
+			if (A.agg_out) {
+				uint64_t *dst = A.agg_out + ((uint64_t)f * P.ag_cap + o) * 3;
+				dst[0] = y0; dst[1] = y1; dst[2] = c;
+			} else commit_seen<W>(P, A, y0, y1, c & 0xffffu, c >> 16);
+		}
 	}
 	for (int o = 32; o; o >>= 1) n_seen += __shfl_down(n_seen, o);
 	if ((threadIdx.x & 63) == 0 && n_seen) atomicAdd(&s_seen, n_seen);
 	__syncthreads();
-	if (threadIdx.x == 0 && s_seen) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)s_seen);
+	if (threadIdx.x == 0) {
+		if (s_seen) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)s_seen);
+		if (A.agg_cnt) A.agg_cnt[f] = s_agg_n;
+	}
+	if (timing) {
+		tq[5] = clock64();
+		for (int t = 0; t < 5; ++t) atomicAdd(&A.stats[10 + t], (unsigned long long)(tq[t + 1] - tq[t]));
+	}
 	(void)s_pad;
+}
+
+// apply the aggregated k-mers of every bucket: one thread per slot of agg_out, full occupancy
+template <typename W>
+__global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
+{
+	const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
+	const uint32_t f = (uint32_t)(gid / P.ag_cap), j = (uint32_t)(gid % P.ag_cap);
+	if (f >= (1u << P.F) || j >= A.agg_cnt[f]) return;
+	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+	const uint64_t *src = A.agg_out + gid * 3;
+	const uint32_t c = (uint32_t)src[2];
+	commit_seen<W>(P, A, src[0], src[1], c & 0xffffu, c >> 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -779,7 +841,7 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 #define TILE1 BFCG_TILE1
 #define BT1 256
 #define TILE2 BFCG_TILE2
-#define BT2 256
+#define BT2 512
 
 template <typename W, int RW>
 static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev)
@@ -807,11 +869,18 @@ static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq
 	BloomArgs A;
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
+	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt;
 	size_t lds = (size_t)bloom_lds_bytes(P);
-	if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024>), dim3(nfine), dim3(1024), lds, st, P, A);
-	else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512>), dim3(nfine), dim3(512), lds, st, P, A);
-	else hipLaunchKernelGGL((k_bloom<W, RW, 256>), dim3(nfine), dim3(256), lds, st, P, A);
+	if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2>), dim3(nfine), dim3(1024), lds, st, P, A);
+	else if (P.bloom_bt == 512 && P.bloom_pf == 2) hipLaunchKernelGGL((k_bloom<W, RW, 512, 2>), dim3(nfine), dim3(512), lds, st, P, A);
+	else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4>), dim3(nfine), dim3(512), lds, st, P, A);
+	else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4>), dim3(nfine), dim3(256), lds, st, P, A);
 	if (ev) hipEventRecord(ev[4], st);
+	if (B.agg_out) {
+		const uint64_t slots = (uint64_t)nfine * P.ag_cap;
+		hipLaunchKernelGGL((k_commit<W>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, P, A);
+	}
+	if (ev) hipEventRecord(ev[5], st);
 }
 
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev)
@@ -829,9 +898,10 @@ int bloom_lds_bytes(const KParams &P)
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 hipError_t set_bloom_lds_attr(const KParams &P)
 {

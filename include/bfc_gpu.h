@@ -119,8 +119,8 @@ enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_
 int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
 
 /* per-stage GPU time of the last batch, HIP events on the context's stream (ms):
- * [0] hist1 [1] scatter1 [2] hist2+scatter2 [3] bloom+table [4] total */
-int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[5]);
+ * [0] hist1+scans [1] scatter1 [2] hist2+scan2+scatter2 [3] bloom regions [4] table commit [5] total */
+int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[6]);
 
 /* results */
 int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *dst);   /* 2^(bf_shift-3) bytes */
