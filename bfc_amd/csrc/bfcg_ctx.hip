@@ -80,21 +80,23 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
 		if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
-		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 512;
-		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 512;
+		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 1024;
+		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 1024;
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
 		P.bloom_pf = (e = getenv("BFCG_PF")) ? atoi(e) : 4;
 		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 512;
 		// LDS budget: half a CU (2 workgroups resident) unless the region alone needs more
 		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)(80 * 1024 - 1024);
 		if (budget > 160 * 1024 - 1024) budget = 160 * 1024 - 1024;
-		if (region + 24 * 1024 > budget) budget = 160 * 1024 - 1024;
-		size_t left = budget - region - (size_t)P.ag_cap * (P.k > 32 ? 20 : 12);
-		uint32_t fs = 512; while ((size_t)fs * 2 * 10 <= left && fs < 16384) fs <<= 1; // 8 B per entry + 2 B of list per entry
+		if (region + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
+		// per k-mer with clear bits: one list entry (record + mask) and n_hashes first-setter entries at <= 50 % load
+		const size_t rwb = 8; // list entry: file-order index + (record index | mask)
+		size_t left = budget - region - (size_t)P.ag_cap * (P.k > 32 ? 24 : 16) - 16;
+		uint32_t fs = 512; while ((size_t)(fs * 2) * 4 + (size_t)(fs * 2 / (2 * P.n_hashes)) * rwb <= left && fs < 32768) fs <<= 1;
 		if ((e = getenv("BFCG_FS")) != 0) fs = (uint32_t)atoi(e);
 		P.fs_cap = fs;
-		P.list_cap = (uint32_t)((left - (size_t)fs * 8) / 4);
-		if (P.list_cap > (1u << 20) - 1) P.list_cap = (1u << 20) - 1;
+		P.list_cap = (uint32_t)((left - (size_t)fs * 4) / rwb);
+		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
 	c->rw = P.k <= 47 ? 2 : 3;

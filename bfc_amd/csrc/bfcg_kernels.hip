@@ -22,6 +22,16 @@ using namespace bfcg;
 
 #define WAVE 64
 
+// Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8, MI355X_MICROARCH.md).  Neighbouring tiles
+// write neighbouring runs of the same bucket, sharing a cache line at the seam; mapping blocks so that each
+// XCD walks a CONTIGUOUS range of tiles lets one L2 merge both halves of those lines.  Speed only.
+__device__ __forceinline__ int64_t xcd_tile(int64_t bid, int64_t n_tiles)
+{
+	const int64_t per = (n_tiles + 7) / 8;
+	if ((bid >> 3) >= per) return n_tiles; // surplus block of an over-sized grid: nothing to do
+	return (bid & 7) * per + (bid >> 3);
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: tile of positions -> bit planes in LDS
 
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(BT) void k_hist1(KParams P, const uint8_t *__restri
 	const int shift2 = P.F2;
 	uint32_t n_k = 0, n_h = 0;
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
-	for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	for (int64_t tile = xcd_tile(blockIdx.x, n_tiles); tile < n_tiles; tile += n_tiles) {
 		__syncthreads();
 		for (int i = threadIdx.x; i < nb1; i += BT) hist[i] = 0;
 		build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	const int nb1 = 1 << P.F1;
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
-	for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	for (int64_t tile = xcd_tile(blockIdx.x, n_tiles); tile < n_tiles; tile += n_tiles) {
 		__syncthreads();
 		for (int i = threadIdx.x; i < nb1; i += BT) { cnt[i] = 0; base[i] = rows1[tile * nb1 + i]; }
 		build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
@@ -283,31 +293,40 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 // level 2: one level-1 bucket (blockIdx.y) into its 2^F2 fine buckets, tiles of TILE records.
 // Histogram rows of bucket b1 live at rows2[row_base[b1] + tile][2^F2].
 
+// level-1 bucket that owns histogram row `row` (row_base is ascending, nb1+1 entries)
+__device__ __forceinline__ int row_bucket(const uint32_t *__restrict__ row_base, int nb1, uint32_t row)
+{
+	int lo = 0, hi = nb1; // invariant: row_base[lo] <= row < row_base[hi]
+	while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (row_base[mid] <= row) lo = mid; else hi = mid; }
+	return lo;
+}
+
 template <typename W, int RW, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2)
 {
 	__shared__ uint32_t hist[512];
-	const int nb2 = 1 << P.F2, b1 = blockIdx.y;
+	const int nb2 = 1 << P.F2, nb1 = 1 << P.F1;
+	const uint32_t n_rows = row_base[nb1];
+	const int64_t row = xcd_tile(blockIdx.x, n_rows);
+	if (row >= n_rows) return;
+	const int b1 = row_bucket(row_base, nb1, (uint32_t)row);
+	const uint32_t tile = (uint32_t)row - row_base[b1];
 	const uint32_t s = start1[b1], e = start1[b1 + 1];
-	const uint32_t n_tiles = (e - s + TILE - 1) / TILE;
-	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		__syncthreads();
-		for (int i = threadIdx.x; i < nb2; i += BT) hist[i] = 0;
-		__syncthreads();
+	for (int i = threadIdx.x; i < nb2; i += BT) hist[i] = 0;
+	__syncthreads();
 #pragma unroll
-		for (int j = 0; j < TILE / BT; ++j) {
-			uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
-			if (i < e) {
-				uint64_t y0, y1; uint32_t idx; bool hi;
-				Rec<RW>::unpack(in + i * RW, y0, y1, idx, hi);
-				atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
-			}
+	for (int j = 0; j < TILE / BT; ++j) {
+		uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
+		if (i < e) {
+			uint64_t y0, y1; uint32_t idx; bool hi;
+			Rec<RW>::unpack(in + i * RW, y0, y1, idx, hi);
+			atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
 		}
-		__syncthreads();
-		uint32_t *row = rows2 + ((size_t)row_base[b1] + tile) * nb2;
-		for (int i = threadIdx.x; i < nb2; i += BT) row[i] = hist[i];
 	}
+	__syncthreads();
+	uint32_t *rowp = rows2 + (size_t)row * nb2;
+	for (int i = threadIdx.x; i < nb2; i += BT) rowp[i] = hist[i];
 }
 
 // one workgroup per level-1 bucket: column totals -> fine starts; rows -> absolute offsets in place
@@ -345,27 +364,28 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
                                                  uint64_t *__restrict__ out)
 {
 	__shared__ uint32_t cnt[512], base[512];
-	const int nb2 = 1 << P.F2, b1 = blockIdx.y;
+	const int nb2 = 1 << P.F2, nb1 = 1 << P.F1;
+	const uint32_t n_rows = row_base[nb1];
+	const int64_t row = xcd_tile(blockIdx.x, n_rows);
+	if (row >= n_rows) return;
+	const int b1 = row_bucket(row_base, nb1, (uint32_t)row);
+	const uint32_t tile = (uint32_t)row - row_base[b1];
 	const uint32_t s = start1[b1], e = start1[b1 + 1];
-	const uint32_t n_tiles = (e - s + TILE - 1) / TILE;
-	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		__syncthreads();
-		const uint32_t *row = rows2 + ((size_t)row_base[b1] + tile) * nb2;
-		for (int i = threadIdx.x; i < nb2; i += BT) { cnt[i] = 0; base[i] = row[i]; }
-		__syncthreads();
+	const uint32_t *rowp = rows2 + (size_t)row * nb2;
+	for (int i = threadIdx.x; i < nb2; i += BT) { cnt[i] = 0; base[i] = rowp[i]; }
+	__syncthreads();
 #pragma unroll
-		for (int j = 0; j < TILE / BT; ++j) {
-			uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
-			if (i < e) {
-				uint64_t w[RW], y0, y1; uint32_t idx; bool hi;
+	for (int j = 0; j < TILE / BT; ++j) {
+		uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
+		if (i < e) {
+			uint64_t w[RW], y0, y1; uint32_t idx; bool hi;
 #pragma unroll
-				for (int t = 0; t < RW; ++t) w[t] = in[i * RW + t];
-				Rec<RW>::unpack(w, y0, y1, idx, hi);
-				uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
-				uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
+			for (int t = 0; t < RW; ++t) w[t] = in[i * RW + t];
+			Rec<RW>::unpack(w, y0, y1, idx, hi);
+			uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
+			uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
 #pragma unroll
-				for (int t = 0; t < RW; ++t) out[dst * RW + t] = w[t];
-			}
+			for (int t = 0; t < RW; ++t) out[dst * RW + t] = w[t];
 		}
 	}
 }
@@ -503,7 +523,8 @@ __device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A
 // small LDS table keyed by the k-mer folds the batch's occurrences into ONE table update.
 // id0 claims the slot by CAS; for k > 32 a second word id1 completes the identity.  A reader that
 // finds id0 equal but id1 not yet published cannot decide and simply takes the direct path
-// (always exact: updates commute).  cnt = occurrences | high-quality occurrences << 16.
+// (always exact: updates commute).  cnt[2p] = occurrences, cnt[2p+1] = high-quality occurrences
+// (plain non-returning LDS adds; a batch has < 2^32 k-mers, so they cannot wrap).
 struct AggView { unsigned long long *id0, *id1; unsigned int *cnt; uint32_t mask; };
 
 template <typename W>
@@ -519,8 +540,7 @@ __device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint
 			cur = atomicCAS(&G.id0[p], FS_EMPTY, a);
 			if (cur == FS_EMPTY) { // claimed
 				if (two) atomicExch(&G.id1[p], (unsigned long long)y1);
-				atomicAdd(&G.cnt[p], 1u | ((uint32_t)hi << 16));
-				return true;
+				cur = a;
 			}
 		}
 		if (cur == a) {
@@ -529,9 +549,8 @@ __device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint
 				if (b == FS_EMPTY) return false; // identity not published yet
 				if (b != y1) continue;           // another k-mer sharing y0
 			}
-			unsigned int c = *(volatile unsigned int *)&G.cnt[p];
-			unsigned int inc = ((c & 0xffffu) < 4096u ? 1u : 0u) | ((hi && (c >> 16) < 4096u) ? (1u << 16) : 0u); // both saturate far below
-			if (inc) atomicAdd(&G.cnt[p], inc);
+			__hip_atomic_fetch_add(&G.cnt[2 * p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (hi) __hip_atomic_fetch_add(&G.cnt[2 * p + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			return true;
 		}
 	}
@@ -558,15 +577,55 @@ __device__ __forceinline__ KRec decode_rec(const KParams &P, const uint64_t *w, 
 	return r;
 }
 
-// LDS layout (dynamic): region 2^R*64 B | fs table fs_cap*8 B | agg id0 ag_cap*8 [| id1 ag_cap*8] | agg cnt ag_cap*4 | list list_cap*4
+// first-setter table in LDS, 4 bytes per entry: bit offset in the region << 13 | index into the LDS list of
+// k-mers with clear bits.  The earliest k-mer (file order = record idx, read through the list) wins a bit.
+#define FS32_EMPTY 0xffffffffu
+__device__ __forceinline__ uint32_t fs32_slot(uint32_t bitoff, uint32_t mask) { return ((bitoff * 0x9E3779B1u) >> 12 ^ bitoff) & mask; }
+
+__device__ __forceinline__ bool fs32_insert(unsigned int *fs, uint32_t mask, uint32_t bitoff, uint32_t li, uint32_t idx, const unsigned int *list_idx)
+{
+	const uint32_t e = (bitoff << 13) | li;
+	uint32_t p = fs32_slot(bitoff, mask);
+	for (int probe = 0; probe < 1024; ++probe, p = (p + 1) & mask) {
+		uint32_t cur = fs[p];
+		if (cur == FS32_EMPTY) {
+			cur = atomicCAS(&fs[p], FS32_EMPTY, e);
+			if (cur == FS32_EMPTY) return true;
+		}
+		if ((cur >> 13) == bitoff) {
+			while (list_idx[cur & 0x1fffu] > idx) { // the holder is later in file order: take the bit over
+				uint32_t old = atomicCAS(&fs[p], cur, e);
+				if (old == cur) break;
+				cur = old;
+			}
+			return true;
+		}
+	}
+	return false;
+}
+// list index of the first setter of a bit, or FS32_EMPTY if the bit has no entry
+__device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t mask, uint32_t bitoff)
+{
+	uint32_t p = fs32_slot(bitoff, mask);
+	for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
+		uint32_t cur = fs[p];
+		if (cur == FS32_EMPTY) return FS32_EMPTY;
+		if ((cur >> 13) == bitoff) return cur & 0x1fffu;
+	}
+	return FS32_EMPTY;
+}
+
+// LDS layout (dynamic): region 2^R*64 B | agg id0 ag*8 [| id1 ag*8] | agg cnt ag*8 | fs fs_cap*4 B | list idx list_cap*4 | list (record index | mask<<20) list_cap*4
 //
-// Latency structure (measured with SQ_WAIT_ANY: a workgroup used to wait 63 % of its life): every
-// exposed HBM round trip counts because only two workgroups fit a CU.  Hence (i) the region and the
-// first PF records per thread are requested together; (ii) k-mers with clear bits stay in the
-// registers of the thread that classified them (no list, no second read) -- only records beyond the
-// first round use the LDS list; (iii) the aggregated seen k-mers are not upserted here: they are
-// streamed to `agg_out` (fire and forget) and k_commit applies them at full occupancy.
-template <typename W, int RW, int BT, int PF>
+// Structure, driven by measurements (SQ_WAIT_ANY 63 % of a workgroup's life, SALU instructions 1.6x VALU):
+//  * pass 1 classifies every k-mer against the pre-batch region: the NH bit tests of the PF records a thread holds are
+//    plain LDS reads issued back to back.  Seen k-mers (all bits set) go to the aggregation table; the others are
+//    COMPACTED into an LDS list, so that the expensive part runs with full lanes instead of 26 % of them;
+//  * pass 1.5 (dense over the list) enters each clear bit into the first-setter table;
+//  * pass 2 (dense) decides seen <=> not the first setter of any of its bits, sets the bits, aggregates;
+//  * the region goes back to HBM, the aggregated k-mers are streamed to k_commit (no returning atomics here).
+// Buckets whose list or first-setter table overflow take the HBM-pool path (exact, slow).
+template <typename W, int RW, int BT, int PF, int NH>
 __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
@@ -581,122 +640,176 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	constexpr bool two = sizeof(W) == 8;
 	unsigned char *sp = smem;
 	unsigned int *region = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
-	unsigned long long *fs = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.fs_cap * 8;
 	AggView G;
 	G.id0 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8;
 	G.id1 = G.id0;
 	if (two) { G.id1 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8; }
-	G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4;
+	G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 8;
 	G.mask = P.ag_cap - 1;
-	uint32_t *list = reinterpret_cast<uint32_t *>(sp);
+	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.fs_cap * 4;
+	unsigned int *list_a = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4; // file-order index of the k-mer
+	unsigned int *list_b = reinterpret_cast<unsigned int *>(sp);                                // record index in the bucket | clear-bit mask << 20
 	const uint32_t fs_mask = P.fs_cap - 1;
 	const uint64_t *recs = A.recs + (uint64_t)rs * RW;
 	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
 	const W m = kmask<W>(P.k);
 	const uint32_t rmask = region_blocks - 1;
-	const int nh = P.n_hashes;
+	const int nh = NH ? NH : P.n_hashes;
 
 	const bool timing = (P.ablate & 64) && threadIdx.x == 0;
 	long long tq[6] = {0, 0, 0, 0, 0, 0};
 	if (timing) tq[0] = clock64();
-	uint64_t r0w[PF][RW];      // round-0 records stay in registers until pass 2
-	uint32_t r0um[PF];
+
+	uint64_t rw[PF][RW];
 #pragma unroll
 	for (int u = 0; u < PF; ++u) {
 		uint32_t i = threadIdx.x + u * BT;
-		r0um[u] = 0;
 		if (i < n) {
 #pragma unroll
-			for (int t = 0; t < RW; ++t) r0w[u][t] = recs[(uint64_t)i * RW + t];
+			for (int t = 0; t < RW; ++t) rw[u][t] = recs[(uint64_t)i * RW + t];
 		}
 	}
 	{ // stage the region (16-byte loads), clear the LDS tables
 		const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
-		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS_EMPTY;
-		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) { G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[i] = 0; }
-		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = (n >= (1u << 20)) ? 1u : 0u; }
+		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS32_EMPTY;
+		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) { G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0; }
+		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = 0; }
 	}
 	__syncthreads();
 	if (timing) tq[1] = clock64();
 
 	uint32_t n_seen = 0;
-	volatile uint32_t *v_ovf = &s_ovf; // set when the LDS list or the LDS first-setter table (48 probes) cannot take a k-mer
+	volatile uint32_t *v_ovf = &s_ovf; // set when the LDS list or the LDS first-setter table cannot take a k-mer
+	const int lane = threadIdx.x & 63;
 
-	// classify one k-mer against the pre-batch region; returns the mask of its clear bits
-	auto classify = [&](const KRec &r) -> uint32_t {
+	// mask of the bits of r that are clear in the (pre-batch) region
+	auto clear_mask = [&](const KRec &r) -> uint32_t {
 		uint32_t z = r.h1, um = 0;
-		for (int j = 0; j < nh; ++j) {
+#pragma unroll
+		for (int j = 0; j < (NH ? NH : 12); ++j) {
+			if (j >= nh) break;
 			uint32_t b = bloom_next(z, r.h2);
-			if (!((region[r.bl * 16 + (b >> 5)] >> (b & 31)) & 1u)) um |= 1u << j;
-		}
-		if (um == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
-			++n_seen;
-			if (A.seen_out) A.seen_out[r.idx] = 2;
-			emit_seen<W>(P, A, G, r.y0, r.y1, r.hi);
-		} else if (!*v_ovf) {
-			z = r.h1;
-			for (int j = 0; j < nh; ++j) {
-				uint32_t b = bloom_next(z, r.h2);
-				if (((um >> j) & 1u) && !fs_insert<false>(fs, fs_mask, r.bl * 512 + b, r.idx, 48)) { *v_ovf = 1; break; }
-			}
+			um |= (((region[r.bl * 16 + (b >> 5)] >> (b & 31)) & 1u) ^ 1u) << j;
 		}
 		return um;
 	};
-	// decide a k-mer with clear bits: seen iff an earlier k-mer of the batch sets each of them; set the bits
-	auto resolve = [&](const KRec &r, uint32_t um) {
-		uint32_t z = r.h1; bool first = false;
-		for (int j = 0; j < nh; ++j) {
-			uint32_t b = bloom_next(z, r.h2);
-			if ((um >> j) & 1u) {
-				uint32_t fi = 0xffffffffu;
-				fs_lookup<false>(fs, fs_mask, r.bl * 512 + b, fi);
-				first |= (fi == r.idx);
-				atomicOr(&region[r.bl * 16 + (b >> 5)], 1u << (b & 31));
-			}
+	// append a k-mer with clear bits to the LDS list: one LDS atomic per wave
+	auto list_push = [&](bool want, uint32_t idx, uint32_t i, uint32_t um) {
+		const unsigned long long vote = __ballot(want);
+		if (!vote) return;
+		const int leader = __ffsll((long long)vote) - 1;
+		uint32_t li0 = 0;
+		if (lane == leader) li0 = atomicAdd(&s_list_n, (uint32_t)__popcll(vote));
+		li0 = __shfl(li0, leader);
+		if (want) {
+			const uint32_t li = li0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1));
+			if (li < P.list_cap) { list_a[li] = idx; list_b[li] = i | (um << 20); }
+			else *v_ovf = 1;
 		}
-		if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-		if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi); }
 	};
 
-	// ---- pass 1, round 0 (registers)
+	// ---- pass 1: classify; seen -> aggregate, clear bits -> list
+	for (uint32_t base = 0; base < n; base += BT * PF) {
+		KRec r[PF]; uint32_t um[PF]; bool act[PF];
 #pragma unroll
-	for (int u = 0; u < PF; ++u) {
-		const uint32_t i = threadIdx.x + u * BT;
-		if (i < n) r0um[u] = classify(decode_rec<W, RW>(P, r0w[u], m, rmask));
-	}
-	// ---- pass 1, further rounds (buckets larger than BT*PF): LDS list of record indices
-	for (uint32_t i = threadIdx.x + BT * PF; i < n; i += BT) {
-		uint64_t w[RW];
+		for (int u = 0; u < PF; ++u) {
+			act[u] = base + threadIdx.x + u * BT < n;
+			um[u] = 0;
+			if (act[u]) { r[u] = decode_rec<W, RW>(P, rw[u], m, rmask); um[u] = clear_mask(r[u]); }
+		}
 #pragma unroll
-		for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
-		uint32_t um = classify(decode_rec<W, RW>(P, w, m, rmask));
-		if (um && !*v_ovf) {
-			uint32_t li = atomicAdd(&s_list_n, 1u);
-			if (li < P.list_cap) list[li] = i | (um << 20); else *v_ovf = 1;
+		for (int u = 0; u < PF; ++u) {
+			if (act[u] && um[u] == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
+				++n_seen;
+				if (A.seen_out) A.seen_out[r[u].idx] = 2;
+				emit_seen<W>(P, A, G, r[u].y0, r[u].y1, r[u].hi);
+			}
+			list_push(act[u] && um[u] != 0, r[u].idx, base + threadIdx.x + u * BT, um[u]);
+		}
+		if (base + BT * PF < n) { // next round (buckets larger than BT*PF)
+#pragma unroll
+			for (int u = 0; u < PF; ++u) {
+				uint32_t i = base + BT * PF + threadIdx.x + u * BT;
+				if (i < n) {
+#pragma unroll
+					for (int t = 0; t < RW; ++t) rw[u][t] = recs[(uint64_t)i * RW + t];
+				}
+			}
 		}
 	}
 	__syncthreads();
 	if (timing) tq[2] = clock64();
+	const uint32_t ln = s_list_n;
+	if (ln > P.list_cap || ln > 8191 || n >= (1u << 20)) s_ovf = 1; // benign race: every writer stores 1
+	// ---- pass 1.5: dense over the list -- enter every clear bit into the first-setter table.
+	// A thread keeps the records of its first LK list entries in registers for pass 2.
+	constexpr int LK = 2;
+	uint64_t lw[LK][RW];
+	if (!*v_ovf) {
+#pragma unroll
+		for (int q = 0; q < LK; ++q) {
+			const uint32_t li = threadIdx.x + q * BT;
+			if (li < ln) {
+				const uint32_t i = list_b[li] & 0xfffffu;
+#pragma unroll
+				for (int t = 0; t < RW; ++t) lw[q][t] = recs[(uint64_t)i * RW + t];
+			}
+		}
+		for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
+			uint64_t w[RW];
+			if (q < LK) {
+#pragma unroll
+				for (int t = 0; t < RW; ++t) w[t] = q == 0 ? lw[0][t] : lw[LK - 1][t];
+			} else {
+				const uint32_t i = list_b[li] & 0xfffffu;
+#pragma unroll
+				for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
+			}
+			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			const uint32_t um = list_b[li] >> 20;
+			uint32_t z = r.h1;
+#pragma unroll
+			for (int j = 0; j < (NH ? NH : 12); ++j) {
+				if (j >= nh) break;
+				uint32_t b = bloom_next(z, r.h2);
+				if (((um >> j) & 1u) && !fs32_insert(fs, fs_mask, r.bl * 512 + b, li, r.idx, list_a)) *v_ovf = 1;
+			}
+		}
+	}
+	__syncthreads();
 
 	bool dirty = true;
 	if (!s_ovf) {
-		// ---- pass 2 (fast)
-		uint32_t any = 0;
-#pragma unroll
-		for (int u = 0; u < PF; ++u)
-			if (r0um[u]) { any = 1; resolve(decode_rec<W, RW>(P, r0w[u], m, rmask), r0um[u]); }
-		const uint32_t ln = s_list_n;
-		for (uint32_t li = threadIdx.x; li < ln; li += BT) {
-			uint32_t i = list[li] & 0xfffffu, um = list[li] >> 20;
+		// ---- pass 2: dense over the list -- seen iff an earlier k-mer of the batch sets each clear bit; set the bits
+		for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
 			uint64_t w[RW];
+			if (q < LK) {
 #pragma unroll
-			for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
-			resolve(decode_rec<W, RW>(P, w, m, rmask), um);
-			any = 1;
+				for (int t = 0; t < RW; ++t) w[t] = q == 0 ? lw[0][t] : lw[LK - 1][t];
+			} else {
+				const uint32_t i = list_b[li] & 0xfffffu;
+#pragma unroll
+				for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
+			}
+			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			const uint32_t um = list_b[li] >> 20;
+			uint32_t z = r.h1; bool first = false;
+#pragma unroll
+			for (int j = 0; j < (NH ? NH : 12); ++j) {
+				if (j >= nh) break;
+				uint32_t b = bloom_next(z, r.h2);
+				if ((um >> j) & 1u) {
+					first |= fs32_lookup(fs, fs_mask, r.bl * 512 + b) == li;
+					atomicOr(&region[r.bl * 16 + (b >> 5)], 1u << (b & 31));
+				}
+			}
+			if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
+			if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi); }
 		}
-		dirty = __syncthreads_or((int)any) != 0;
+		dirty = ln != 0;
+		__syncthreads();
 	} else {
 		// ---- slow path: first-setter table in HBM (slice of the pool), sized by the region's bit count
 		uint64_t want = (uint64_t)n * nh * 2;
@@ -762,21 +875,23 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 		unsigned long long a = p < P.ag_cap ? G.id0[p] : FS_EMPTY;
 		const bool used = a != FS_EMPTY;
 		const unsigned long long vote = __ballot(used);
-		const int lane = threadIdx.x & 63;
 		uint32_t o0 = 0;
 		if (vote) {
-			if (lane == __ffsll((long long)vote) - 1) o0 = atomicAdd(&s_agg_n, (uint32_t)__popcll(vote));
-			o0 = __shfl(o0, __ffsll((long long)vote) - 1);
+			const int leader = __ffsll((long long)vote) - 1;
+			if (lane == leader) o0 = atomicAdd(&s_agg_n, (uint32_t)__popcll(vote));
+			o0 = __shfl(o0, leader);
 		}
 		if (used) {
 			const uint32_t o = o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1));
-			unsigned int c = G.cnt[p];
+			uint32_t c = G.cnt[2 * p], h = G.cnt[2 * p + 1];
+			if (c > 0xffffu) c = 0xffffu;
+			if (h > 0xffffu) h = 0xffffu;
 			uint64_t y0, y1;
 			if (two) { y0 = a; y1 = G.id1[p]; } else { y0 = a >> P.k; y1 = a & (uint64_t)m; }
 			if (A.agg_out) {
 				uint64_t *dst = A.agg_out + ((uint64_t)f * P.ag_cap + o) * 3;
-				dst[0] = y0; dst[1] = y1; dst[2] = c;
-			} else commit_seen<W>(P, A, y0, y1, c & 0xffffu, c >> 16);
+				dst[0] = y0; dst[1] = y1; dst[2] = c | (h << 16);
+			} else commit_seen<W>(P, A, y0, y1, c, h);
 		}
 	}
 	for (int o = 32; o; o >>= 1) n_seen += __shfl_down(n_seen, o);
@@ -850,19 +965,21 @@ static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq
 	const int64_t tiles1 = (n_pos + TILE1 - 1) / TILE1;
 	const int n_chunks = (int)((tiles1 + SCAN_CH - 1) / SCAN_CH);
 	if (ev) hipEventRecord(ev[0], st);
-	hipLaunchKernelGGL((k_hist1<W, TILE1, BT1>), dim3(grid_for(tiles1, 1 << 20)), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.stats);
+	const unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8); // one block per tile, dealt XCD-contiguously
+	hipLaunchKernelGGL((k_hist1<W, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.stats);
 	hipLaunchKernelGGL(k_colsum, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(512), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(grid_for(tiles1, 1 << 20)), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.recs1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.recs1);
 	if (ev) hipEventRecord(ev[2], st);
 	const uint64_t *fine_recs = B.recs1; const uint32_t *fine_start = B.start1;
 	if (P.F2 > 0) {
-		int gx = (int)((B.max_kmers / nb1) / TILE2 + 1); if (gx > 1024) gx = 1024;
-		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(gx, nb1), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2);
+		// rows of level 2 <= k-mers/TILE2 + one ragged row per bucket; surplus blocks exit at once
+		const unsigned g2 = (unsigned)((((uint64_t)n_pos / TILE2 + nb1 + 1 + 7) / 8) * 8);
+		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2);
 		hipLaunchKernelGGL(k_scan2, dim3(nb1), dim3(512), 0, st, P, B.start1, B.row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(gx, nb1), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2, B.recs2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2, B.recs2);
 		fine_recs = B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
@@ -871,10 +988,11 @@ static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt;
 	size_t lds = (size_t)bloom_lds_bytes(P);
-	if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2>), dim3(nfine), dim3(1024), lds, st, P, A);
-	else if (P.bloom_bt == 512 && P.bloom_pf == 2) hipLaunchKernelGGL((k_bloom<W, RW, 512, 2>), dim3(nfine), dim3(512), lds, st, P, A);
-	else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4>), dim3(nfine), dim3(512), lds, st, P, A);
-	else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4>), dim3(nfine), dim3(256), lds, st, P, A);
+	if (P.n_hashes == 4) {
+		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4>), dim3(nfine), dim3(1024), lds, st, P, A);
+		else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4>), dim3(nfine), dim3(512), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4, 4>), dim3(nfine), dim3(256), lds, st, P, A);
+	} else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0>), dim3(nfine), dim3(512), lds, st, P, A);
 	if (ev) hipEventRecord(ev[4], st);
 	if (B.agg_out) {
 		const uint64_t slots = (uint64_t)nfine * P.ag_cap;
@@ -892,16 +1010,18 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 
 int bloom_lds_bytes(const KParams &P)
 {
-	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 8 + (size_t)P.ag_cap * (P.k > 32 ? 20 : 12) + (size_t)P.list_cap * 4);
+	const int rw = P.k <= 47 ? 2 : 3;
+	(void)rw;
+	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + (size_t)P.ag_cap * (P.k > 32 ? 24 : 16) + (size_t)P.list_cap * 8 + 16);
 }
 
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 hipError_t set_bloom_lds_attr(const KParams &P)
 {
