@@ -140,6 +140,8 @@ def main():
             g.count_dev(d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
             if acc:
                 ms = g.last_batch_ms()
+                if os.environ.get("BFC_BENCH_VERBOSE"):
+                    log("[bench] batch %d: %s" % (r0 // batch_reads, {k_: round(v_, 3) for k_, v_ in ms.items()}))
                 for kk in stage:
                     stage[kk] += ms[kk]
                 n_launch += 1

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #define BFCG_TILE1 4096
-#define BFCG_TILE2 8192
+#define BFCG_TILE2 4096
 #define BFCG_SCAN_CH 64
 #include <stdint.h>
 

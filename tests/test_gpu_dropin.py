@@ -1,0 +1,115 @@
+"""GPU tests (-m gpu) of the drop-in boundary: bfc_count(fn, opt) fed from FASTA/FASTQ files, and the reference's
+own UNMODIFIED main() + corrector linked against libbfc_gpu.so (oracle/_ref/bfc-dropin, built in place by
+oracle/Makefile where /root/reference exists; it travels prebuilt to the GPU box)."""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from bfc_amd import gen
+
+pytestmark = pytest.mark.gpu
+
+DROPIN = os.path.join(oracle.REF_DIR, "bfc-dropin")
+needs_dropin = pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/bfc-dropin not built (needs /root/reference at build time)")
+
+
+@pytest.fixture(scope="module")
+def g1_fq(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fq")
+    fn = str(d / "g1.fq")
+    gen.fixture("g1").fastq(fn)
+    assert oracle.md5_file(fn) == "7e17d87fc623a6f7171a607d68dde51a"
+    return fn
+
+
+def _opt(gpu_lib, **kw):
+    o = gpu_lib.bfc_opt_init()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def test_bfc_count_fastq(gpu_lib, g1_fq):
+    """bfc_count on a FASTQ file (count.c:127): table identical (L1) to `bfc -t1`; chunking (-L) is invisible."""
+    for chunk in (100000000, 100000):
+        t = gpu_lib.bfc_count(g1_fq, _opt(gpu_lib, k=31, bf_shift=26, chunk_size=chunk))
+        assert t.count() == 99561
+        assert oracle.l1_digest(*t.export_sorted()) == "237be10261b07ef0677f8136b0a327b6"
+        assert t.hist()[0] == 4
+        t.close()
+
+
+def test_bfc_count_gz_fasta_and_no_mt_io(gpu_lib, g1_fq, tmp_path):
+    """gzip input, FASTA input (every k-mer high quality, count.c:85; SURVEY B.3 FASTA golden) and -J (no reader thread)."""
+    gz = str(tmp_path / "g1.fq.gz")
+    with open(g1_fq, "rb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
+        g.write(f.read())
+    t = gpu_lib.bfc_count(gz, _opt(gpu_lib, k=31, bf_shift=26, no_mt_io=1))
+    assert oracle.l1_digest(*t.export_sorted()) == "237be10261b07ef0677f8136b0a327b6"
+    t.close()
+    fa = str(tmp_path / "g1.fa")
+    with open(g1_fq) as f, open(fa, "w") as g:
+        for i, line in enumerate(f):
+            if i % 4 == 0:
+                g.write(">" + line[1:])
+            elif i % 4 == 1:
+                g.write(line[:70] + "\n" + line[70:])  # multi-line FASTA
+    t = gpu_lib.bfc_count(fa, _opt(gpu_lib, k=31, bf_shift=26))
+    sizes, slots = t.export_sorted()
+    assert t.count() == 99561 and oracle.l1_digest(sizes, slots) == "4e4705f65c9bcc880b6e28a3453cc4fc"
+    assert np.array_equal((slots >> np.uint64(8)) & np.uint64(0x3f), np.minimum(slots & np.uint64(0xff), np.uint64(63)))
+    t.close()
+
+
+def test_bfc_count_filter_mode(gpu_lib, g1_fq):
+    """-1 mode returns the bloom filter of k-mers seen twice (count.c:148-154) as a host bfc_bf_t."""
+    b = gpu_lib.bfc_count(g1_fq, _opt(gpu_lib, k=51, bf_shift=26, filter_mode=1))
+    bits = b.bytes()
+    L = oracle.lib()
+    assert (b.n_shift, b.n_hashes) == (26, 4)
+    assert int(L.orc_popcount_bytes(bits.ctypes.data, len(bits))) == 364980
+    assert int(L.orc_fnv1a64(bits.ctypes.data, len(bits))) == 0xafeb3dee4fc349c5
+    b.close()
+
+
+def _run(args, stdin=None):
+    r = subprocess.run([DROPIN] + args, stdin=stdin, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r
+
+
+@needs_dropin
+def test_dropin_full_pipeline(g1_fq):
+    """Reference main() + correct.c, unmodified, consuming the GPU-built table: corrected reads byte-identical
+    to reference `bfc -k31 -b26 -t1 g1.fq` (golden md5 from SURVEY B.3)."""
+    r = _run(["-k", "31", "-b", "26", "-t", "4", g1_fq])
+    assert hashlib.md5(r.stdout).hexdigest() == "06a4284e5010e34a1645d1d8015d6da9"
+    assert r.stdout.startswith(b"@r0\tec:Z:0_0:2_0_1:0_0")
+
+
+@needs_dropin
+def test_dropin_trim_mode_and_stdin(g1_fq):
+    """`bfc -1` (count + bloom-query trim pass in correct.c:478-497,556-569): stdout md5 golden; reads from stdin too."""
+    r = _run(["-1", "-k", "51", "-b", "26", "-t", "2", g1_fq])
+    assert hashlib.md5(r.stdout).hexdigest() == "f751f7b1aa28fd74b23194bc7f70158c"
+    with open(g1_fq, "rb") as f:
+        r2 = _run(["-E", "-k", "31", "-b", "26", "-d", "/dev/null", "-"], stdin=f)
+    assert b"# distinct k-mers: 99561" in r2.stderr
+
+
+@needs_dropin
+def test_dropin_dump_restores_in_reference(g1_fq, tmp_path):
+    """-d dump written by this library: L1-identical to `bfc -t1 -d`, and the *reference* restores it (-r) and
+    corrects with it to the same bytes."""
+    dump = str(tmp_path / "g1.hash")
+    _run(["-E", "-k", "31", "-b", "26", "-d", dump, g1_fq])
+    k, l_pre, sizes, slots = oracle.parse_dump(dump)
+    assert (k, l_pre) == (31, 20) and oracle.l1_digest(sizes, slots) == "237be10261b07ef0677f8136b0a327b6"
+    ref = os.path.join(oracle.REF_DIR, "bfc-ref")
+    r = subprocess.run([ref, "-r", dump, "-t", "2", g1_fq], capture_output=True, timeout=600)
+    assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == "06a4284e5010e34a1645d1d8015d6da9"
