@@ -97,7 +97,7 @@ def lib():
         L.orc_kmers_in_read.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_max_streak.restype = C.c_uint64
         L.orc_max_streak.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_trim_decide.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_trim_decide.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 

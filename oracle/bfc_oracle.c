@@ -433,7 +433,7 @@ uint64_t orc_max_streak(int k, const orc_bf_t *bf, const uint8_t *seq, int len)
 	return max;
 }
 /* keep/trim decision of correct.c:557-569.  Returns 1 and [*start,*end) if the read is kept. */
-int orc_trim_decide(uint64_t max, int k, int len, double min_frac, int *start, int *end)
+int orc_trim_decide(uint64_t max, int k, int len, float min_frac, int *start, int *end) /* min_frac is a float in bfc_opt_t (bfc.h:21): 0.9f < 0.9 */
 {
 	if ((max >> 32) && (double)((max >> 32) + (uint64_t)k) / len > min_frac) {
 		int s = (int)(uint32_t)max, e = s + (int)(max >> 32);

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json from THE REFERENCE ITSELF (oracle/_ref/libbfcref.so and oracle/_ref/bfc-ref,
+compiled in place from /root/reference by oracle/Makefile).  Run in the build container only:
+
+    make -C oracle && python tests/golden/make_goldens.py
+
+The files hold data only (inputs are defined by the deterministic generator bfcgen; outputs are
+numbers and digests).  kat.json: single-k-mer known answers through the reference's inline k-mer math, bloom
+addressing and key packing.  fixtures.json: whole-run checksums of `bfc -t1` semantics on fixtures g1 / g42.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from bfc_amd import gen  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+S = "ACGTTGCATGCCGATTACAGGCTAGCTTAGGCCATATCGGATCCGTAAGCTTGACCTGAAGTCA"
+u64p = C.POINTER(C.c_uint64)
+
+
+def kat():
+    R = oracle.ref()
+    R.bfc_bf_init.restype = C.c_void_p
+    R.bfc_ch_init.restype = C.c_void_p
+    out = []
+    for (k, b, start) in [(31, 33, 0), (31, 33, 1), (33, 33, 0), (33, 37, 0), (51, 37, 0), (63, 37, 0), (21, 30, 0), (32, 33, 0), (47, 26, 0), (37, 20, 3)]:
+        x = (C.c_uint64 * 4)(0, 0, 0, 0)
+        for ch in S[start:start + k]:
+            R.ref_kmer_append(k, x, "ACGT".index(ch))
+        y = (C.c_uint64 * 2)()
+        h = R.ref_kmer_hash(k, x, y)
+        # the reference exposes bloom addressing only through insert: probe a fresh filter and read back the touched bits
+        st = R.ref_state_new(k, min(b, 30), 4, 20, 0)  # small filter just to own a table for sub/key
+        R.ref_state_free(st)
+        out.append(dict(k=k, b=b, kmer=S[start:start + k], x=[int(v) for v in x], hash=int(h), y0=int(y[0]), y1=int(y[1])))
+    return out
+
+
+def kat_bloom_and_key(entries):
+    """bloom positions / table slot via the reference's own insert functions on tiny instances"""
+    R = oracle.ref()
+    R.bfc_bf_init.restype = C.c_void_p
+    R.bfc_bf_init.argtypes = [C.c_int, C.c_int]
+    R.bfc_ch_init.restype = C.c_void_p
+    R.bfc_ch_init.argtypes = [C.c_int, C.c_int]
+    R.bfc_ch_insert.argtypes = [C.c_void_p, u64p, C.c_int, C.c_int]
+    R.bfc_bf_destroy.argtypes = [C.c_void_p]
+    for e in entries:
+        bsmall = 20  # positions inside the block depend on b: recompute with the real b through bit arithmetic is the
+        # implementation's job; here we record what the reference sets for a 2^20-bit filter and for the entry's own b when small
+        for bb in sorted({bsmall, e["b"] if e["b"] <= 30 else bsmall}):
+            bf = R.bfc_bf_init(bb, 4)
+            R.bfc_bf_insert(bf, e["hash"])
+            bits = np.ctypeslib.as_array(C.cast(R.ref_bf_bits(bf), C.POINTER(C.c_uint8)), shape=(1 << (bb - 3),))
+            nz = np.nonzero(bits)[0]
+            pos = sorted(int(i) * 8 + j for i in nz for j in range(8) if bits[i] >> j & 1)
+            e.setdefault("bloom_bits", {})[str(bb)] = pos  # absolute bit addresses in the bitmap
+            R.bfc_bf_destroy(bf)
+        ch = R.bfc_ch_init(e["k"], 20)
+        y = (C.c_uint64 * 2)(e["y0"], e["y1"])
+        R.bfc_ch_insert(ch, y, 1, 1)
+        R.bfc_ch_insert(ch, y, 0, 1)
+        with tempfile.NamedTemporaryFile(suffix=".hash") as tf:
+            R.bfc_ch_dump(ch, tf.name.encode())
+            k, l_pre, sizes, slots = oracle.parse_dump(tf.name)
+        R.bfc_ch_destroy(ch)
+        e["l_pre"] = l_pre
+        e["sub"] = int(np.nonzero(sizes)[0][0])
+        e["slot_after_high_then_low"] = int(slots[0])
+    return entries
+
+
+def fixtures():
+    out = []
+    cases = [("g1", 31, 26, 0), ("g1", 33, 30, 0), ("g1", 51, 26, 0), ("g1", 51, 26, 1), ("g1", 63, 28, 0), ("g1", 21, 22, 0), ("g1", 32, 25, 0),
+             ("g42", 31, 30, 0), ("g42", 33, 33, 0), ("g42", 51, 30, 1)]
+    cache = {}
+    for name, k, b, fm in cases:
+        if name not in cache:
+            rs = gen.fixture(name)
+            cache[name] = (rs, rs.reads())
+        rs, (seq, qual, off) = cache[name]
+        c = oracle.Counter(k, b, filter_mode=fm, impl="ref")
+        c.count(seq, qual, off)
+        st = c.stats()
+        pop, fnv = c.bloom_checksums()
+        e = dict(fixture=name, k=k, b=b, filter_mode=fm, n_reads=rs.n_reads, **st, bf_popcount=pop, bf_fnv1a64=fnv)
+        if fm:
+            pop2, fnv2 = c.bloom_checksums(high=True)
+            e.update(bf_high_popcount=pop2, bf_high_fnv1a64=fnv2)
+        else:
+            mode, cnt, high = c.table_hist()
+            with tempfile.NamedTemporaryFile(suffix=".hash") as tf:
+                c.dump(tf.name)
+                e["dump_md5"] = oracle.md5_file(tf.name)
+                kk, l_pre, sizes, slots = oracle.parse_dump(tf.name)
+            e.update(distinct=c.table_count(), hist_mode=mode, cnt_1_4=[int(v) for v in cnt[1:5]], high_0_2=[int(v) for v in high[0:3]],
+                     l_pre=l_pre, l1_digest=oracle.l1_digest(sizes, slots))
+        c.close()
+        print(e, file=sys.stderr)
+        out.append(e)
+    # the reference binary end to end on g1 (stdout digests)
+    ref = os.path.join(oracle.REF_DIR, "bfc-ref")
+    with tempfile.TemporaryDirectory() as d:
+        fq = os.path.join(d, "g1.fq")
+        cache["g1"][0].fastq(fq)
+        runs = {}
+        for label, args in (("full_k31_b26", ["-k", "31", "-b", "26", "-t", "1"]), ("trim_k51_b26", ["-1", "-k", "51", "-b", "26", "-t", "1"])):
+            r = subprocess.run([ref] + args + [fq], capture_output=True)
+            runs[label] = dict(args=args, stdout_md5=hashlib.md5(r.stdout).hexdigest(), first_line=r.stdout.split(b"\n")[0].decode())
+        runs["fastq_md5"] = oracle.md5_file(fq)
+    return out, runs
+
+
+if __name__ == "__main__":
+    assert oracle.have_ref(), "build oracle/_ref first (make -C oracle)"
+    k = kat_bloom_and_key(kat())
+    json.dump(k, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
+    fx, runs = fixtures()
+    json.dump(dict(fixtures=fx, binary_runs=runs), open(os.path.join(HERE, "fixtures.json"), "w"), indent=1)
+    print("wrote kat.json (%d), fixtures.json (%d)" % (len(k), len(fx)))

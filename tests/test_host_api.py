@@ -1,0 +1,124 @@
+"""CPU tests (-m "not gpu") of libbfc_gpu.so's host side: the library loads and exports every symbol include/bfc_gpu.h
+declares; the reference-shaped single-element / query / dump / restore entry points (bbf.h, htab.h) behave like the
+reference; and counting without a GPU fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported(gpu_lib):
+    from bfc_amd import _lib
+    L = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "bfc_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(bfcg?_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 38
+    for n in sorted(names):
+        assert hasattr(L, n), "symbol %s declared in include/bfc_gpu.h but not exported" % n
+    assert names == set(_lib.SYMBOLS), names ^ set(_lib.SYMBOLS)
+
+
+def test_struct_layouts_match_reference_abi(gpu_lib):
+    from bfc_amd._lib import BfcOpt, BfcBf
+    assert C.sizeof(BfcOpt) == 22 * 4 and BfcOpt.min_frac.offset == 32 and BfcOpt.l_pre.offset == 36  # bfc.h:15-33
+    assert (BfcBf.n_shift.offset, BfcBf.n_hashes.offset, BfcBf.b.offset) == (0, 4, 8)              # bbf.h:9-12, read by correct.c:490
+
+
+def test_no_gpu_means_loud_failure(gpu_lib):
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import bfc_amd\n"
+            "try:\n    bfc_amd.GpuCounter(31, 26)\nexcept bfc_amd.BfcGpuError as e:\n    print('LOUD', e)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert "LOUD" in r.stdout and "no CPU fallback" in (r.stdout + r.stderr)
+
+
+def test_host_bloom_matches_oracle(gpu_lib):
+    """bfc_bf_init/insert/get (bbf.c): same bits, same return values; bad shifts give NULL (bbf.c:9)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    hb = gpu_lib.HostBloom.init(20, 4)
+    ob = L.orc_bf_new(20, 4)
+    for h in rng.integers(0, 2 ** 63, 5000, dtype=np.int64).astype(np.uint64):
+        h = int(h)
+        assert hb.get(h) == L.orc_bf_get(ob, h)
+        assert hb.insert(h) == L.orc_bf_insert(ob, h)
+        assert hb.get(h) == 4
+    ref = np.ctypeslib.as_array(C.cast(L.orc_bf_bits(ob), C.POINTER(C.c_uint8)), shape=(1 << 17,))
+    assert np.array_equal(hb.bytes(), ref)
+    assert gpu_lib.HostBloom.init(8, 4) is None and gpu_lib.HostBloom.init(56, 4) is None
+    hb.close(); L.orc_bf_free(ob)
+
+
+@pytest.mark.parametrize("k,l_pre", [(31, 20), (33, 20), (51, 20), (63, 20), (21, 10)])
+def test_host_table_matches_oracle(gpu_lib, k, l_pre, tmp_path):
+    """bfc_ch_insert/get/count/hist/dump/restore (htab.c) on the host table vs the oracle: saturation at 255/63,
+    growth, l_pre clamping, and a dump the oracle's parser and our restore both read back (L1)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(k)
+    m = (1 << k) - 1
+    keys = [(int(a) & m, int(b) & m) for a, b in zip(rng.integers(0, 2 ** 63, 3000, dtype=np.int64), rng.integers(0, 2 ** 63, 3000, dtype=np.int64))]
+    t = gpu_lib.HostTable.init(k, l_pre)
+    oc = L.orc_ch_new(k, l_pre)
+    assert t.k == k and t.l_pre == L.orc_ch_lpre(oc)
+    for rep in range(3):
+        for i, (a, b) in enumerate(keys):
+            hi = (i + rep) & 1
+            y = (C.c_uint64 * 2)(a, b)
+            assert t.insert(a, b, hi) == 0
+            L.orc_ch_insert(oc, y, hi)
+    for _ in range(300):  # saturation of one key
+        t.insert(*keys[0], 1)
+        L.orc_ch_insert(oc, (C.c_uint64 * 2)(*keys[0]), 1)
+    assert t.get(*keys[0]) == L.orc_ch_get(oc, (C.c_uint64 * 2)(*keys[0])) == (63 << 8 | 255)
+    for a, b in keys[:500] + [(1, 2), (m, m)]:
+        assert t.get(a, b) == L.orc_ch_get(oc, (C.c_uint64 * 2)(a, b))
+    assert t.count() == L.orc_ch_count(oc)
+    cnt = np.zeros(256, dtype=np.uint64); high = np.zeros(64, dtype=np.uint64)
+    omode = L.orc_ch_hist(oc, cnt.ctypes.data_as(C.POINTER(C.c_uint64)), high.ctypes.data_as(C.POINTER(C.c_uint64)))
+    mode, c2, h2 = t.hist()
+    assert mode == omode and np.array_equal(cnt, c2) and np.array_equal(high, h2)
+    fn = str(tmp_path / "t.hash")
+    assert t.dump(fn) == 0
+    kk, lp, sizes, slots = oracle.parse_dump(fn)
+    osz = np.zeros(1 << lp, dtype=np.uint32)
+    n = L.orc_ch_export(oc, osz.ctypes.data_as(C.POINTER(C.c_uint32)), None)
+    osl = np.zeros(n, dtype=np.uint64)
+    L.orc_ch_export(oc, osz.ctypes.data_as(C.POINTER(C.c_uint32)), osl.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert (kk, lp) == (k, t.l_pre) and np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    t2 = gpu_lib.HostTable.restore(fn)
+    s2 = t2.export_sorted()
+    assert t2.count() == t.count() and np.array_equal(s2[0], osz) and np.array_equal(s2[1], osl)
+    assert gpu_lib.HostTable.restore(str(tmp_path / "missing")) is None  # htab.c:157
+    assert t.dump(str(tmp_path / "no_such_dir" / "x")) == -1                # htab.c:134
+    t.close(); t2.close(); L.orc_ch_free(oc)
+
+
+def test_kmer_occ_uses_the_strand_canonical_hash(gpu_lib):
+    """bfc_ch_kmer_occ (htab.c:94-99): a k-mer and its reverse complement hit the same slot."""
+    L = oracle.lib()
+    k = 31
+    s = "ACGTTGCATGCCGATTACAGGCTAGCTTAGG"
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = "".join(comp[c] for c in reversed(s))
+    t = gpu_lib.HostTable.init(k, 20)
+    xs = []
+    for st in (s, rc):
+        x = (C.c_uint64 * 4)(0, 0, 0, 0)
+        for ch in st:
+            L.orc_kmer_push(k, x, "ACGT".index(ch))
+        xs.append([int(v) for v in x])
+    y = (C.c_uint64 * 2)()
+    L.orc_kmer_hash(k, (C.c_uint64 * 4)(*xs[0]), y)
+    assert t.kmer_occ(xs[0]) == -1
+    t.insert(int(y[0]), int(y[1]), 1)
+    assert t.kmer_occ(xs[0]) == t.kmer_occ(xs[1]) == (1 << 8 | 1)
+    t.close()
