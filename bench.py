@@ -100,12 +100,14 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    use_dist = world > 1 or bool(os.environ.get("BFC_BENCH_FORCE_DIST"))
     dist = None
-    if world > 1:
-        import torch
+    if use_dist:
+        import torch  # first: libbfc_gpu.so then binds to the HIP runtime torch already loaded (one runtime per process)
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import numpy as np
     import bfc_amd
     from bfc_amd import gen, build
@@ -114,7 +116,8 @@ def main():
     if dist:
         dist.barrier()
 
-    # ---- synthetic input (c2), one independent read set per rank (weak scaling: per-GPU work is fixed)
+    # ---- synthetic input (c2), one read set per rank (weak scaling: per-GPU work is fixed).  With N > 1 the N sets are one
+    # data set in rank-major batch order: global batch t = rank 0's t-th slice, rank 1's t-th slice, ...
     t0 = time.time()
     rs = gen.ReadSet(seed=2 + rank, G=4_600_000, cov=args.cov, L=150, err=0.01)
     seq, qual, off = rs.reads()
@@ -123,25 +126,62 @@ def main():
     s_seq, s_qual = bfc_amd.to_stream(seq, off), bfc_amd.to_stream(qual, off)
     stride = rs.L + 1
     batch_reads = min(args.batch_reads, n_reads)
-    g = bfc_amd.GpuCounter(K, BF_SHIFT, q=Q, n_hashes=N_HASHES, l_pre=L_PRE, device=local, max_batch_pos=batch_reads * stride)
+
+    def make_counter(n_ranks):
+        return bfc_amd.GpuCounter(K, BF_SHIFT, q=Q, n_hashes=N_HASHES, l_pre=L_PRE, device=local, max_batch_pos=batch_reads * stride,
+                                  rank=rank if n_ranks > 1 else 0, n_ranks=n_ranks)
+
+    # owner-computes exchange over RCCL; a collective preflight decides for ALL ranks whether it is usable here
+    mode = "1 GPU"
+    eng = None
+    if use_dist:
+        from bfc_amd import dist as bdist
+        import torch
+        ok = 1
+        try:
+            g = make_counter(world)
+            eng = bdist.GpuEngine(g)
+        except Exception as e:  # noqa: BLE001
+            log("[bench] rank %d: exchange path unavailable: %r" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            mode = "dp%d: read shards per GPU, bloom regions + table keys owned by one GPU each, 1 all-to-all of 16-byte k-mer records per batch (RCCL)" % world
+        else:
+            eng = None
+            g = make_counter(1)
+            mode = "%d independent read shards (exchange preflight failed: no cross-GPU counting)" % world
+    else:
+        g = make_counter(1)
     d_seq = g.dev_alloc(len(s_seq)); d_qual = g.dev_alloc(len(s_qual))
     g.h2d(d_seq, s_seq); g.h2d(d_qual, s_qual)
     del seq, qual
-    log("[bench] rank %d: %d reads, %d k-mers, input staged in HBM in %.1fs" % (rank, n_reads, n_kmers, time.time() - t0))
+    n_batches = (n_reads + batch_reads - 1) // batch_reads
+    if dist:
+        import torch
+        nb = torch.tensor([n_batches], device="cuda"); dist.all_reduce(nb, op=dist.ReduceOp.MAX); n_batches = int(nb.item())
+    log("[bench] rank %d: %d reads, %d k-mers, input staged in HBM in %.1fs; mode: %s" % (rank, n_reads, n_kmers, time.time() - t0, mode))
 
     stage = dict(hist1=0.0, scatter1=0.0, level2=0.0, bloom=0.0, commit=0.0, total=0.0)
     n_launch = 0
+    xchg_s = 0.0
 
     def step(acc):
-        nonlocal n_launch
+        nonlocal n_launch, xchg_s
         g.reset()
-        for r0 in range(0, n_reads, batch_reads):
-            r1 = min(n_reads, r0 + batch_reads)
-            g.count_dev(d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
-            if acc:
+        for t in range(n_batches):
+            r0 = min(n_reads, t * batch_reads); r1 = min(n_reads, r0 + batch_reads)
+            if eng is not None:
+                tx = time.perf_counter()
+                bdist.count_batch(eng, d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
+                if acc:
+                    xchg_s += time.perf_counter() - tx
+            elif r1 > r0:
+                g.count_dev(d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
+            if acc and r1 > r0:
                 ms = g.last_batch_ms()
                 if os.environ.get("BFC_BENCH_VERBOSE"):
-                    log("[bench] batch %d: %s" % (r0 // batch_reads, {k_: round(v_, 3) for k_, v_ in ms.items()}))
+                    log("[bench] batch %d: %s" % (t, {k_: round(v_, 3) for k_, v_ in ms.items()}))
                 for kk in stage:
                     stage[kk] += ms[kk]
                 n_launch += 1
@@ -162,14 +202,16 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
+    st = g.stats()
     if dist:
         import torch
-        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        tk = torch.tensor([float(n_kmers)], device="cuda", dtype=torch.float64); dist.all_reduce(tk); total_kmers = float(tk.item())
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        tk = torch.tensor([float(n_kmers), float(st["n_kmers"]), float(st["n_seen"]), float(st["n_keys"])], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tk)
+        total_kmers, gpu_kmers, tot_seen, tot_keys = [float(v) for v in tk.tolist()]
     else:
-        total_kmers = float(n_kmers)
-    st = g.stats()
-    assert st["n_kmers"] == n_kmers, "GPU k-mer count %d != host count %d" % (st["n_kmers"], n_kmers)
+        total_kmers, gpu_kmers, tot_seen, tot_keys = float(n_kmers), float(st["n_kmers"]), float(st["n_seen"]), float(st["n_keys"])
+    assert gpu_kmers == total_kmers, "GPU k-mer count %d != host count %d" % (gpu_kmers, total_kmers)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -183,9 +225,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "c2: E. coli 100x 150 bp synthetic (bfcgen seed 2+rank, G=4.6M, 1%% subst.), k=31, -b33 -H4, l_pre 20, "
                                    "bloom-insert + htab build; 1 step = reset + full count of %d reads / %d k-mers per GPU" % (n_reads, n_kmers),
-                       "batch_reads": batch_reads, "batches_per_step": (n_reads + batch_reads - 1) // batch_reads,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent read shards, one per GPU (no exchange yet)" % world,
-                       "phase_cycles": st.get("phase_cycles"), "n_seen": st["n_seen"], "n_distinct": st["n_keys"], "slow_buckets": st["slow_buckets"], "tab_cshift": st["tab_cshift"],
+                       "batch_reads": batch_reads, "batches_per_step": n_batches,
+                       "parallelism": mode, "exchange_plus_stages_s_per_step": round(xchg_s / args.steps, 4) if eng is not None else None,
+                       "phase_cycles": st.get("phase_cycles"), "n_seen": int(tot_seen), "n_distinct": int(tot_keys), "slow_buckets": st["slow_buckets"], "tab_cshift": st["tab_cshift"],
                        "stage_ms_per_step": {kk: round(v / args.steps, 3) for kk, v in stage.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_bloom (bloom regions in LDS + exact seen + table upsert)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

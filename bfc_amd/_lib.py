@@ -36,7 +36,7 @@ class BfcKmer(C.Structure):
 class BfcgParams(C.Structure):
     _fields_ = [("k", C.c_int), ("q", C.c_int), ("bf_shift", C.c_int), ("n_hashes", C.c_int), ("l_pre", C.c_int),
                 ("filter_mode", C.c_int), ("device", C.c_int), ("max_batch_pos", C.c_uint64),
-                ("region_shift", C.c_int), ("tab_cshift", C.c_int), ("debug_seen", C.c_int)]
+                ("region_shift", C.c_int), ("tab_cshift", C.c_int), ("debug_seen", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int)]
 
 
 # every symbol include/bfc_gpu.h declares: name -> (restype, argtypes)
@@ -64,6 +64,9 @@ SYMBOLS = {
     "bfcg_count_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_sync": (C.c_int, [C.c_void_p]),
+    "bfcg_mg_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "bfcg_mg_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, u32p]),
+    "bfcg_mg_process": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
     "bfcg_dev_alloc": (C.c_void_p, [C.c_void_p, C.c_uint64]),
     "bfcg_dev_free": (None, [C.c_void_p, C.c_void_p]),
     "bfcg_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),

@@ -195,12 +195,14 @@ class GpuCounter:
     """Device-level counting context (bfcg_ctx_t)."""
 
     def __init__(self, k, bf_shift, q=20, n_hashes=4, l_pre=20, filter_mode=0, device=0, max_batch_pos=1 << 24,
-                 region_shift=0, tab_cshift=0, debug_seen=False):
+                 region_shift=0, tab_cshift=0, debug_seen=False, rank=0, n_ranks=1):
         self.L = _lib.load()
         p = BfcgParams()
         self.L.bfcg_params_default(C.byref(p))
         p.k, p.q, p.bf_shift, p.n_hashes, p.l_pre, p.filter_mode = k, q, bf_shift, n_hashes, l_pre, filter_mode
         p.device, p.max_batch_pos, p.region_shift, p.tab_cshift, p.debug_seen = device, int(max_batch_pos), region_shift, tab_cshift, int(debug_seen)
+        p.rank, p.n_ranks = rank, n_ranks
+        self.rank, self.n_ranks = rank, n_ranks
         self.params = p
         self.bf_shift, self.k = bf_shift, k
         self.ctx = self.L.bfcg_create(C.byref(p))
@@ -233,6 +235,21 @@ class GpuCounter:
     def count_dev(self, d_seq, d_qual, n_pos):
         self._ck(self.L.bfcg_count_batch_dev(self.ctx, d_seq, d_qual, n_pos))
 
+    # ---- multi-GPU stages (owner computes); the exchange between them lives in bfc_amd/dist.py
+    def mg_info(self):
+        out = (C.c_int * 4)()
+        self.L.bfcg_mg_info(self.ctx, out)
+        return dict(nb1=out[0], nb_loc=out[1], rec_bytes=out[2], n_ranks=out[3])
+
+    def mg_scatter(self, d_seq, d_qual, n_pos, d_send):
+        counts = np.zeros(self.mg_info()["nb1"], dtype=np.uint32)
+        self._ck(self.L.bfcg_mg_scatter(self.ctx, d_seq, d_qual, n_pos, d_send, counts.ctypes.data_as(u32p)))
+        return counts
+
+    def mg_process(self, d_recv, seg_cnt):
+        seg_cnt = np.ascontiguousarray(seg_cnt, dtype=np.uint32)
+        self._ck(self.L.bfcg_mg_process(self.ctx, d_recv, seg_cnt.ctypes.data_as(u32p)))
+
     def dev_alloc(self, nbytes):
         p = self.L.bfcg_dev_alloc(self.ctx, nbytes)
         if not p:
@@ -262,7 +279,7 @@ class GpuCounter:
         return dict(hist1=float(out[0]), scatter1=float(out[1]), level2=float(out[2]), bloom=float(out[3]), commit=float(out[4]), total=float(out[5]))
 
     def bloom_bytes(self, which=0):
-        out = np.empty(1 << (self.bf_shift - 3), dtype=np.uint8)
+        out = np.empty((1 << (self.bf_shift - 3)) // self.n_ranks, dtype=np.uint8)  # the slice this rank owns
         self._ck(self.L.bfcg_bloom_to_host(self.ctx, which, out.ctypes.data))
         return out
 

@@ -34,7 +34,10 @@ struct bfcg_ctx {
 	uint64_t n_batches;
 	float last_ms[6];
 	int rw;                      // u64 words per record
-	uint64_t bloom_bytes;
+	uint64_t bloom_bytes;        // bytes of the bloom slice this rank owns
+	int n_ranks, rank, log2n;
+	uint32_t *d_seg, *h_seg;     // multi-GPU: seg_beg | seg_end | row_base | bucket_start (device / pinned host)
+	uint64_t recv_cap;           // records the level-2 buffers can take
 };
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
@@ -62,6 +65,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	if (prm->bf_shift < 9 + 0 || prm->bf_shift > 37) { set_err("bf_shift=%d outside [9,37] (bbf.c:9, bfc.h:9)", prm->bf_shift); return NULL; }
 	if (prm->n_hashes < 1 || prm->n_hashes > 12) { set_err("n_hashes=%d outside [1,12]", prm->n_hashes); return NULL; }
 	if (prm->max_batch_pos == 0 || prm->max_batch_pos >= (1ULL << 32)) { set_err("max_batch_pos must be in [1, 2^32)"); return NULL; }
+	const int n_ranks = prm->n_ranks > 0 ? prm->n_ranks : 1;
+	int log2n = 0; while ((1 << log2n) < n_ranks) ++log2n;
+	if ((1 << log2n) != n_ranks || n_ranks > 64 || prm->rank < 0 || prm->rank >= n_ranks) { set_err("n_ranks=%d must be a power of two <= 64 and 0 <= rank=%d < n_ranks", n_ranks, prm->rank); return NULL; }
+	if (n_ranks > 1 && prm->max_batch_pos >= (1ULL << (32 - log2n))) { set_err("with %d ranks a batch holds < 2^%d positions", n_ranks, 32 - log2n); return NULL; }
 	HIPCKN(hipSetDevice(prm->device));
 
 	bfcg_ctx_t *c = (bfcg_ctx_t *)calloc(1, sizeof(bfcg_ctx_t));
@@ -100,16 +107,21 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
 	c->rw = P.k <= 47 ? 2 : 3;
-	c->bloom_bytes = 1ULL << (P.bf_shift - 3);
+	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
+	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
+	P.idx_rank = n_ranks > 1 ? (uint32_t)prm->rank << (32 - log2n) : 0u;
+	c->bloom_bytes = (1ULL << (P.bf_shift - 3)) >> log2n; // owner computes: this rank keeps 1/n_ranks of the regions
 
 	BatchBufs &B = c->B;
 	B.max_kmers = prm->max_batch_pos;
-	const int nb1 = 1 << P.F1, nfine = 1 << P.F;
+	const int nb1 = 1 << P.F1, nfine = (1 << P.F) >> log2n; // fine buckets owned by this rank
+	// records arriving from all ranks for the owned buckets: hashing balances them; 25 % + 1 M head room, checked per batch
+	c->recv_cap = n_ranks > 1 ? B.max_kmers + B.max_kmers / 4 + (1u << 20) : B.max_kmers;
 	HIPCKN(hipStreamCreate(&c->st));
 	for (int i = 0; i < 6; ++i) HIPCKN(hipEventCreate(&c->ev[i]));
 	{
 		const uint64_t tiles1 = (prm->max_batch_pos + BFCG_TILE1 - 1) / BFCG_TILE1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
-		const uint64_t rows2 = B.max_kmers / BFCG_TILE2 + nb1 + 1;
+		const uint64_t rows2 = c->recv_cap / BFCG_TILE2 + nb1 + 1;
 		HIPCKN(hipMalloc(&B.rows1, sizeof(uint32_t) * tiles1 * nb1));
 		HIPCKN(hipMalloc(&B.chunk1, sizeof(uint32_t) * chunks1 * nb1));
 		HIPCKN(hipMalloc(&B.start1, sizeof(uint32_t) * (nb1 + 1) * 2)); B.row_base = B.start1 + nb1 + 1;
@@ -119,7 +131,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		}
 	}
 	HIPCKN(hipMalloc(&B.recs1, B.max_kmers * c->rw * 8));
-	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, B.max_kmers * c->rw * 8));
+	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw * 8));
+	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * (4 * nb1 + 8))); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * (4 * nb1 + 8))); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
 	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
@@ -152,7 +165,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->B.rows1); (void)hipFree(c->B.chunk1); (void)hipFree(c->B.start1); (void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs1); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
-	(void)hipFree(c->d_seq); (void)hipFree(c->d_qual); (void)hipHostFree(c->h_stats);
+	(void)hipFree(c->d_seq); (void)hipFree(c->d_qual); (void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
 	(void)hipStreamDestroy(c->st);
 	free(c);
@@ -217,14 +230,8 @@ static int table_maintain(bfcg_ctx_t *c)
 	}
 }
 
-extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
+static int finish_batch(bfcg_ctx_t *c)
 {
-	if (n_pos == 0) return 0;
-	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
-	HIPCK(hipSetDevice(c->prm.device));
-	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
-	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
-	run_batch(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, c->st, c->ev);
 	HIPCK(hipGetLastError());
 	if (fetch_stats(c) != 0) return -1;
 	++c->n_batches;
@@ -233,6 +240,75 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 	if (c->h_stats[ST_ERR_POOL]) return set_err("first-setter pool exhausted in %llu bloom regions: batch too large for max_batch_pos", (unsigned long long)c->h_stats[ST_ERR_POOL]);
 	if (c->B.table) return table_maintain(c);
 	return 0;
+}
+
+// ---- multi-GPU (owner computes): stage A on every rank, exchange by the caller, stage B on the owner
+
+extern "C" int bfcg_mg_info(bfcg_ctx_t *c, int out[4])
+{
+	out[0] = 1 << c->P.F1; out[1] = (1 << c->P.F1) >> c->log2n; out[2] = c->rw * 8; out[3] = c->n_ranks;
+	return 0;
+}
+
+extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts)
+{
+	const int nb1 = 1 << c->P.F1;
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	HIPCK(hipSetDevice(c->prm.device));
+	if (n_pos == 0) { memset(counts, 0, sizeof(uint32_t) * nb1); return 0; }
+	run_stage_a(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->st, c->ev);
+	HIPCK(hipGetLastError());
+	uint32_t *h = (uint32_t *)(c->h_stats + ST_N * (ST_SLOTS + 1)); // pinned scratch behind the statistics mirror
+	(void)h;
+	uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (nb1 + 1));
+	hipError_t e = hipMemcpyAsync(tmp, c->B.start1, sizeof(uint32_t) * (nb1 + 1), hipMemcpyDeviceToHost, c->st);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+	if (e != hipSuccess) { free(tmp); return set_err("reading the level-1 bucket starts failed: %s", hipGetErrorString(e)); }
+	for (int b = 0; b < nb1; ++b) counts[b] = tmp[b + 1] - tmp[b];
+	free(tmp);
+	return 0;
+}
+
+// d_recv: records for the owned level-1 buckets, source-major (rank 0's block, rank 1's block, ...), inside each block
+// grouped by bucket; seg_cnt[s * nb_loc + b] = records from source s for owned bucket b
+extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt)
+{
+	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, n_seg = nb_loc * N;
+	HIPCK(hipSetDevice(c->prm.device));
+	uint32_t *seg_beg = c->h_seg, *seg_end = seg_beg + n_seg, *row_base = seg_end + n_seg, *bucket_start = row_base + n_seg + 1;
+	uint64_t off = 0, rows = 0, tot = 0;
+	for (int s = 0; s < N; ++s)
+		for (int b = 0; b < nb_loc; ++b) { // position of (source s, bucket b) in the receive buffer
+			int seg = b * N + s;
+			seg_beg[seg] = (uint32_t)off; off += seg_cnt[s * nb_loc + b]; seg_end[seg] = (uint32_t)off;
+		}
+	if (off > c->recv_cap) return set_err("received %llu records for this rank's buckets, capacity %llu", (unsigned long long)off, (unsigned long long)c->recv_cap);
+	for (int seg = 0; seg < n_seg; ++seg) { row_base[seg] = (uint32_t)rows; rows += (seg_end[seg] - seg_beg[seg] + BFCG_TILE2 - 1) / BFCG_TILE2; }
+	row_base[n_seg] = (uint32_t)rows;
+	for (int b = 0; b < nb_loc; ++b) {
+		bucket_start[b] = (uint32_t)tot;
+		for (int s = 0; s < N; ++s) tot += seg_cnt[s * nb_loc + b];
+	}
+	bucket_start[nb_loc] = (uint32_t)tot;
+	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
+	HIPCK(hipMemcpyAsync(c->d_seg, c->h_seg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
+	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
+	const uint32_t *d = c->d_seg;
+	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->ev);
+	return finish_batch(c);
+}
+
+extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
+{
+	if (c->n_ranks > 1) return set_err("this context is one of %d ranks: use bfcg_mg_scatter / bfcg_mg_process", c->n_ranks);
+	if (n_pos == 0) return 0;
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	HIPCK(hipSetDevice(c->prm.device));
+	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
+	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
+	run_batch(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, c->st, c->ev);
+	return finish_batch(c);
 }
 
 extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)

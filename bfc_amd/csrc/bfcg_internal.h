@@ -21,6 +21,7 @@ struct KParams {
 	int tab_cshift; // log2(slots per sub-table region)
 	uint32_t fs_cap, list_cap; // LDS first-setter table entries (pow2), unresolved-list entries
 	uint32_t ag_cap;            // LDS aggregation table entries (pow2)
+	uint32_t idx_rank;          // rank << (32 - rank_bits): prefixed to the in-batch position so file order is rank-major
 	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
 	int bloom_pf;               // records per thread kept in registers by the bloom kernel (2/4)
 	int bloom_bt;               // threads per workgroup of the bloom kernel (256/512/1024)
@@ -40,6 +41,9 @@ struct BatchBufs {
 	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
 };
 
+void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev);
+void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
+                 const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev);
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev);
 int bloom_lds_bytes(const KParams &P);
 hipError_t set_bloom_lds_attr(const KParams &P);

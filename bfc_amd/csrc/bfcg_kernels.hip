@@ -282,7 +282,7 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 			if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
 				uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
 				uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
-				uint32_t idx = (uint32_t)(tile * TILE + r); // end position = file order
+				uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
 				Rec<RW>::pack(out + dst * RW, (uint64_t)y0, (uint64_t)y1, idx, hi);
 			}
 		}
@@ -302,17 +302,18 @@ __device__ __forceinline__ int row_bucket(const uint32_t *__restrict__ row_base,
 }
 
 template <typename W, int RW, int TILE, int BT>
-__global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
+__global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
+                                              const uint32_t *__restrict__ seg_end, int n_seg,
                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2)
 {
 	__shared__ uint32_t hist[512];
-	const int nb2 = 1 << P.F2, nb1 = 1 << P.F1;
-	const uint32_t n_rows = row_base[nb1];
+	const int nb2 = 1 << P.F2;
+	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
 	if (row >= n_rows) return;
-	const int b1 = row_bucket(row_base, nb1, (uint32_t)row);
+	const int b1 = row_bucket(row_base, n_seg, (uint32_t)row); // segment = one level-1 bucket (from one source rank)
 	const uint32_t tile = (uint32_t)row - row_base[b1];
-	const uint32_t s = start1[b1], e = start1[b1 + 1];
+	const uint32_t s = seg_beg[b1], e = seg_end[b1];
 	for (int i = threadIdx.x; i < nb2; i += BT) hist[i] = 0;
 	__syncthreads();
 #pragma unroll
@@ -330,12 +331,12 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restr
 }
 
 // one workgroup per level-1 bucket: column totals -> fine starts; rows -> absolute offsets in place
-__global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__restrict__ start1, const uint32_t *__restrict__ row_base,
-                                               uint32_t *__restrict__ rows2, uint32_t *__restrict__ start2)
+__global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__restrict__ bucket_start, int segs_per_bucket,
+                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2, uint32_t *__restrict__ start2)
 {
 	__shared__ uint32_t tot[512];
 	const int nb2 = 1 << P.F2, b1 = blockIdx.x, c = threadIdx.x;
-	const uint32_t r0 = row_base[b1], r1 = row_base[b1 + 1];
+	const uint32_t r0 = row_base[b1 * segs_per_bucket], r1 = row_base[(b1 + 1) * segs_per_bucket];
 	uint32_t total = 0;
 	if (c < nb2) {
 #pragma unroll 16
@@ -350,19 +351,20 @@ __global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__rest
 		__syncthreads();
 	}
 	if (c < nb2) {
-		uint32_t run = start1[b1] + tot[c] - total;
+		uint32_t run = bucket_start[b1] + tot[c] - total;
 		start2[((size_t)b1 << P.F2) + c] = run;
 #pragma unroll 16
 		for (uint32_t r = r0; r < r1; ++r) { uint32_t v = rows2[(size_t)r * nb2 + c]; rows2[(size_t)r * nb2 + c] = run; run += v; }
 	}
-	if (b1 == (int)gridDim.x - 1 && c == 0) start2[(size_t)gridDim.x << P.F2] = start1[gridDim.x];
+	if (b1 == (int)gridDim.x - 1 && c == 0) start2[(size_t)gridDim.x << P.F2] = bucket_start[gridDim.x];
 }
 
 // The tile is first ordered by fine bucket in LDS, then copied out: neighbouring lanes store neighbouring
 // records of one run, so the 16-byte stores coalesce into line-sized requests (registers->HBM scatter of single
 // records measured 2x WRITE_SIZE inflation and ~1.1 TB/s).
 template <typename W, int RW, int TILE, int BT>
-__global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ start1,
+__global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
+                                                 const uint32_t *__restrict__ seg_end, int n_seg,
                                                  const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ rows2,
                                                  uint64_t *__restrict__ out)
 {
@@ -371,13 +373,13 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
 	uint64_t *stage = reinterpret_cast<uint64_t *>(smem2);                              // TILE * RW words
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 8); // bucket of each staged record
 	__shared__ uint32_t cnt[512], loff[512], gdelta[512];
-	const int nb2 = 1 << P.F2, nb1 = 1 << P.F1;
-	const uint32_t n_rows = row_base[nb1];
+	const int nb2 = 1 << P.F2;
+	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
 	if (row >= n_rows) return;
-	const int b1 = row_bucket(row_base, nb1, (uint32_t)row);
+	const int b1 = row_bucket(row_base, n_seg, (uint32_t)row);
 	const uint32_t tile = (uint32_t)row - row_base[b1];
-	const uint32_t s = start1[b1], e = start1[b1 + 1];
+	const uint32_t s = seg_beg[b1], e = seg_end[b1];
 	const uint32_t *rowp = rows2 + (size_t)row * nb2;
 	for (int i = threadIdx.x; i < 512; i += BT) cnt[i] = 0;
 	__syncthreads();
@@ -549,6 +551,7 @@ struct BloomArgs {
 	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
 	uint64_t *agg_out;             // aggregated seen k-mers: [n_fine][ag_cap][3] (y0, y1, count|high<<16), or NULL = commit inline
 	uint32_t *agg_cnt;             // entries per fine bucket
+	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
 };
 
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 {
 	const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
 	const uint32_t f = (uint32_t)(gid / P.ag_cap), j = (uint32_t)(gid % P.ag_cap);
-	if (f >= (1u << P.F) || j >= A.agg_cnt[f]) return;
+	if (f >= A.n_fine || j >= A.agg_cnt[f]) return;
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	const uint64_t *src = A.agg_out + gid * 3;
 	const uint32_t c = (uint32_t)src[2];
@@ -1005,10 +1008,11 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 #define TILE2 BFCG_TILE2
 #define BT2 512
 
+// stage A: bases -> records grouped by (global) level-1 bucket in `out1`; B.start1[2^F1+1] = bucket starts
 template <typename W, int RW>
-static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev)
+static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
 {
-	const int nb1 = 1 << P.F1, nfine = 1 << P.F;
+	const int nb1 = 1 << P.F1;
 	const int64_t tiles1 = (n_pos + TILE1 - 1) / TILE1;
 	const int n_chunks = (int)((tiles1 + SCAN_CH - 1) / SCAN_CH);
 	if (ev) hipEventRecord(ev[0], st);
@@ -1018,22 +1022,31 @@ static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(512), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.recs1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
-	const uint64_t *fine_recs = B.recs1; const uint32_t *fine_start = B.start1;
+}
+
+// stage B: records in `in1` as n_seg segments (seg_beg/seg_end, row_base over segments, bucket_start over the
+// nb_loc = n_seg/segs_per_bucket owned level-1 buckets) -> fine buckets -> bloom regions -> table
+template <typename W, int RW>
+static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg,
+                          int segs_per_bucket, const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev)
+{
+	const int nb_loc = n_seg / segs_per_bucket, nfine = nb_loc << P.F2;
+	const uint64_t *fine_recs = in1; const uint32_t *fine_start = bucket_start;
 	if (P.F2 > 0) {
-		// rows of level 2 <= k-mers/TILE2 + one ragged row per bucket; surplus blocks exit at once
-		const unsigned g2 = (unsigned)((((uint64_t)n_pos / TILE2 + nb1 + 1 + 7) / 8) * 8);
-		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, B.recs1, B.start1, B.row_base, B.rows2);
-		hipLaunchKernelGGL(k_scan2, dim3(nb1), dim3(512), 0, st, P, B.start1, B.row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 8 + 2), st, P, B.recs1, B.start1, B.row_base, B.rows2, B.recs2);
+		// rows of level 2 <= records/TILE2 + one ragged row per segment; surplus blocks exit at once
+		const unsigned g2 = (unsigned)(((n_rec_bound / TILE2 + n_seg + 1 + 7) / 8) * 8);
+		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
+		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3(512), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 8 + 2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, B.recs2);
 		fine_recs = B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
 	BloomArgs A;
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
-	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt;
+	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine;
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.n_hashes == 4) {
 		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4>), dim3(nfine), dim3(1024), lds, st, P, A);
@@ -1048,11 +1061,20 @@ static void run_batch_t(const KParams &P, const BatchBufs &B, const uint8_t *seq
 	if (ev) hipEventRecord(ev[5], st);
 }
 
+#define DISPATCH_W(fn, ...) do { if (P.k <= 32) fn<uint32_t, 2>(__VA_ARGS__); else if (P.k <= 47) fn<uint64_t, 2>(__VA_ARGS__); else fn<uint64_t, 3>(__VA_ARGS__); } while (0)
+
+void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
+{ DISPATCH_W(run_stage_a_t, P, B, seq, qual, n_pos, out1, st, ev); }
+
+void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
+                 const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev)
+{ DISPATCH_W(run_stage_b_t, P, B, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, bucket_start, n_rec_bound, st, ev); }
+
+// single GPU: both stages back to back, segment = level-1 bucket, everything stays on the device
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev)
 {
-	if (P.k <= 32) run_batch_t<uint32_t, 2>(P, B, seq, qual, n_pos, st, ev);
-	else if (P.k <= 47) run_batch_t<uint64_t, 2>(P, B, seq, qual, n_pos, st, ev);
-	else run_batch_t<uint64_t, 3>(P, B, seq, qual, n_pos, st, ev);
+	run_stage_a(P, B, seq, qual, n_pos, B.recs1, st, ev);
+	run_stage_b(P, B, B.recs1, B.start1, B.start1 + 1, 1 << P.F1, 1, B.row_base, B.start1, (uint64_t)n_pos, st, ev);
 }
 
 int bloom_lds_bytes(const KParams &P)

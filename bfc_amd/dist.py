@@ -1,0 +1,152 @@
+"""Multi-GPU orchestration: owner-computes partition of the k-mer counting path.
+
+One process per GPU.  Rank r owns 1/N of the bloom regions (contiguous level-1 buckets) and every k-mer that falls
+into them, hence also a disjoint part of the count table.  Per global batch:
+
+    stage A (every rank)   bases -> records grouped by level-1 bucket          bfcg_mg_scatter
+    exchange               all-to-all of bucket sizes, then of records         torch.distributed (RCCL on GPUs, gloo in CPU tests)
+    stage B (the owner)    level 2 -> bloom regions -> table                    bfcg_mg_process
+
+File order across ranks is rank-major inside a batch (rank 0's share, then rank 1's, ...): stage A prefixes the rank to
+every record's in-batch position, which is what the bloom kernel orders first setters by -- so results are those of
+`bfc -t1` on the batches concatenated in that order.
+
+The exchange code below is backend-agnostic: an *engine* supplies `scatter(...) -> counts` / `process(seg_cnt)` and
+owns `send` / `recv` tensors.  `GpuEngine` drives libbfc_gpu.so; tests/ supply a CPU engine built on the oracle to pin
+the protocol under gloo with world_size 2.
+"""
+import numpy as np
+
+
+def exchange(engine, counts, group=None):
+    """All-to-all of one batch. counts: uint32[nb1] sizes of this rank's level-1 buckets (records in engine.send,
+    grouped by bucket). Returns seg_cnt uint32[world][nb_loc] for the owned buckets; engine.recv holds the records
+    source-major."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    nb1 = len(counts)
+    if nb1 % world:
+        raise ValueError("level-1 buckets (%d) not divisible by world size %d" % (nb1, world))
+    nb_loc = nb1 // world
+    rw = engine.rec_words
+    dev = engine.send.device
+    mine = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).view(world, nb_loc).to(dev)  # [destination][bucket]
+    theirs = torch.empty_like(mine)                                                                       # [source][bucket]
+    dist.all_to_all_single(theirs, mine, group=group)
+    theirs_h = theirs.cpu()
+    in_splits = (mine.cpu().sum(1) * rw).tolist()
+    out_splits = (theirs_h.sum(1) * rw).tolist()
+    n_out = int(sum(out_splits))
+    if n_out > engine.recv.numel():
+        raise RuntimeError("rank receives %d words, receive buffer holds %d" % (n_out, engine.recv.numel()))
+    dist.all_to_all_single(engine.recv[:n_out], engine.send[:int(sum(in_splits))], out_splits, in_splits, group=group)
+    return theirs_h.numpy().astype(np.uint32)
+
+
+class GpuEngine:
+    """Stage A / stage B on libbfc_gpu.so with torch-owned exchange buffers (torch is plumbing: device memory + RCCL)."""
+
+    def __init__(self, counter):
+        import torch
+        self.g = counter
+        info = counter.mg_info()
+        self.rec_words = info["rec_bytes"] // 8
+        cap = int(counter.params.max_batch_pos)
+        dev = torch.device("cuda", counter.params.device)
+        self.send = torch.empty(cap * self.rec_words, dtype=torch.int64, device=dev)
+        self.recv = torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int64, device=dev)
+
+    def scatter(self, d_seq, d_qual, n_pos):
+        return self.g.mg_scatter(d_seq, d_qual, n_pos, self.send.data_ptr())  # synchronises the library's stream
+
+    def process(self, seg_cnt):
+        import torch
+        torch.cuda.synchronize(self.send.device)  # the all-to-all ran on torch's stream
+        self.g.mg_process(self.recv.data_ptr(), seg_cnt)
+
+
+def count_batch(engine, d_seq, d_qual, n_pos, group=None):
+    """One global batch on this rank: stage A, exchange, stage B."""
+    counts = engine.scatter(d_seq, d_qual, n_pos)
+    seg_cnt = exchange(engine, counts, group)
+    engine.process(seg_cnt)
+    return seg_cnt
+
+
+class LocalCluster:
+    """N ranks emulated on ONE device by N contexts and a host-mediated exchange: exercises stage A / stage B, the
+    segment bookkeeping and the rank-major order on real kernels where only one GPU is available (tests)."""
+
+    def __init__(self, gpu_lib, n_ranks, k, bf_shift, max_batch_pos, **kw):
+        self.n = n_ranks
+        self.ctx = [gpu_lib.GpuCounter(k, bf_shift, max_batch_pos=max_batch_pos, rank=r, n_ranks=n_ranks, **kw) for r in range(n_ranks)]
+        info = self.ctx[0].mg_info()
+        self.rw, self.nb1, self.nb_loc = info["rec_bytes"] // 8, info["nb1"], info["nb_loc"]
+        self.cap = max_batch_pos
+        self.d_send = [c.dev_alloc(self.cap * self.rw * 8) for c in self.ctx]
+        self.d_recv = [c.dev_alloc((self.cap * 2 + 4096) * self.rw * 8) for c in self.ctx]
+
+    def batch(self, shares):
+        """shares[r] = (seq_stream, qual_stream or None) of rank r for this global batch."""
+        import ctypes as C
+        sends, counts = [], []
+        for r, (s, q) in enumerate(shares):
+            c = self.ctx[r]
+            s = np.ascontiguousarray(s, dtype=np.uint8)
+            d_s = c.dev_alloc(max(len(s), 16)); c.h2d(d_s, s)
+            d_q = None
+            if q is not None:
+                q = np.ascontiguousarray(q, dtype=np.uint8)
+                d_q = c.dev_alloc(max(len(q), 16)); c.h2d(d_q, q)
+            cnt = c.mg_scatter(d_s, d_q, len(s), self.d_send[r])
+            host = np.empty(int(cnt.sum()) * self.rw, dtype=np.uint64)
+            if len(host):
+                c._ck(c.L.bfcg_d2h(c.ctx, host.ctypes.data, self.d_send[r], host.nbytes))
+            sends.append(host); counts.append(cnt)
+            c.dev_free(d_s)
+            if d_q:
+                c.dev_free(d_q)
+        for o in range(self.n):  # owner o receives, source-major, its bucket range from every source
+            parts, seg = [], np.zeros((self.n, self.nb_loc), dtype=np.uint32)
+            for s_ in range(self.n):
+                starts = np.concatenate([[0], np.cumsum(counts[s_].astype(np.int64))])
+                lo, hi = starts[o * self.nb_loc], starts[(o + 1) * self.nb_loc]
+                parts.append(sends[s_][lo * self.rw:hi * self.rw])
+                seg[s_] = counts[s_][o * self.nb_loc:(o + 1) * self.nb_loc]
+            recv = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+            if len(recv):
+                self.ctx[o].h2d(self.d_recv[o], recv)
+            self.ctx[o].mg_process(self.d_recv[o], seg)
+
+    def bloom_bytes(self, which=0):
+        return np.concatenate([c.bloom_bytes(which) for c in self.ctx])
+
+    def stats(self):
+        out = {}
+        for c in self.ctx:
+            for k_, v in c.stats().items():
+                if isinstance(v, int):
+                    out[k_] = out.get(k_, 0) + v
+        return out
+
+    def export_sorted(self):
+        """Union of the per-rank tables (disjoint key sets) in L1 form."""
+        parts = [c.export_table().export_sorted() for c in self.ctx]
+        sizes = sum(p[0].astype(np.int64) for p in parts)
+        n_sub = len(sizes)
+        starts = [np.concatenate([[0], np.cumsum(p[0].astype(np.int64))]) for p in parts]
+        out = np.empty(int(sizes.sum()), dtype=np.uint64)
+        pos = 0
+        nz = np.nonzero(sizes)[0]
+        for sub in nz:
+            chunk = np.concatenate([p[1][st[sub]:st[sub + 1]] for p, st in zip(parts, starts)])
+            chunk.sort()
+            out[pos:pos + len(chunk)] = chunk
+            pos += len(chunk)
+        assert pos == len(out) and n_sub == len(parts[0][0])
+        return sizes.astype(np.uint32), out
+
+    def close(self):
+        for c, a, b in zip(self.ctx, self.d_send, self.d_recv):
+            c.dev_free(a); c.dev_free(b); c.close()

@@ -87,6 +87,7 @@ typedef struct {
 	int region_shift;           /* log2 bloom blocks per LDS region; 0 = default */
 	int tab_cshift;             /* initial log2 slots per sub-table; 0 = default */
 	int debug_seen;             /* allocate the per-position seen-flag buffer (tests) */
+	int rank, n_ranks;          /* multi-GPU, owner computes: this process is rank of n_ranks (0/0 or 0/1: single GPU) */
 } bfcg_params_t;
 
 void bfcg_params_default(bfcg_params_t *p);
@@ -106,6 +107,16 @@ int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos);
 int bfcg_sync(bfcg_ctx_t *c);
 
+/* Multi-GPU (one process per GPU; SURVEY 8e partitioning B, "owner computes"): rank r owns 1/n_ranks of the bloom
+ * regions and every k-mer that falls into them.  Per global batch every rank calls bfcg_mg_scatter on ITS contiguous
+ * share of the batch (rank-major file order): records are written to d_send grouped by level-1 bucket and
+ * counts[2^F1] (host) receives the bucket sizes; bucket b belongs to rank b / nb_loc.  The caller exchanges records
+ * (all-to-all over RCCL) so that d_recv holds, source-major, the records of the owned buckets, and calls
+ * bfcg_mg_process with seg_cnt[source][owned bucket].  info: {2^F1, owned buckets nb_loc, bytes per record, n_ranks}. */
+int bfcg_mg_info(bfcg_ctx_t *c, int out[4]);
+int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts);
+int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt);
+
 /* device memory helpers so that callers (bench.py) can stage inputs without another runtime */
 void *bfcg_dev_alloc(bfcg_ctx_t *c, uint64_t bytes);
 void  bfcg_dev_free(bfcg_ctx_t *c, void *p);
@@ -123,7 +134,7 @@ int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
 int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[6]);
 
 /* results */
-int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *dst);   /* 2^(bf_shift-3) bytes */
+int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *dst);   /* 2^(bf_shift-3) / n_ranks bytes: the owned slice */
 bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which);   /* host bfc_bf_t (caller: bfc_bf_destroy) */
 bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (caller: bfc_ch_destroy) */
 
