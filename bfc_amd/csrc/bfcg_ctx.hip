@@ -33,7 +33,7 @@ struct bfcg_ctx {
 	unsigned long long *h_stats; // pinned mirror
 	uint64_t n_batches;
 	float last_ms[6];
-	int rw;                      // u64 words per record
+	int rw;                      // bytes per record: 12 (k <= 31), 16 (k <= 47), 24
 	uint64_t bloom_bytes;        // bytes of the bloom slice this rank owns
 	int n_ranks, rank, log2n;
 	uint32_t *d_seg, *h_seg;     // multi-GPU: seg_beg | seg_end | row_base | bucket_start (device / pinned host)
@@ -106,7 +106,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
-	c->rw = P.k <= 47 ? 2 : 3;
+	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 24;
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
 	P.idx_rank = n_ranks > 1 ? (uint32_t)prm->rank << (32 - log2n) : 0u;
@@ -130,8 +130,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 			HIPCKN(hipMalloc(&B.start2, sizeof(uint32_t) * (nfine + 1)));
 		}
 	}
-	HIPCKN(hipMalloc(&B.recs1, B.max_kmers * c->rw * 8));
-	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw * 8));
+	HIPCKN(hipMalloc(&B.recs1, B.max_kmers * c->rw));
+	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw));
 	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * (4 * nb1 + 8))); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * (4 * nb1 + 8))); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
@@ -246,7 +246,7 @@ static int finish_batch(bfcg_ctx_t *c)
 
 extern "C" int bfcg_mg_info(bfcg_ctx_t *c, int out[4])
 {
-	out[0] = 1 << c->P.F1; out[1] = (1 << c->P.F1) >> c->log2n; out[2] = c->rw * 8; out[3] = c->n_ranks;
+	out[0] = 1 << c->P.F1; out[1] = (1 << c->P.F1) >> c->log2n; out[2] = c->rw; out[3] = c->n_ranks;
 	return 0;
 }
 

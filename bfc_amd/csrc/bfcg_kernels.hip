@@ -127,28 +127,65 @@ __device__ __forceinline__ bool kmer_at(const uint32_t *planes, int r, int k, W 
 // ------------------------------------------------------------------------------------------
 // records
 
-template <int RW> struct Rec;
-template <> struct Rec<2> { // k <= 47: y0,y1 < 2^47; flag at bit 47 of w0; idx split over the top 16 bits
-	static __device__ __forceinline__ void pack(uint64_t *dst, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+// A record is RD dwords:  RD=3 (k <= 31): y0 | is_high<<31, y1, file index   -- 12 bytes
+//                         RD=4 (k <= 47): two u64 = y0 | is_high<<47 | index[15:0]<<48, y1 | index[31:16]<<48
+//                         RD=6 (k <= 63): y0 | is_high<<63, y1, index (u64 each)
+template <int RD> struct RecW { uint32_t d[RD]; };
+
+template <int RD> __device__ __forceinline__ RecW<RD> rec_load(const uint32_t *p);
+template <> __device__ __forceinline__ RecW<3> rec_load<3>(const uint32_t *p)
+{ const uint3 v = *reinterpret_cast<const uint3 *>(p); RecW<3> r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; return r; }
+template <> __device__ __forceinline__ RecW<4> rec_load<4>(const uint32_t *p)
+{ const uint4 v = *reinterpret_cast<const uint4 *>(p); RecW<4> r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; return r; }
+template <> __device__ __forceinline__ RecW<6> rec_load<6>(const uint32_t *p)
+{
+	const uint2 *q = reinterpret_cast<const uint2 *>(p);
+	const uint2 a = q[0], b = q[1], c = q[2];
+	RecW<6> r; r.d[0] = a.x; r.d[1] = a.y; r.d[2] = b.x; r.d[3] = b.y; r.d[4] = c.x; r.d[5] = c.y; return r;
+}
+template <int RD> __device__ __forceinline__ void rec_store(uint32_t *p, const RecW<RD> &r);
+template <> __device__ __forceinline__ void rec_store<3>(uint32_t *p, const RecW<3> &r)
+{ *reinterpret_cast<uint3 *>(p) = make_uint3(r.d[0], r.d[1], r.d[2]); }
+template <> __device__ __forceinline__ void rec_store<4>(uint32_t *p, const RecW<4> &r)
+{ *reinterpret_cast<uint4 *>(p) = make_uint4(r.d[0], r.d[1], r.d[2], r.d[3]); }
+template <> __device__ __forceinline__ void rec_store<6>(uint32_t *p, const RecW<6> &r)
+{
+	uint2 *q = reinterpret_cast<uint2 *>(p);
+	q[0] = make_uint2(r.d[0], r.d[1]); q[1] = make_uint2(r.d[2], r.d[3]); q[2] = make_uint2(r.d[4], r.d[5]);
+}
+
+template <int RD> struct Rec;
+template <> struct Rec<3> {
+	static __device__ __forceinline__ void pack(RecW<3> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	{ r.d[0] = (uint32_t)y0 | ((uint32_t)hi << 31); r.d[1] = (uint32_t)y1; r.d[2] = idx; }
+	static __device__ __forceinline__ void unpack(const RecW<3> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	{ y0 = r.d[0] & 0x7fffffffu; hi = r.d[0] >> 31; y1 = r.d[1]; idx = r.d[2]; }
+};
+template <> struct Rec<4> {
+	static __device__ __forceinline__ void pack(RecW<4> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
 	{
-		ulonglong2 v;
-		v.x = y0 | ((uint64_t)hi << 47) | ((uint64_t)(idx & 0xffffu) << 48);
-		v.y = y1 | ((uint64_t)(idx >> 16) << 48);
-		*reinterpret_cast<ulonglong2 *>(dst) = v;
+		const uint64_t a = y0 | ((uint64_t)hi << 47) | ((uint64_t)(idx & 0xffffu) << 48), b = y1 | ((uint64_t)(idx >> 16) << 48);
+		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)b; r.d[3] = (uint32_t)(b >> 32);
 	}
-	static __device__ __forceinline__ void unpack(const uint64_t *src, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	static __device__ __forceinline__ void unpack(const RecW<4> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
 	{
-		ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
-		y0 = v.x & ((1ULL << 47) - 1); hi = (v.x >> 47) & 1;
-		y1 = v.y & ((1ULL << 48) - 1);
-		idx = (uint32_t)(v.x >> 48) | ((uint32_t)(v.y >> 48) << 16);
+		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32), b = r.d[2] | ((uint64_t)r.d[3] << 32);
+		y0 = a & ((1ULL << 47) - 1); hi = (a >> 47) & 1;
+		y1 = b & ((1ULL << 48) - 1);
+		idx = (uint32_t)(a >> 48) | ((uint32_t)(b >> 48) << 16);
 	}
 };
-template <> struct Rec<3> { // k <= 63
-	static __device__ __forceinline__ void pack(uint64_t *dst, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
-	{ dst[0] = y0 | ((uint64_t)hi << 63); dst[1] = y1; dst[2] = idx; }
-	static __device__ __forceinline__ void unpack(const uint64_t *src, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
-	{ y0 = src[0] & ~(1ULL << 63); hi = src[0] >> 63; y1 = src[1]; idx = (uint32_t)src[2]; }
+template <> struct Rec<6> {
+	static __device__ __forceinline__ void pack(RecW<6> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	{
+		const uint64_t a = y0 | ((uint64_t)hi << 63);
+		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)y1; r.d[3] = (uint32_t)(y1 >> 32); r.d[4] = idx; r.d[5] = 0;
+	}
+	static __device__ __forceinline__ void unpack(const RecW<6> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	{
+		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32);
+		y0 = a & ~(1ULL << 63); hi = a >> 63; y1 = r.d[2] | ((uint64_t)r.d[3] << 32); idx = r.d[4];
+	}
 };
 
 template <typename W> __device__ __forceinline__ uint32_t fine_id(const KParams &P, uint64_t y0, uint64_t y1)
@@ -261,7 +298,7 @@ __global__ __launch_bounds__(256) void k_apply(uint32_t *__restrict__ rows, int 
 // pass B: K1 again, records stored straight from registers to rows1[tile][bucket] + rank
 template <typename W, int RW, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
-                                                 int64_t n_pos, const uint32_t *__restrict__ rows1, uint64_t *__restrict__ out)
+                                                 int64_t n_pos, const uint32_t *__restrict__ rows1, uint32_t *__restrict__ out)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	constexpr int S = TILE / BT;
@@ -283,7 +320,9 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 				uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
 				uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
 				uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
-				Rec<RW>::pack(out + dst * RW, (uint64_t)y0, (uint64_t)y1, idx, hi);
+				RecW<RW> rec;
+				Rec<RW>::pack(rec, (uint64_t)y0, (uint64_t)y1, idx, hi);
+				rec_store<RW>(out + dst * RW, rec);
 			}
 		}
 	}
@@ -302,7 +341,7 @@ __device__ __forceinline__ int row_bucket(const uint32_t *__restrict__ row_base,
 }
 
 template <typename W, int RW, int TILE, int BT>
-__global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
+__global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
                                               const uint32_t *__restrict__ seg_end, int n_seg,
                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2)
 {
@@ -321,7 +360,7 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint64_t *__restr
 		uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(in + i * RW, y0, y1, idx, hi);
+			Rec<RW>::unpack(rec_load<RW>(in + i * RW), y0, y1, idx, hi);
 			atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
 		}
 	}
@@ -363,15 +402,15 @@ __global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__rest
 // records of one run, so the 16-byte stores coalesce into line-sized requests (registers->HBM scatter of single
 // records measured 2x WRITE_SIZE inflation and ~1.1 TB/s).
 template <typename W, int RW, int TILE, int BT>
-__global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
+__global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
                                                  const uint32_t *__restrict__ seg_end, int n_seg,
                                                  const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ rows2,
-                                                 uint64_t *__restrict__ out)
+                                                 uint32_t *__restrict__ out)
 {
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-	uint64_t *stage = reinterpret_cast<uint64_t *>(smem2);                              // TILE * RW words
-	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 8); // bucket of each staged record
+	uint32_t *stage = reinterpret_cast<uint32_t *>(smem2);                              // TILE * RW dwords
+	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 4); // bucket of each staged record
 	__shared__ uint32_t cnt[512], loff[512], gdelta[512];
 	const int nb2 = 1 << P.F2;
 	const uint32_t n_rows = row_base[n_seg];
@@ -383,7 +422,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
 	const uint32_t *rowp = rows2 + (size_t)row * nb2;
 	for (int i = threadIdx.x; i < 512; i += BT) cnt[i] = 0;
 	__syncthreads();
-	uint64_t w[S][RW];
+	RecW<RW> w[S];
 	uint32_t br[S]; // bucket << 16 | rank inside (tile, bucket)
 #pragma unroll
 	for (int j = 0; j < S; ++j) {
@@ -391,8 +430,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
 		br[j] = 0xffffffffu;
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
-#pragma unroll
-			for (int t = 0; t < RW; ++t) w[j][t] = in[i * RW + t];
+			w[j] = rec_load<RW>(in + i * RW);
 			Rec<RW>::unpack(w[j], y0, y1, idx, hi);
 			uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
 			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
@@ -423,7 +461,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
 		if (br[j] != 0xffffffffu) {
 			const uint32_t b = br[j] >> 16, pos = cnt[b] + (br[j] & 0xffffu);
 #pragma unroll
-			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j][t];
+			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
 			sbk[pos] = (unsigned short)b;
 		}
 	}
@@ -431,11 +469,10 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint64_t *__re
 	const uint32_t n_in = min((uint32_t)TILE, e - s - tile * TILE);
 	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
 		const uint64_t dst = (uint32_t)(pos + gdelta[sbk[pos]]);
-		if (RW == 2) *reinterpret_cast<ulonglong2 *>(out + dst * 2) = *reinterpret_cast<const ulonglong2 *>(stage + (size_t)pos * 2);
-		else {
+		RecW<RW> rec;
 #pragma unroll
-			for (int t = 0; t < RW; ++t) out[dst * RW + t] = stage[(size_t)pos * RW + t];
-		}
+		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
+		rec_store<RW>(out + dst * RW, rec);
 	}
 }
 
@@ -540,7 +577,7 @@ __device__ __forceinline__ bool fs_lookup(const unsigned long long *tab, uint32_
 }
 
 struct BloomArgs {
-	const uint64_t *recs;          // fine-bucketed records
+	const uint32_t *recs;          // fine-bucketed records (RD dwords each)
 	const uint32_t *start;         // fine bucket starts (n_fine+1)
 	unsigned long long *bloom;     // first bloom filter (device)
 	unsigned long long *bloom_hi;  // second bloom filter (filter mode) or NULL
@@ -618,7 +655,7 @@ __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, 
 struct KRec { uint64_t y0, y1; uint32_t idx, bl, h1, h2; bool hi; };
 
 template <typename W, int RW>
-__device__ __forceinline__ KRec decode_rec(const KParams &P, const uint64_t *w, W m, uint32_t rmask)
+__device__ __forceinline__ KRec decode_rec(const KParams &P, const RecW<RW> &w, W m, uint32_t rmask)
 {
 	KRec r;
 	Rec<RW>::unpack(w, r.y0, r.y1, r.idx, r.hi);
@@ -700,7 +737,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	unsigned int *list_a = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4; // file-order index of the k-mer
 	unsigned int *list_b = reinterpret_cast<unsigned int *>(sp);                                // record index in the bucket | clear-bit mask << 20
 	const uint32_t fs_mask = P.fs_cap - 1;
-	const uint64_t *recs = A.recs + (uint64_t)rs * RW;
+	const uint32_t *recs = A.recs + (uint64_t)rs * RW;
 	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
 	const W m = kmask<W>(P.k);
 	const uint32_t rmask = region_blocks - 1;
@@ -710,13 +747,12 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	long long tq[6] = {0, 0, 0, 0, 0, 0};
 	if (timing) tq[0] = clock64();
 
-	uint64_t rw[PF][RW];
+	RecW<RW> rw[PF];
 #pragma unroll
 	for (int u = 0; u < PF; ++u) {
 		uint32_t i = threadIdx.x + u * BT;
 		if (i < n) {
-#pragma unroll
-			for (int t = 0; t < RW; ++t) rw[u][t] = recs[(uint64_t)i * RW + t];
+			rw[u] = rec_load<RW>(recs + (uint64_t)i * RW);
 		}
 	}
 	{ // stage the region (16-byte loads), clear the LDS tables
@@ -782,10 +818,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 #pragma unroll
 			for (int u = 0; u < PF; ++u) {
 				uint32_t i = base + BT * PF + threadIdx.x + u * BT;
-				if (i < n) {
-#pragma unroll
-					for (int t = 0; t < RW; ++t) rw[u][t] = recs[(uint64_t)i * RW + t];
-				}
+				if (i < n) rw[u] = rec_load<RW>(recs + (uint64_t)i * RW);
 			}
 		}
 	}
@@ -796,27 +829,20 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	// ---- pass 1.5: dense over the list -- enter every clear bit into the first-setter table.
 	// A thread keeps the records of its first LK list entries in registers for pass 2.
 	constexpr int LK = 2;
-	uint64_t lw[LK][RW];
+	RecW<RW> lw[LK];
 	if (!*v_ovf) {
 #pragma unroll
 		for (int q = 0; q < LK; ++q) {
 			const uint32_t li = threadIdx.x + q * BT;
 			if (li < ln) {
 				const uint32_t i = list_b[li] & 0xfffffu;
-#pragma unroll
-				for (int t = 0; t < RW; ++t) lw[q][t] = recs[(uint64_t)i * RW + t];
+				lw[q] = rec_load<RW>(recs + (uint64_t)i * RW);
 			}
 		}
 		for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
-			uint64_t w[RW];
-			if (q < LK) {
-#pragma unroll
-				for (int t = 0; t < RW; ++t) w[t] = q == 0 ? lw[0][t] : lw[LK - 1][t];
-			} else {
-				const uint32_t i = list_b[li] & 0xfffffu;
-#pragma unroll
-				for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
-			}
+			RecW<RW> w;
+			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
+			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
 			KRec r = decode_rec<W, RW>(P, w, m, rmask);
 			const uint32_t um = list_b[li] >> 20;
 			uint32_t z = r.h1;
@@ -834,15 +860,9 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	if (!s_ovf) {
 		// ---- pass 2: dense over the list -- seen iff an earlier k-mer of the batch sets each clear bit; set the bits
 		for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
-			uint64_t w[RW];
-			if (q < LK) {
-#pragma unroll
-				for (int t = 0; t < RW; ++t) w[t] = q == 0 ? lw[0][t] : lw[LK - 1][t];
-			} else {
-				const uint32_t i = list_b[li] & 0xfffffu;
-#pragma unroll
-				for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
-			}
+			RecW<RW> w;
+			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
+			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
 			KRec r = decode_rec<W, RW>(P, w, m, rmask);
 			const uint32_t um = list_b[li] >> 20;
 			uint32_t z = r.h1; bool first = false;
@@ -880,10 +900,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 		__syncthreads();
 		const uint32_t gmask = cap - 1;
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			uint64_t w[RW];
-#pragma unroll
-			for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
-			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask);
 			uint32_t z = r.h1;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, r.h2);
@@ -893,10 +910,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 		__threadfence();
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			uint64_t w[RW];
-#pragma unroll
-			for (int t = 0; t < RW; ++t) w[t] = recs[(uint64_t)i * RW + t];
-			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask);
 			uint32_t z = r.h1; bool first = false, unresolved = false;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, r.h2), fi;
@@ -1010,7 +1024,7 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 
 // stage A: bases -> records grouped by (global) level-1 bucket in `out1`; B.start1[2^F1+1] = bucket starts
 template <typename W, int RW>
-static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
+static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
 {
 	const int nb1 = 1 << P.F1;
 	const int64_t tiles1 = (n_pos + TILE1 - 1) / TILE1;
@@ -1029,18 +1043,18 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 // stage B: records in `in1` as n_seg segments (seg_beg/seg_end, row_base over segments, bucket_start over the
 // nb_loc = n_seg/segs_per_bucket owned level-1 buckets) -> fine buckets -> bloom regions -> table
 template <typename W, int RW>
-static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg,
+static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg,
                           int segs_per_bucket, const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev)
 {
 	const int nb_loc = n_seg / segs_per_bucket, nfine = nb_loc << P.F2;
-	const uint64_t *fine_recs = in1; const uint32_t *fine_start = bucket_start;
+	const uint32_t *fine_recs = in1; const uint32_t *fine_start = bucket_start;
 	if (P.F2 > 0) {
 		// rows of level 2 <= records/TILE2 + one ragged row per segment; surplus blocks exit at once
 		const unsigned g2 = (unsigned)(((n_rec_bound / TILE2 + n_seg + 1 + 7) / 8) * 8);
 		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
 		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3(512), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 8 + 2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, B.recs2);
-		fine_recs = B.recs2; fine_start = B.start2;
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4 + 2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
+		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
 	BloomArgs A;
@@ -1061,14 +1075,14 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint64_t *
 	if (ev) hipEventRecord(ev[5], st);
 }
 
-#define DISPATCH_W(fn, ...) do { if (P.k <= 32) fn<uint32_t, 2>(__VA_ARGS__); else if (P.k <= 47) fn<uint64_t, 2>(__VA_ARGS__); else fn<uint64_t, 3>(__VA_ARGS__); } while (0)
+#define DISPATCH_W(fn, ...) do { if (P.k <= 31) fn<uint32_t, 3>(__VA_ARGS__); else if (P.k == 32) fn<uint32_t, 4>(__VA_ARGS__); else if (P.k <= 47) fn<uint64_t, 4>(__VA_ARGS__); else fn<uint64_t, 6>(__VA_ARGS__); } while (0)
 
 void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
-{ DISPATCH_W(run_stage_a_t, P, B, seq, qual, n_pos, out1, st, ev); }
+{ DISPATCH_W(run_stage_a_t, P, B, seq, qual, n_pos, (uint32_t *)out1, st, ev); }
 
 void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
                  const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev)
-{ DISPATCH_W(run_stage_b_t, P, B, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, bucket_start, n_rec_bound, st, ev); }
+{ DISPATCH_W(run_stage_b_t, P, B, (const uint32_t *)in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, bucket_start, n_rec_bound, st, ev); }
 
 // single GPU: both stages back to back, segment = level-1 bucket, everything stays on the device
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev)
@@ -1079,15 +1093,13 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 
 int bloom_lds_bytes(const KParams &P)
 {
-	const int rw = P.k <= 47 ? 2 : 3;
-	(void)rw;
 	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + (size_t)P.ag_cap * (P.k > 32 ? 24 : 16) + (size_t)P.list_cap * 8 + 16);
 }
 
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 8 + 2)); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2)); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
@@ -1096,9 +1108,10 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 hipError_t set_bloom_lds_attr(const KParams &P)
 {
 	int lds = bloom_lds_bytes(P);
-	if (P.k <= 32) return set_attr_t<uint32_t, 2>(lds);
-	if (P.k <= 47) return set_attr_t<uint64_t, 2>(lds);
-	return set_attr_t<uint64_t, 3>(lds);
+	if (P.k <= 31) return set_attr_t<uint32_t, 3>(lds);
+	if (P.k == 32) return set_attr_t<uint32_t, 4>(lds);
+	if (P.k <= 47) return set_attr_t<uint64_t, 4>(lds);
+	return set_attr_t<uint64_t, 6>(lds);
 }
 
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st)

@@ -51,11 +51,11 @@ class GpuEngine:
         import torch
         self.g = counter
         info = counter.mg_info()
-        self.rec_words = info["rec_bytes"] // 8
+        self.rec_words = info["rec_bytes"] // 4  # exchange buffers are int32 tensors
         cap = int(counter.params.max_batch_pos)
         dev = torch.device("cuda", counter.params.device)
-        self.send = torch.empty(cap * self.rec_words, dtype=torch.int64, device=dev)
-        self.recv = torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int64, device=dev)
+        self.send = torch.empty(cap * self.rec_words, dtype=torch.int32, device=dev)
+        self.recv = torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int32, device=dev)
 
     def scatter(self, d_seq, d_qual, n_pos):
         return self.g.mg_scatter(d_seq, d_qual, n_pos, self.send.data_ptr())  # synchronises the library's stream
@@ -82,10 +82,10 @@ class LocalCluster:
         self.n = n_ranks
         self.ctx = [gpu_lib.GpuCounter(k, bf_shift, max_batch_pos=max_batch_pos, rank=r, n_ranks=n_ranks, **kw) for r in range(n_ranks)]
         info = self.ctx[0].mg_info()
-        self.rw, self.nb1, self.nb_loc = info["rec_bytes"] // 8, info["nb1"], info["nb_loc"]
+        self.rw, self.nb1, self.nb_loc = info["rec_bytes"] // 4, info["nb1"], info["nb_loc"]
         self.cap = max_batch_pos
-        self.d_send = [c.dev_alloc(self.cap * self.rw * 8) for c in self.ctx]
-        self.d_recv = [c.dev_alloc((self.cap * 2 + 4096) * self.rw * 8) for c in self.ctx]
+        self.d_send = [c.dev_alloc(self.cap * self.rw * 4) for c in self.ctx]
+        self.d_recv = [c.dev_alloc((self.cap * 2 + 4096) * self.rw * 4) for c in self.ctx]
 
     def batch(self, shares):
         """shares[r] = (seq_stream, qual_stream or None) of rank r for this global batch."""
@@ -100,7 +100,7 @@ class LocalCluster:
                 q = np.ascontiguousarray(q, dtype=np.uint8)
                 d_q = c.dev_alloc(max(len(q), 16)); c.h2d(d_q, q)
             cnt = c.mg_scatter(d_s, d_q, len(s), self.d_send[r])
-            host = np.empty(int(cnt.sum()) * self.rw, dtype=np.uint64)
+            host = np.empty(int(cnt.sum()) * self.rw, dtype=np.uint32)
             if len(host):
                 c._ck(c.L.bfcg_d2h(c.ctx, host.ctypes.data, self.d_send[r], host.nbytes))
             sends.append(host); counts.append(cnt)
@@ -114,7 +114,7 @@ class LocalCluster:
                 lo, hi = starts[o * self.nb_loc], starts[(o + 1) * self.nb_loc]
                 parts.append(sends[s_][lo * self.rw:hi * self.rw])
                 seg[s_] = counts[s_][o * self.nb_loc:(o + 1) * self.nb_loc]
-            recv = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+            recv = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
             if len(recv):
                 self.ctx[o].h2d(self.d_recv[o], recv)
             self.ctx[o].mg_process(self.d_recv[o], seg)
