@@ -72,6 +72,15 @@ def cpu_baseline(rs, n_cores):
             "t1_mkmers_per_s": out["t1"]["mkmers_per_s"], "detail": out}
 
 
+def pmc_traffic():
+    """HBM bytes per k_bloom launch measured with rocprofv3 PMC passes of this same command (committed summary)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc.json")) as f:
+            return round(json.load(f)["k_bloom"]["hbm_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def count_kmers(seq, L, k):
     """Number of bfc_kmer_insert calls: sum over ACGT runs of max(0, len-k+1) (vectorised, fixed-length reads)."""
     import numpy as np
@@ -156,21 +165,34 @@ def main():
     d_seq = g.dev_alloc(len(s_seq)); d_qual = g.dev_alloc(len(s_qual))
     g.h2d(d_seq, s_seq); g.h2d(d_qual, s_qual)
     del seq, qual
-    n_batches = (n_reads + batch_reads - 1) // batch_reads
-    if dist:
-        import torch
-        nb = torch.tensor([n_batches], device="cuda"); dist.all_reduce(nb, op=dist.ReduceOp.MAX); n_batches = int(nb.item())
     log("[bench] rank %d: %d reads, %d k-mers, input staged in HBM in %.1fs; mode: %s" % (rank, n_reads, n_kmers, time.time() - t0, mode))
 
     stage = dict(hist1=0.0, scatter1=0.0, level2=0.0, bloom=0.0, commit=0.0, total=0.0)
     n_launch = 0
     xchg_s = 0.0
 
+    # batch schedule: equal batches of batch_reads reads (batch boundaries never change results).  BFC_BENCH_RAMP=1 tries
+    # smaller first batches for the cold filter.
+    sched = []
+    r = 0
+    ramp = [8, 4, 2] if os.environ.get("BFC_BENCH_RAMP") else []  # measured: no gain (each batch streams the whole bitmap once), off by default
+    for d in ramp:
+        n = min(n_reads - r, (batch_reads // d) // 16 * 16)
+        if n > 0:
+            sched.append((r, r + n)); r += n
+    while r < n_reads:
+        n = min(n_reads - r, batch_reads)
+        sched.append((r, r + n)); r += n
+    n_batches = len(sched)
+    if dist:
+        import torch
+        nb = torch.tensor([n_batches], device="cuda"); dist.all_reduce(nb, op=dist.ReduceOp.MAX); n_batches = int(nb.item())
+
     def step(acc):
         nonlocal n_launch, xchg_s
         g.reset()
         for t in range(n_batches):
-            r0 = min(n_reads, t * batch_reads); r1 = min(n_reads, r0 + batch_reads)
+            r0, r1 = sched[t] if t < len(sched) else (n_reads, n_reads)
             if eng is not None:
                 tx = time.perf_counter()
                 bdist.count_batch(eng, d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
@@ -181,7 +203,7 @@ def main():
             if acc and r1 > r0:
                 ms = g.last_batch_ms()
                 if os.environ.get("BFC_BENCH_VERBOSE"):
-                    log("[bench] batch %d: %s" % (t, {k_: round(v_, 3) for k_, v_ in ms.items()}))
+                    log("[bench] batch %d (%d reads): %s" % (t, r1 - r0, {k_: round(v_, 3) for k_, v_ in ms.items()}))
                 for kk in stage:
                     stage[kk] += ms[kk]
                 n_launch += 1
@@ -231,7 +253,7 @@ def main():
                        "stage_ms_per_step": {kk: round(v / args.steps, 3) for kk, v in stage.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_bloom (bloom regions in LDS + exact seen + table upsert)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kmers_per_launch": int(kmers_per_launch), "avg_launch_ms": round(bloom_ms, 4),
+                         "traffic": pmc_traffic(), "traffic_note": "HBM bytes per k_bloom launch from profiles/round1_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command)", "kmers_per_launch": int(kmers_per_launch), "avg_launch_ms": round(bloom_ms, 4),
                          "algorithmic_bytes_per_kmer": BLOOM_BYTES_PER_KMER,
                          "pipeline_frac": round(BLOOM_BYTES_PER_KMER * n_kmers * args.steps / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }

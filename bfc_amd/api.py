@@ -270,7 +270,7 @@ class GpuCounter:
         out = np.zeros(16, dtype=np.uint64)
         self._ck(self.L.bfcg_stats(self.ctx, out.ctypes.data_as(u64p)))
         d = {STAT_NAMES[i]: int(out[i]) for i in STAT_NAMES}
-        d["phase_cycles"] = [int(out[i]) for i in range(10, 15)]  # BFCG_ABLATE&64: k_bloom stage/pass1/pass2/writeback/handover
+        d["phase_cycles"] = [int(out[i]) for i in range(10, 16)]  # BFCG_ABLATE&64: k_bloom stage/pass1/pass2/writeback/handover
         return d
 
     def last_batch_ms(self):

@@ -27,9 +27,16 @@ struct bfcg_ctx {
 	bfcg_params_t prm;
 	KParams P;
 	BatchBufs B;
-	hipStream_t st;
-	hipEvent_t ev[6];
-	uint8_t *d_seq, *d_qual;     // staging for host batches
+	hipStream_t st;              // stage B (level 2, bloom regions, table) -- also the stream of everything synchronous
+	hipStream_t stA;             // stage A (K1 histogram + level-1 scatter) of the NEXT batch runs here, under stage B of the current one
+	hipStream_t stC;             // small D2H copies that must not queue behind kernels
+	hipEvent_t evt[2][7];        // timing events per in-flight batch ([6] = start of stage B on its stream)
+	hipEvent_t evA[2], evB[2], evCopy; // stage A done / stage B done (buffer set reusable) / host batch copied
+	uint32_t *rows1[2], *chunk1[2], *start1[2]; uint64_t *recs1[2]; // double-buffered stage-A outputs
+	uint8_t *d_seq2[2], *d_qual2[2]; // staging for host batches (one per in-flight batch)
+	int cur, pend;               // buffer set of the next batch; 1 if the previous batch is not finalised yet
+	int used[2];
+	uint8_t *d_seq, *d_qual;     // = d_seq2[0], d_qual2[0]
 	unsigned long long *h_stats; // pinned mirror
 	uint64_t n_batches;
 	float last_ms[6];
@@ -117,20 +124,28 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	const int nb1 = 1 << P.F1, nfine = (1 << P.F) >> log2n; // fine buckets owned by this rank
 	// records arriving from all ranks for the owned buckets: hashing balances them; 25 % + 1 M head room, checked per batch
 	c->recv_cap = n_ranks > 1 ? B.max_kmers + B.max_kmers / 4 + (1u << 20) : B.max_kmers;
-	HIPCKN(hipStreamCreate(&c->st));
-	for (int i = 0; i < 6; ++i) HIPCKN(hipEventCreate(&c->ev[i]));
+	HIPCKN(hipStreamCreate(&c->st)); HIPCKN(hipStreamCreate(&c->stA)); HIPCKN(hipStreamCreate(&c->stC));
+	for (int b = 0; b < 2; ++b) {
+		for (int i = 0; i < 7; ++i) HIPCKN(hipEventCreate(&c->evt[b][i]));
+		HIPCKN(hipEventCreateWithFlags(&c->evA[b], hipEventDisableTiming)); HIPCKN(hipEventCreateWithFlags(&c->evB[b], hipEventDisableTiming));
+	}
+	HIPCKN(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
 	{
 		const uint64_t tiles1 = (prm->max_batch_pos + BFCG_TILE1 - 1) / BFCG_TILE1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
 		const uint64_t rows2 = c->recv_cap / BFCG_TILE2 + nb1 + 1;
-		HIPCKN(hipMalloc(&B.rows1, sizeof(uint32_t) * tiles1 * nb1));
-		HIPCKN(hipMalloc(&B.chunk1, sizeof(uint32_t) * chunks1 * nb1));
-		HIPCKN(hipMalloc(&B.start1, sizeof(uint32_t) * (nb1 + 1) * 2)); B.row_base = B.start1 + nb1 + 1;
+		for (int b = 0; b < 2; ++b) {
+			HIPCKN(hipMalloc(&c->rows1[b], sizeof(uint32_t) * tiles1 * nb1));
+			HIPCKN(hipMalloc(&c->chunk1[b], sizeof(uint32_t) * chunks1 * nb1));
+			HIPCKN(hipMalloc(&c->start1[b], sizeof(uint32_t) * (nb1 + 1) * 2));
+		}
+		B.rows1 = c->rows1[0]; B.chunk1 = c->chunk1[0]; B.start1 = c->start1[0]; B.row_base = B.start1 + nb1 + 1;
 		if (P.F2 > 0) {
 			HIPCKN(hipMalloc(&B.rows2, sizeof(uint32_t) * rows2 * (1u << P.F2)));
 			HIPCKN(hipMalloc(&B.start2, sizeof(uint32_t) * (nfine + 1)));
 		}
 	}
-	HIPCKN(hipMalloc(&B.recs1, B.max_kmers * c->rw));
+	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], B.max_kmers * c->rw));
+	B.recs1 = c->recs1[0];
 	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw));
 	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * (4 * nb1 + 8))); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * (4 * nb1 + 8))); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
@@ -149,8 +164,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * 24));
 		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
 	}
-	HIPCKN(hipMalloc(&c->d_seq, prm->max_batch_pos));
-	HIPCKN(hipMalloc(&c->d_qual, prm->max_batch_pos));
+	for (int b = 0; b < 2; ++b) { HIPCKN(hipMalloc(&c->d_seq2[b], prm->max_batch_pos)); HIPCKN(hipMalloc(&c->d_qual2[b], prm->max_batch_pos)); }
+	c->d_seq = c->d_seq2[0]; c->d_qual = c->d_qual2[0];
 	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 2)));
 	HIPCKN(set_bloom_lds_attr(P));
 	if (bfcg_reset(c) != 0) { bfcg_destroy(c); return NULL; }
@@ -161,33 +176,39 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->prm.device);
-	(void)hipStreamSynchronize(c->st);
-	(void)hipFree(c->B.rows1); (void)hipFree(c->B.chunk1); (void)hipFree(c->B.start1); (void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs1); (void)hipFree(c->B.recs2);
+	(void)hipDeviceSynchronize();
+	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
+	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
-	(void)hipFree(c->d_seq); (void)hipFree(c->d_qual); (void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
-	for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
-	(void)hipStreamDestroy(c->st);
+	(void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
+	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
+	(void)hipEventDestroy(c->evCopy);
+	(void)hipStreamDestroy(c->st); (void)hipStreamDestroy(c->stA); (void)hipStreamDestroy(c->stC);
 	free(c);
 }
+
+static int drain(bfcg_ctx_t *c);
 
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
 {
 	HIPCK(hipSetDevice(c->prm.device));
+	if (c->pend && drain(c) != 0) return -1;
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
 	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
 	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
+	HIPCK(hipStreamSynchronize(c->st)); // stage A of the next batch runs on another stream: the zeroing must have landed
 	c->n_batches = 0;
 	return 0;
 }
 
 // bring the slotted counters to the host and fold them into h_stats[0..ST_N)
-static int fetch_stats(bfcg_ctx_t *c)
+static int fetch_stats_on(bfcg_ctx_t *c, hipStream_t s)
 {
 	unsigned long long *raw = c->h_stats + ST_N;
-	HIPCK(hipMemcpyAsync(raw, c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
+	HIPCK(hipMemcpyAsync(raw, c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, s));
+	HIPCK(hipStreamSynchronize(s));
 	for (int i = 0; i < ST_N; ++i) {
 		unsigned long long s = 0;
 		for (int j = 0; j < ST_SLOTS; ++j) s += raw[(size_t)j * ST_N + i];
@@ -197,7 +218,36 @@ static int fetch_stats(bfcg_ctx_t *c)
 	return 0;
 }
 
-extern "C" int bfcg_sync(bfcg_ctx_t *c) { HIPCK(hipStreamSynchronize(c->st)); return 0; }
+static int fetch_stats(bfcg_ctx_t *c) { return fetch_stats_on(c, c->st); }
+
+static int table_maintain(bfcg_ctx_t *c);
+
+static int batch_times(bfcg_ctx_t *c, int b)
+{
+	for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->evt[b][i == 2 ? 6 : i], c->evt[b][i + 1]));
+	c->last_ms[5] = c->last_ms[0] + c->last_ms[1] + c->last_ms[2] + c->last_ms[3] + c->last_ms[4]; // GPU time of the stages (they overlap across batches)
+	return 0;
+}
+static int check_health(bfcg_ctx_t *c)
+{
+	if (c->h_stats[ST_ERR_POOL]) return set_err("first-setter pool exhausted in %llu bloom regions: batch too large for max_batch_pos", (unsigned long long)c->h_stats[ST_ERR_POOL]);
+	if (c->B.table) return table_maintain(c);
+	return 0;
+}
+// finish every batch in flight: afterwards the device is idle, statistics are final, the table is maintained
+static int drain(bfcg_ctx_t *c)
+{
+	if (!c->pend) return 0;
+	HIPCK(hipStreamSynchronize(c->stA));
+	HIPCK(hipStreamSynchronize(c->st));
+	HIPCK(hipGetLastError());
+	c->pend = 0;
+	if (batch_times(c, c->cur ^ 1) != 0) return -1;
+	if (fetch_stats(c) != 0) return -1;
+	return check_health(c);
+}
+
+extern "C" int bfcg_sync(bfcg_ctx_t *c) { return drain(c); }
 
 // grow the table by one doubling and replay parked k-mers until none is left
 static int table_maintain(bfcg_ctx_t *c)
@@ -230,16 +280,13 @@ static int table_maintain(bfcg_ctx_t *c)
 	}
 }
 
-static int finish_batch(bfcg_ctx_t *c)
+static int finish_batch(bfcg_ctx_t *c) // synchronous batches (multi-GPU stages) on stream st with event set 0
 {
 	HIPCK(hipGetLastError());
 	if (fetch_stats(c) != 0) return -1;
 	++c->n_batches;
-	for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
-	HIPCK(hipEventElapsedTime(&c->last_ms[5], c->ev[0], c->ev[5]));
-	if (c->h_stats[ST_ERR_POOL]) return set_err("first-setter pool exhausted in %llu bloom regions: batch too large for max_batch_pos", (unsigned long long)c->h_stats[ST_ERR_POOL]);
-	if (c->B.table) return table_maintain(c);
-	return 0;
+	if (batch_times(c, 0) != 0) return -1;
+	return check_health(c);
 }
 
 // ---- multi-GPU (owner computes): stage A on every rank, exchange by the caller, stage B on the owner
@@ -256,7 +303,8 @@ extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
 	if (n_pos == 0) { memset(counts, 0, sizeof(uint32_t) * nb1); return 0; }
-	run_stage_a(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->st, c->ev);
+	if (drain(c) != 0) return -1;
+	run_stage_a(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->st, c->evt[0]);
 	HIPCK(hipGetLastError());
 	uint32_t *h = (uint32_t *)(c->h_stats + ST_N * (ST_SLOTS + 1)); // pinned scratch behind the statistics mirror
 	(void)h;
@@ -275,6 +323,7 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 {
 	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, n_seg = nb_loc * N;
 	HIPCK(hipSetDevice(c->prm.device));
+	if (drain(c) != 0) return -1;
 	uint32_t *seg_beg = c->h_seg, *seg_end = seg_beg + n_seg, *row_base = seg_end + n_seg, *bucket_start = row_base + n_seg + 1;
 	uint64_t off = 0, rows = 0, tot = 0;
 	for (int s = 0; s < N; ++s)
@@ -291,12 +340,49 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 	}
 	bucket_start[nb_loc] = (uint32_t)tot;
 	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
+	HIPCK(hipEventRecord(c->evt[0][6], c->st));
 	HIPCK(hipMemcpyAsync(c->d_seg, c->h_seg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
 	const uint32_t *d = c->d_seg;
-	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->ev);
+	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[0]);
 	return finish_batch(c);
+}
+
+// One batch, software-pipelined over two streams: stage A of this batch (ALU-bound K1) is enqueued on stA and runs
+// under stage B of the previous batch (LDS/latency-bound) on st.  The call returns once the PREVIOUS batch is
+// finalised (statistics read, table maintained); bfcg_sync / bfcg_stats / exports drain the pipeline.
+static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
+{
+	const int b = c->cur, nb1 = 1 << c->P.F1;
+	BatchBufs Bt = c->B;
+	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1; Bt.recs1 = c->recs1[b];
+	if (c->used[b]) HIPCK(hipStreamWaitEvent(c->stA, c->evB[b], 0)); // stage B two batches ago has released this buffer set
+	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, c->stA, c->evt[b]);
+	HIPCK(hipEventRecord(c->evA[b], c->stA));
+	HIPCK(hipStreamWaitEvent(c->st, c->evA[b], 0));
+	HIPCK(hipEventRecord(c->evt[b][6], c->st));
+	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
+	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
+	run_stage_b(c->P, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
+	HIPCK(hipEventRecord(c->evB[b], c->st));
+	HIPCK(hipGetLastError());
+	c->used[b] = 1;
+	++c->n_batches;
+	// finalise the previous batch while this one runs
+	if (c->pend) {
+		const int pb = b ^ 1;
+		HIPCK(hipEventSynchronize(c->evB[pb]));
+		if (batch_times(c, pb) != 0) return -1;
+		if (fetch_stats_on(c, c->stC) != 0) return -1; // counters may already include part of the running batch: fine for the checks below
+		const uint64_t slots = 1ULL << (c->P.l_pre + c->P.tab_cshift);
+		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->B.table && c->h_stats[ST_KEYS] * 2 > slots)) {
+			c->pend = 1; c->cur = b ^ 1; // make drain() see the batch just enqueued
+			return drain(c);
+		}
+	}
+	c->pend = 1; c->cur = b ^ 1;
+	return 0;
 }
 
 extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
@@ -305,20 +391,25 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 	if (n_pos == 0) return 0;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
-	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
-	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
-	run_batch(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, c->st, c->ev);
-	return finish_batch(c);
+	int rc = enqueue_batch(c, d_seq, d_qual, n_pos);
+	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c); // debug aids want one batch at a time
+	return rc;
 }
 
 extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)
 {
+	if (c->n_ranks > 1) return set_err("this context is one of %d ranks: use bfcg_mg_scatter / bfcg_mg_process", c->n_ranks);
 	if (n_pos == 0) return 0;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
-	HIPCK(hipMemcpyAsync(c->d_seq, h_seq, n_pos, hipMemcpyHostToDevice, c->st));
-	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual, h_qual, n_pos, hipMemcpyHostToDevice, c->st));
-	return bfcg_count_batch_dev(c, c->d_seq, h_qual ? c->d_qual : NULL, n_pos);
+	const int b = c->cur;
+	HIPCK(hipMemcpyAsync(c->d_seq2[b], h_seq, n_pos, hipMemcpyHostToDevice, c->stA)); // ordered behind stage A of two batches ago (same stream)
+	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual2[b], h_qual, n_pos, hipMemcpyHostToDevice, c->stA));
+	HIPCK(hipEventRecord(c->evCopy, c->stA));
+	int rc = enqueue_batch(c, c->d_seq2[b], h_qual ? c->d_qual2[b] : NULL, n_pos);
+	HIPCK(hipEventSynchronize(c->evCopy)); // the caller may reuse its host buffers now
+	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c);
+	return rc;
 }
 
 extern "C" void *bfcg_dev_alloc(bfcg_ctx_t *c, uint64_t bytes)
@@ -335,6 +426,7 @@ extern "C" int bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t byte
 
 extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
 {
+	if (drain(c) != 0) return -1;
 	if (fetch_stats(c) != 0) return -1;
 	for (int i = 0; i < BFCG_ST_N; ++i) out[i] = c->h_stats[i];
 	out[BFCG_ST_TAB_CSHIFT] = (uint64_t)c->P.tab_cshift;
@@ -348,6 +440,7 @@ extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)
 {
 	unsigned long long *src = which ? c->B.bloom_hi : c->B.bloom;
 	if (!src) return set_err("bloom filter %d does not exist in this mode", which);
+	if (drain(c) != 0) return -1;
 	HIPCK(hipMemcpyAsync(dst, src, c->bloom_bytes, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	return 0;
@@ -364,6 +457,7 @@ extern "C" bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which)
 extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 {
 	if (!c->B.table) { set_err("no count table in filter mode"); return NULL; }
+	if (drain(c) != 0) return NULL;
 	bfc_ch_t *ch = bfc_ch_alloc_raw(c->P.k, c->P.l_pre, c->P.tab_cshift);
 	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
 	if (hipMemcpyAsync(bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
@@ -375,6 +469,7 @@ extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 extern "C" int bfcg_hash_positions(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos, uint64_t *out)
 {
 	if (n_pos > c->prm.max_batch_pos) return set_err("too many positions");
+	if (drain(c) != 0) return -1;
 	uint64_t *d_out = 0;
 	HIPCK(hipSetDevice(c->prm.device));
 	HIPCK(hipMalloc(&d_out, n_pos * 24));
@@ -391,6 +486,7 @@ extern "C" int bfcg_hash_positions(bfcg_ctx_t *c, const uint8_t *h_seq, const ui
 extern "C" int bfcg_seen_flags(bfcg_ctx_t *c, uint8_t *dst, uint64_t n_pos)
 {
 	if (!c->B.seen_out) return set_err("context was created without debug_seen");
+	if (drain(c) != 0) return -1;
 	HIPCK(hipMemcpyAsync(dst, c->B.seen_out, n_pos, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	return 0;

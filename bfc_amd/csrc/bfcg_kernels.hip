@@ -744,7 +744,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	const int nh = NH ? NH : P.n_hashes;
 
 	const bool timing = (P.ablate & 64) && threadIdx.x == 0;
-	long long tq[6] = {0, 0, 0, 0, 0, 0};
+	long long tq[7] = {0, 0, 0, 0, 0, 0, 0};
 	if (timing) tq[0] = clock64();
 
 	RecW<RW> rw[PF];
@@ -855,6 +855,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 		}
 	}
 	__syncthreads();
+	if (timing) tq[6] = clock64();
 
 	bool dirty = true;
 	if (!s_ovf) {
@@ -968,6 +969,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	if (timing) {
 		tq[5] = clock64();
 		for (int t = 0; t < 5; ++t) atomicAdd(&A.stats[10 + t], (unsigned long long)(tq[t + 1] - tq[t]));
+		atomicAdd(&A.stats[15], (unsigned long long)(tq[6] - tq[2])); // pass 1.5 alone (part of slot 12)
 	}
 	(void)s_pad;
 }

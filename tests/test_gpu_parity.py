@@ -179,3 +179,48 @@ def test_filter_mode(gpu_lib, g1):
         assert int(L.orc_popcount_bytes(bits.ctypes.data, len(bits))) == pop
         assert int(L.orc_fnv1a64(bits.ctypes.data, len(bits))) == fnv
     g.close()
+
+
+def test_massive_duplicates_saturate_exactly(gpu_lib):
+    """Skew: the same reads thousands of times (a poly-A read and one ordinary read).  Counters saturate at 255 / 63
+    (htab.c:77-78), the LDS aggregation must not wrap, and one bloom region receives almost every k-mer."""
+    L = 150
+    polyA = np.frombuffer(b"A" * L, dtype=np.uint8)
+    rng = np.random.default_rng(3)
+    other = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)]
+    n = 6000
+    seq = np.concatenate([polyA if i % 3 else other for i in range(n)])
+    qual = np.full(len(seq), ord("I"), dtype=np.uint8)
+    qual[10::75] = ord("#")  # some low-quality bases: most 31-mers stay high quality
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = oracle.Counter(31, 24)
+    oc.count(seq, qual, off)
+    for nb in (1, 3):
+        g = _gpu_count(gpu_lib, 31, 24, seq, qual, off, nb)
+        assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+        assert g.stats()["n_seen"] == oc.stats()["n_seen"]
+        sizes, slots = g.export_table().export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+        assert int((slots & np.uint64(0xff)).max()) == 255 and int(((slots >> np.uint64(8)) & np.uint64(0x3f)).max()) == 63
+        g.close()
+
+
+def test_unaligned_device_streams_take_the_byte_path(gpu_lib, g1):
+    """Batches whose device pointers are not 16-byte aligned (e.g. a slice of a resident read set) use the ballot path of
+    the plane builder; same results."""
+    rs, (seq, qual, off) = g1
+    n = 2000
+    s = gpu_lib.to_stream(seq[:n * rs.L], off[:n + 1]); q = gpu_lib.to_stream(qual[:n * rs.L], off[:n + 1])
+    oc = oracle.Counter(31, 24)
+    oc.count(seq[:n * rs.L], qual[:n * rs.L], off[:n + 1])
+    g = gpu_lib.GpuCounter(31, 24, max_batch_pos=len(s) + 64)
+    d_s = g.dev_alloc(len(s) + 64); d_q = g.dev_alloc(len(q) + 64)
+    pad = np.zeros(5, dtype=np.uint8)
+    g.h2d(d_s, np.concatenate([pad, s])); g.h2d(d_q, np.concatenate([pad[:3], q]))  # seq at +5, qual at +3
+    g.count_dev(d_s + 5, d_q + 3, len(s))
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.dev_free(d_s); g.dev_free(d_q); g.close()
