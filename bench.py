@@ -40,7 +40,7 @@ def cpu_baseline(rs, n_cores):
     """Reference `bfc -E -k31 -t<cores>` on a bounded read sample, net of its fixed setup."""
     ref = os.path.join(ROOT, "oracle", "_ref", "bfc-ref")
     if not os.path.exists(ref):
-        return None
+        return cpu_baseline_port(rs)
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     out = {}
 
@@ -70,6 +70,21 @@ def cpu_baseline(rs, n_cores):
             "sample": "oracle/_ref/bfc-ref -E -k31 -b33 -t%d on the first %d reads of the same synthetic set (%d k-mers), "
                       "wall %.2fs minus %.2fs setup (1-read run)" % (best["threads"], best["reads"], best["kmers"], best["wall_s"], best["setup_s"]),
             "t1_mkmers_per_s": out["t1"]["mkmers_per_s"], "detail": out}
+
+
+def cpu_baseline_port(rs):
+    """Fallback when the reference binary did not travel: the single-threaded C restatement (oracle/) on a bounded sample."""
+    import oracle
+    n_reads = min(100000, rs.n_reads)
+    seq, qual, off = rs.reads(0, n_reads)
+    c = oracle.Counter(K, BF_SHIFT, q=Q, n_hashes=N_HASHES, l_pre=L_PRE)
+    t0 = time.time()
+    n = c.count(seq, qual, off)
+    dt = time.time() - t0
+    c.close()
+    return {"value": round(n / dt / 1e6, 3), "unit": "M k-mers/s", "cores": 1, "kind": "port",
+            "sample": "oracle/bfc_oracle.c (sequential restatement), first %d reads of the same synthetic set (%d k-mers) in %.2fs; "
+                      "oracle/_ref/bfc-ref was not available on this box" % (n_reads, n, dt)}
 
 
 def pmc_traffic():
