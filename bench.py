@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-reads", type=int, default=int(os.environ.get("BFC_BENCH_BATCH_READS", 1 << 19)))
+    ap.add_argument("--batch-reads", type=int, default=int(os.environ.get("BFC_BENCH_BATCH_READS", 786432)))
     ap.add_argument("--cov", type=float, default=100.0, help="coverage of the 4.6 Mbp genome (100 = config c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

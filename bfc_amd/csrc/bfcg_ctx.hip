@@ -86,7 +86,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	// geometry of the bloom kernel; environment overrides are tuning knobs, not semantics
 	{
 		const char *e;
-		P.R = prm->region_shift > 0 ? prm->region_shift : ((e = getenv("BFCG_R")) ? atoi(e) : 9);
+		P.R = prm->region_shift > 0 ? prm->region_shift : ((e = getenv("BFCG_R")) ? atoi(e) : 8);
 		if (P.R > 10) P.R = 10;
 		if (P.R < 4) P.R = 4;
 		if (P.R > P.bf_shift - 9) P.R = P.bf_shift - 9;
@@ -94,13 +94,13 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
 		if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
-		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 1024;
-		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 1024;
+		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 512;
+		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 512;
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
 		P.bloom_pf = (e = getenv("BFCG_PF")) ? atoi(e) : 4;
-		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 512;
-		// LDS budget: half a CU (2 workgroups resident) unless the region alone needs more
-		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)(80 * 1024 - 1024);
+		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 256;
+		// LDS budget: a third of a CU (3 workgroups of 512 threads resident = 24 waves) unless the region alone needs more
+		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)53000;
 		if (budget > 160 * 1024 - 1024) budget = 160 * 1024 - 1024;
 		if (region + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
 		// per k-mer with clear bits: one list entry (record + mask) and n_hashes first-setter entries at <= 50 % load

@@ -295,36 +295,80 @@ __global__ __launch_bounds__(256) void k_apply(uint32_t *__restrict__ rows, int 
 	}
 }
 
-// pass B: K1 again, records stored straight from registers to rows1[tile][bucket] + rank
+// pass B: K1 again; the tile's records are ordered by level-1 bucket in LDS and copied out run by run with
+// neighbouring lanes (coalesced stores), at rows1[tile][bucket] (absolute offsets after the scan).
 template <typename W, int RW, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                                  int64_t n_pos, const uint32_t *__restrict__ rows1, uint32_t *__restrict__ out)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	constexpr int S = TILE / BT;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
+	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
+	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4); // bucket of each staged record
 	__shared__ uint32_t planes[4 * PW];
-	__shared__ uint32_t cnt[512], base[512];
+	__shared__ uint32_t cnt[512], loff[512], gdelta[512];
+	__shared__ uint32_t s_total;
 	const int nb1 = 1 << P.F1;
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
-	for (int64_t tile = xcd_tile(blockIdx.x, n_tiles); tile < n_tiles; tile += n_tiles) {
-		__syncthreads();
-		for (int i = threadIdx.x; i < nb1; i += BT) { cnt[i] = 0; base[i] = rows1[tile * nb1 + i]; }
-		build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
-		__syncthreads();
-#pragma unroll 4
-		for (int j = 0; j < S; ++j) {
-			int r = j * BT + threadIdx.x;
-			W y0, y1; bool hi;
-			if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
-				uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
-				uint64_t dst = (uint64_t)base[b] + atomicAdd(&cnt[b], 1u);
-				uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
-				RecW<RW> rec;
-				Rec<RW>::pack(rec, (uint64_t)y0, (uint64_t)y1, idx, hi);
-				rec_store<RW>(out + dst * RW, rec);
-			}
+	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	for (int i = threadIdx.x; i < 512; i += BT) cnt[i] = 0;
+	build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
+	__syncthreads();
+	RecW<RW> w[S];
+	uint32_t br[S]; // bucket << 16 | rank inside (tile, bucket)
+#pragma unroll
+	for (int j = 0; j < S; ++j) {
+		const int r = j * BT + threadIdx.x;
+		W y0, y1; bool hi;
+		br[j] = 0xffffffffu;
+		if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
+			const uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
+			const uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
+			Rec<RW>::pack(w[j], (uint64_t)y0, (uint64_t)y1, idx, hi);
+			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
 		}
+	}
+	__syncthreads();
+	{ // exclusive scan of the 512 counters (Hillis-Steele in LDS)
+		for (int i = threadIdx.x; i < 512; i += BT) loff[i] = cnt[i];
+		__syncthreads();
+		for (int o = 1; o < 512; o <<= 1) {
+			uint32_t v[512 / BT > 0 ? 512 / BT : 1];
+			int q = 0;
+			for (int i = threadIdx.x; i < 512; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
+			__syncthreads();
+			q = 0;
+			for (int i = threadIdx.x; i < 512; i += BT, ++q) loff[i] += v[q];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) s_total = loff[511];
+		for (int i = threadIdx.x; i < nb1; i += BT) {
+			const uint32_t ex = loff[i] - cnt[i];
+			gdelta[i] = rows1[tile * nb1 + i] - ex; // global record index = staged position + gdelta[bucket] (u32 modular)
+			cnt[i] = ex;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < S; ++j) {
+		if (br[j] != 0xffffffffu) {
+			const uint32_t b = br[j] >> 16, pos = cnt[b] + (br[j] & 0xffffu);
+#pragma unroll
+			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
+			sbk[pos] = (unsigned short)b;
+		}
+	}
+	__syncthreads();
+	const uint32_t n_in = s_total;
+	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
+		const uint64_t dst = (uint32_t)(pos + gdelta[sbk[pos]]);
+		RecW<RW> rec;
+#pragma unroll
+		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
+		rec_store<RW>(out + dst * RW, rec);
 	}
 }
 
@@ -1021,6 +1065,7 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 
 #define TILE1 BFCG_TILE1
 #define BT1 256
+#define BTS1 512
 #define TILE2 BFCG_TILE2
 #define BT2 512
 
@@ -1038,7 +1083,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(512), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4 + 2), st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1101,6 +1146,7 @@ int bloom_lds_bytes(const KParams &P)
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
+	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, TILE1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE1 * (RW * 4 + 2)); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2)); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
