@@ -270,7 +270,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(), "traffic_note": "HBM bytes per k_bloom launch from profiles/round1_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command)", "kmers_per_launch": int(kmers_per_launch), "avg_launch_ms": round(bloom_ms, 4),
                          "algorithmic_bytes_per_kmer": BLOOM_BYTES_PER_KMER,
-                         "pipeline_frac": round(BLOOM_BYTES_PER_KMER * n_kmers * args.steps / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "whole_job_frac": round(BLOOM_BYTES_PER_KMER * total_kmers * args.steps / dt / 1e9 / HBM_PEAK_GBS / world, 4)},
         }
         if not args.no_cpu_baseline:
             try:

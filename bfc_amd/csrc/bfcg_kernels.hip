@@ -630,7 +630,7 @@ struct BloomArgs {
 	uint64_t *tab_ovf; uint32_t tab_ovf_cap; unsigned long long *ovf_cnt;
 	unsigned long long *pool; unsigned long long pool_cap; // global first-setter pool (entries)
 	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
-	uint64_t *agg_out;             // aggregated seen k-mers: [n_fine][ag_cap][3] (y0, y1, count|high<<16), or NULL = commit inline
+	uint64_t *agg_out;             // aggregated seen k-mers: three planes [y0 | y1 | count|high<<16] of [n_fine][ag_cap], or NULL = commit inline
 	uint32_t *agg_cnt;             // entries per fine bucket
 	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
 };
@@ -997,9 +997,9 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			if (h > 0xffffu) h = 0xffffu;
 			uint64_t y0, y1;
 			if (two) { y0 = a; y1 = G.id1[p]; } else { y0 = a >> P.k; y1 = a & (uint64_t)m; }
-			if (A.agg_out) {
-				uint64_t *dst = A.agg_out + ((uint64_t)f * P.ag_cap + o) * 3;
-				dst[0] = y0; dst[1] = y1; dst[2] = c | (h << 16);
+			if (A.agg_out) { // three planes (y0 | y1 | counts): every store instruction writes whole lines
+				const uint64_t slot = (uint64_t)f * P.ag_cap + o, plane = (uint64_t)A.n_fine * P.ag_cap;
+				A.agg_out[slot] = y0; A.agg_out[plane + slot] = y1; A.agg_out[2 * plane + slot] = c | (h << 16);
 			} else commit_seen<W>(P, A, y0, y1, c, h);
 		}
 	}
@@ -1026,9 +1026,9 @@ __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 	const uint32_t f = (uint32_t)(gid / P.ag_cap), j = (uint32_t)(gid % P.ag_cap);
 	if (f >= A.n_fine || j >= A.agg_cnt[f]) return;
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
-	const uint64_t *src = A.agg_out + gid * 3;
-	const uint32_t c = (uint32_t)src[2];
-	commit_seen<W>(P, A, src[0], src[1], c & 0xffffu, c >> 16);
+	const uint64_t plane = (uint64_t)A.n_fine * P.ag_cap;
+	const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
+	commit_seen<W>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -41,18 +41,28 @@ def main(d, title):
             j = json.loads(line)
             print("Command: `python bench.py --steps %d --warmup %d --no-cpu-baseline` under `rocprofv3 --kernel-trace` (MI355X, gfx950).\n" % (j["steps"], j["warmup"]))
             print("bench line of that run: value = %.1f %s, %.3f ms/step, stage ms/step %s\n" % (j["value"], j["unit"], j["ms_per_step"], json.dumps(j["config"]["stage_ms_per_step"])))
-    print("## Kernel trace (all dispatches of the run, warm-up included)\n")
-    print("| kernel | calls | total ms | avg us | min us | max us | % GPU time | wg | vgpr | sgpr | LDS B |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
-    for name, n, t, mn, mx, wg, vg, sg, lds in rows:
-        print("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.1f | %d | %s | %s | %s |" % (short(name), n, t / 1e6, t / n / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot, wg, vg, sg, lds))
+    def table(rows, tot):
+        print("| kernel | calls | total ms | avg us | min us | max us | % of kernel time | wg | vgpr | sgpr | LDS B |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|")
+        for name, n, t, mn, mx, wg, vg, sg, lds in rows:
+            print("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.1f | %d | %s | %s | %s |" % (short(name), n, t / 1e6, t / n / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot, wg, vg, sg, lds))
+    print("## Kernel trace of the benchmarked command (batches pipelined over two streams: durations of overlapping kernels include the time they share the chip)\n")
+    table(rows, tot)
+    ps = os.path.join(d, "trace_sync", "p_results.db")
+    if os.path.exists(ps):
+        rows2 = kernel_rows(ps)
+        for line in open(os.path.join(d, "trace_sync.log")):
+            if line.startswith('{"metric"'):
+                j = json.loads(line)
+                print("\n## Same command with BFCG_SYNC_BATCHES=1 (no overlap between kernels; %.1f %s, %.3f ms/step)\n" % (j["value"], j["unit"], j["ms_per_step"]))
+        table(rows2, sum(r[2] for r in rows2))
     pm = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         p = os.path.join(d, sub, "p_results.db")
         if os.path.exists(p):
             for k, v in pmc_rows(p).items():
                 pm.setdefault(k, {}).update(v)
-    print("\n## PMC counters per launch (separate passes, same command)\n")
+    print("\n## PMC counters per launch (separate passes, BFCG_SYNC_BATCHES=1 so that counters belong to one kernel)\n")
     print("FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side.  On gfx950 FETCH_SIZE counts a wide coalesced stream at half its")
     print("bytes (MI355X_MICROARCH.md, HBM section), so `read GB (x2)` doubles it; WRITE_SIZE is taken as is.\n")
     print("| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | read GB (x2) | write GB | L2 hit % | SQ_WAIT_ANY / SQ_WAVE_CYCLES | LDS conflict / LDS instr |")
