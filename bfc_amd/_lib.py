@@ -67,6 +67,11 @@ SYMBOLS = {
     "bfcg_mg_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "bfcg_mg_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, u32p]),
     "bfcg_mg_process": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
+    "bfcg_trim_create": (C.c_void_p, [C.c_int, C.POINTER(BfcBf), C.c_int, C.c_uint64, C.c_uint64]),
+    "bfcg_trim_destroy": (None, [C.c_void_p]),
+    "bfcg_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_uint64, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "bfcg_trim_last_ms": (C.c_float, [C.c_void_p]),
+    "bfcg_trim_dev_seq": (C.c_void_p, [C.c_void_p]),
     "bfcg_dev_alloc": (C.c_void_p, [C.c_void_p, C.c_uint64]),
     "bfcg_dev_free": (None, [C.c_void_p, C.c_void_p]),
     "bfcg_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),

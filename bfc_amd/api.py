@@ -303,3 +303,40 @@ class GpuCounter:
         out = np.zeros(n_pos, dtype=np.uint8)
         self._ck(self.L.bfcg_seen_flags(self.ctx, out.ctypes.data, n_pos))
         return out
+
+
+class GpuTrimmer:
+    """Trim pass of `bfc -1` on the GPU (bfcg_trim_*): bloom query kernel + longest streak per read."""
+
+    def __init__(self, k, bloom, device=0, max_pos=1 << 24, max_reads=1 << 18):
+        self.L = _lib.load()
+        self.k = k
+        self.t = self.L.bfcg_trim_create(k, bloom.ptr, device, int(max_pos), int(max_reads))
+        if not self.t:
+            raise BfcGpuError("bfcg_trim_create failed: " + self.L.bfcg_last_error().decode())
+
+    def close(self):
+        if self.t:
+            self.L.bfcg_trim_destroy(self.t)
+            self.t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trim(self, seq_stream, off, min_frac=0.9, d_seq=None):
+        """off: stream offsets (n_reads+1). Returns (start int32[n], end int32[n]); start -1 = read dropped."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        start = np.empty(n, dtype=np.int32); end = np.empty(n, dtype=np.int32)
+        s = np.ascontiguousarray(seq_stream, dtype=np.uint8) if seq_stream is not None else None
+        rc = self.L.bfcg_trim_batch(self.t, s.ctypes.data if s is not None else None, d_seq, int(off[-1]), off.ctypes.data_as(u64p), n,
+                                    C.c_float(min_frac), start.ctypes.data_as(C.POINTER(C.c_int32)), end.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return start, end
+
+    def last_ms(self):
+        return float(self.L.bfcg_trim_last_ms(self.t))

@@ -16,7 +16,7 @@ SO = os.path.join(HERE, "libbfc_gpu.so")
 ARCH = "gfx950"
 
 HIP_SRCS = ["bfcg_kernels.hip", "bfcg_ctx.hip"]
-C_SRCS = ["bfc_host.c", "bfc_count.c"]
+C_SRCS = ["bfc_host.c", "bfc_count.c", "bfc_trim.c"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

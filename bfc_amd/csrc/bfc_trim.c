@@ -1,0 +1,130 @@
+/* bfc_trim.c -- `bfc -1` trim pass behind the reference's own entry point
+ *     void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)        (bfc.h:40, correct.c:620)
+ * for opt->filter_mode: per read, one bloom query per k-mer (max_streak, correct.c:478-497), keep the longest streak if
+ * (streak + k) / length > min_frac (correct.c:557-569), print kept reads (correct.c:605-611).  The queries and the streak
+ * scan run on the GPU (bfcg_trim_batch); the host parses and prints.
+ *
+ * An unmodified correct.c can never call a batched kernel, so this object provides `bfc_correct` itself; the reference's
+ * corrector is linked under another name (compile correct.c with -Dbfc_correct=bfc_correct_cpu, source untouched, see
+ * INTEGRATION.md) and is what this function forwards to when filter_mode is off.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <unistd.h>
+#include <sys/time.h>
+#include <sys/resource.h>
+#include "bfc_gpu.h"
+
+extern double bfc_real_time __attribute__((weak));
+extern int bfc_verbose __attribute__((weak));
+void bfc_correct_cpu(const char *fn, const bfc_opt_t *opt, const void *ptr) __attribute__((weak));
+void *bfcg_host_alloc(uint64_t bytes);
+void bfcg_host_free(void *p);
+
+static double t_real(void) { struct timeval tp; gettimeofday(&tp, 0); return tp.tv_sec + tp.tv_usec * 1e-6; }
+static double t_cpu(void)
+{
+	struct rusage r; getrusage(RUSAGE_SELF, &r);
+	return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+#include "bfc_ingest.h"
+
+typedef struct { uint64_t off_hdr; int l_name; int has_comment, has_qual; } rinfo_t;
+
+void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
+{
+	const bfc_bf_t *bf = (const bfc_bf_t*)ptr;
+	parser_t ps;
+	batch_t b;
+	bfcg_trim_t *tr;
+	uint64_t cap, max_reads, *off;
+	int32_t *st, *en;
+	rinfo_t *ri;
+	char *hdrs = 0, *last_comment = 0; size_t l_hdrs, m_hdrs = 0;
+	const char *env;
+	double t0 = (&bfc_real_time && bfc_real_time > 0.) ? bfc_real_time : t_real();
+
+	if (!opt->filter_mode) {
+		if (bfc_correct_cpu) { bfc_correct_cpu(fn, opt, ptr); return; }
+		fprintf(stderr, "[E::%s] error correction is the reference's correct.c: link it as bfc_correct_cpu (INTEGRATION.md)\n", __func__);
+		abort();
+	}
+	if (!(&bfc_verbose) || bfc_verbose >= 3)
+		fprintf(stderr, "[M::%s @%.1f*%.1f%%] Starting...\n", __func__, t_real() - t0, 100. * t_cpu() / (t_real() - t0 + 1e-6));
+	cap = (uint64_t)(opt->chunk_size > 0 ? opt->chunk_size : 100000000);
+	if ((env = getenv("BFC_GPU_BATCH")) != 0) cap = strtoull(env, 0, 10);
+	if (cap < (1u << 16)) cap = 1u << 16;
+	cap += cap / 64 + (1u << 20);
+	max_reads = cap / 16 + 1024;
+	tr = bfcg_trim_create(opt->k, bf, (env = getenv("BFC_GPU_DEVICE")) ? atoi(env) : 0, cap, max_reads);
+	if (!tr) { fprintf(stderr, "[E::%s] cannot set up the GPU trim pass: %s\n", __func__, bfcg_last_error()); abort(); }
+
+	memset(&ps, 0, sizeof(ps));
+	ps.keep_hdr = 1;
+	ps.chunk_size = (uint64_t)(opt->chunk_size > 0 ? opt->chunk_size : 100000000);
+	if (ps.chunk_size > cap - cap / 32) ps.chunk_size = cap - cap / 32;
+	ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
+	if (ps.rd.fp == 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
+	gzbuffer(ps.rd.fp, 1 << 18);
+	ps.rd.buf = (uint8_t*)malloc(RD_BUF);
+	memset(&b, 0, sizeof(b));
+	b.cap = cap;
+	b.seq = (uint8_t*)bfcg_host_alloc(cap); b.qual = (uint8_t*)malloc(cap);
+	off = (uint64_t*)malloc((max_reads + 1) * 8); st = (int32_t*)malloc(max_reads * 4); en = (int32_t*)malloc(max_reads * 4);
+	ri = (rinfo_t*)malloc(max_reads * sizeof(rinfo_t));
+	if (!b.seq || !b.qual || !off || !st || !en || !ri) { fprintf(stderr, "[E::%s] out of memory\n", __func__); abort(); }
+
+	for (;;) { /* one batch: parse (keeping headers), trim on the GPU, print */
+		uint64_t bases = 0, r, n = 0;
+		int last = 0;
+		b.n_pos = 0; b.n_seqs = 0; l_hdrs = 0;
+		off[0] = 0;
+		for (;;) {
+			if (!ps.have_rec) { if (!next_record(&ps)) { last = 1; break; } ps.have_rec = 1; }
+			if (ps.l_seq + 1 > b.cap) { fprintf(stderr, "[E::%s] a read of %zu bases does not fit a GPU batch\n", __func__, ps.l_seq); abort(); }
+			if (n == max_reads || !batch_put(&b, ps.seq, ps.rec_has_qual ? ps.qual : 0, ps.l_seq)) break;
+			ps.have_rec = 0;
+			if (l_hdrs + ps.l_hdr + 1 > m_hdrs) { m_hdrs = (l_hdrs + ps.l_hdr + 1) * 2; hdrs = (char*)realloc(hdrs, m_hdrs); }
+			memcpy(hdrs + l_hdrs, ps.hdr, ps.l_hdr + 1);
+			{ /* name = up to the first white space, comment = the rest of the line (kseq.h:196-197) */
+				size_t j = 0;
+				while (j < ps.l_hdr && !isspace(ps.hdr[j])) ++j;
+				ri[n].off_hdr = l_hdrs; ri[n].l_name = (int)j; ri[n].has_comment = j < ps.l_hdr; ri[n].has_qual = ps.rec_has_qual;
+			}
+			l_hdrs += ps.l_hdr + 1;
+			off[++n] = b.n_pos;
+			bases += ps.l_seq;
+			if (bases >= ps.chunk_size) break;
+		}
+		if (n) {
+			fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_ec_cb", (int)n);
+			if (bfcg_trim_batch(tr, b.seq, 0, b.n_pos, off, n, opt->min_frac, st, en) != 0) {
+				fprintf(stderr, "[E::%s] GPU trim pass failed: %s\n", __func__, bfcg_last_error()); abort();
+			}
+			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_ec_cb", t_real() - t0, 100. * t_cpu() / (t_real() - t0 + 1e-6), (int)n);
+			for (r = 0; r < n; ++r) { /* correct.c:595-611 */
+				char *h = hdrs + ri[r].off_hdr;
+				int is_fq = ri[r].has_qual && !opt->no_qual;
+				/* a record without a comment inherits the last comment read (kseq leaves comment.s untouched and bseq_read
+				 * strdup()s it, bseq.c:64): reproduced, because the output must be byte-identical */
+				if (ri[r].has_comment) { free(last_comment); last_comment = strdup(h + ri[r].l_name + 1); }
+				if (st[r] < 0) continue;
+				putchar(is_fq ? '@' : '>');
+				fwrite(h, 1, (size_t)ri[r].l_name, stdout);
+				if (last_comment) { putchar('\t'); fputs(last_comment, stdout); }
+				putchar('\n');
+				fwrite(b.seq + off[r] + st[r], 1, (size_t)(en[r] - st[r]), stdout); putchar('\n');
+				if (is_fq) { puts("+"); fwrite(b.qual + off[r] + st[r], 1, (size_t)(en[r] - st[r]), stdout); putchar('\n'); }
+			}
+		}
+		if (last) break;
+	}
+	bfcg_trim_destroy(tr);
+	gzclose(ps.rd.fp);
+	free(ps.rd.buf); free(ps.rd.line); free(ps.seq); free(ps.qual); free(ps.hdr);
+	bfcg_host_free(b.seq); free(b.qual); free(off); free(st); free(en); free(ri); free(hdrs); free(last_comment);
+}

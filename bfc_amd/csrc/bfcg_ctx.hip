@@ -500,3 +500,76 @@ extern "C" void *bfcg_host_alloc(uint64_t bytes)
 	return p;
 }
 extern "C" void bfcg_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// trim pass of `bfc -1` on the GPU (config c5): the bloom filter of k-mers seen twice is resident in HBM, every read
+// of a batch gets its longest streak of bloom hits and the keep / trim decision of correct.c:557-569
+
+struct bfcg_trim {
+	KParams P;
+	int device;
+	hipStream_t st;
+	unsigned int *bloom;
+	uint8_t *d_seq, *d_flags;
+	uint64_t *d_off;
+	int32_t *d_start, *d_end;
+	uint64_t max_pos, max_reads;
+	hipEvent_t e0, e1;
+	float last_ms;
+};
+
+extern "C" bfcg_trim_t *bfcg_trim_create(int k, const bfc_bf_t *bf, int device, uint64_t max_pos, uint64_t max_reads)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("no HIP device available: the trim pass has no CPU fallback here"); return NULL; }
+	if (!bf || k < 1 || k > 63 || bf->n_shift < 9 || bf->n_shift > 37 || bf->n_hashes < 1 || bf->n_hashes > 12) { set_err("bad arguments to bfcg_trim_create"); return NULL; }
+	HIPCKN(hipSetDevice(device));
+	bfcg_trim_t *t = (bfcg_trim_t *)calloc(1, sizeof(bfcg_trim_t));
+	memset(&t->P, 0, sizeof(t->P));
+	t->P.k = k; t->P.bf_shift = bf->n_shift; t->P.n_hashes = bf->n_hashes; t->P.q = 0;
+	t->device = device; t->max_pos = max_pos; t->max_reads = max_reads;
+	HIPCKN(hipStreamCreate(&t->st));
+	HIPCKN(hipEventCreate(&t->e0)); HIPCKN(hipEventCreate(&t->e1));
+	HIPCKN(hipMalloc(&t->bloom, 1ULL << (bf->n_shift - 3)));
+	HIPCKN(hipMemcpy(t->bloom, bf->b, 1ULL << (bf->n_shift - 3), hipMemcpyHostToDevice));
+	HIPCKN(hipMalloc(&t->d_seq, max_pos)); HIPCKN(hipMalloc(&t->d_flags, max_pos));
+	HIPCKN(hipMalloc(&t->d_off, (max_reads + 1) * 8));
+	HIPCKN(hipMalloc(&t->d_start, max_reads * 4)); HIPCKN(hipMalloc(&t->d_end, max_reads * 4));
+	return t;
+}
+
+extern "C" void bfcg_trim_destroy(bfcg_trim_t *t)
+{
+	if (!t) return;
+	(void)hipSetDevice(t->device);
+	(void)hipStreamSynchronize(t->st);
+	(void)hipFree(t->bloom); (void)hipFree(t->d_seq); (void)hipFree(t->d_flags); (void)hipFree(t->d_off); (void)hipFree(t->d_start); (void)hipFree(t->d_end);
+	(void)hipEventDestroy(t->e0); (void)hipEventDestroy(t->e1);
+	(void)hipStreamDestroy(t->st);
+	free(t);
+}
+
+// device-resident stream (d_seq may be NULL: then h_seq is copied in).  off[n_reads+1] are stream offsets: read r is
+// [off[r], off[r+1]-1), byte off[r+1]-1 its separator.  start[r] = -1 if the read is dropped, else keep [start, end).
+extern "C" int bfcg_trim_batch(bfcg_trim_t *t, const uint8_t *h_seq, const uint8_t *d_seq, uint64_t n_pos, const uint64_t *h_off, uint64_t n_reads,
+                               float min_frac, int32_t *start, int32_t *end)
+{
+	if (n_pos > t->max_pos || n_reads > t->max_reads) return set_err("trim batch exceeds the capacity given to bfcg_trim_create");
+	if (n_reads == 0) return 0;
+	HIPCK(hipSetDevice(t->device));
+	if (!d_seq) { HIPCK(hipMemcpyAsync(t->d_seq, h_seq, n_pos, hipMemcpyHostToDevice, t->st)); d_seq = t->d_seq; }
+	HIPCK(hipMemcpyAsync(t->d_off, h_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, t->st));
+	HIPCK(hipEventRecord(t->e0, t->st));
+	run_query(t->P, d_seq, (int64_t)n_pos, t->bloom, t->d_flags, t->st);
+	run_streak(t->P.k, min_frac, t->d_flags, t->d_off, n_reads, t->d_start, t->d_end, t->st);
+	HIPCK(hipEventRecord(t->e1, t->st));
+	HIPCK(hipGetLastError());
+	HIPCK(hipMemcpyAsync(start, t->d_start, n_reads * 4, hipMemcpyDeviceToHost, t->st));
+	HIPCK(hipMemcpyAsync(end, t->d_end, n_reads * 4, hipMemcpyDeviceToHost, t->st));
+	HIPCK(hipStreamSynchronize(t->st));
+	HIPCK(hipEventElapsedTime(&t->last_ms, t->e0, t->e1));
+	return 0;
+}
+extern "C" float bfcg_trim_last_ms(bfcg_trim_t *t) { return t->last_ms; }
+extern "C" void *bfcg_trim_dev_seq(bfcg_trim_t *t) { return t->d_seq; }

@@ -1057,6 +1057,61 @@ __global__ __launch_bounds__(BT) void k_hash_only(KParams P, const uint8_t *__re
 }
 
 // ------------------------------------------------------------------------------------------
+// trim pass of `bfc -1` (config c5): bloom QUERY kernel + per-read longest streak
+//   k_query : K1 + bfc_bf_get (bbf.c:47-63) for the k-mer ending at every position -> flag byte 0 none / 1 miss / 2 hit
+//   k_streak: max_streak (correct.c:478-497) and the keep/trim rule (correct.c:557-569), one lane per read
+
+template <typename W, int TILE, int BT>
+__global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restrict__ seq, int64_t n_pos,
+                                              const unsigned int *__restrict__ bloom, uint8_t *__restrict__ flags)
+{
+	constexpr int PW = (TILE + 64) / 32 + 2;
+	__shared__ uint32_t planes[4 * PW];
+	const W m = kmask<W>(P.k);
+	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
+	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	build_planes<TILE, BT>(seq, nullptr, n_pos, tile * TILE, P.q, planes);
+	__syncthreads();
+#pragma unroll 4
+	for (int j = 0; j < TILE / BT; ++j) {
+		const int r = j * BT + threadIdx.x;
+		const int64_t e = tile * TILE + r;
+		if (e >= n_pos) continue;
+		W y0, y1; bool hi;
+		uint8_t fl = 0;
+		if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
+			BloomAddr a = bloom_addr(bloom_hash<W>(P.k, y0, y1, m), P.bf_shift);
+			const unsigned int *blk = bloom + a.blk * 16; // one 64-byte block per query
+			uint32_t z = a.h1, cnt = 0;
+			for (int t = 0; t < P.n_hashes; ++t) { uint32_t b = bloom_next(z, a.h2); cnt += (blk[b >> 5] >> (b & 31)) & 1u; }
+			fl = cnt == (uint32_t)P.n_hashes ? 2 : 1;
+		}
+		flags[e] = fl;
+	}
+}
+
+// reads r: positions [off[r], off[r+1]-1) of the stream (the last byte of the span is the separator)
+__global__ __launch_bounds__(256) void k_streak(int k, float min_frac, const uint8_t *__restrict__ flags, const uint64_t *__restrict__ off,
+                                                uint64_t n_reads, int32_t *__restrict__ out_start, int32_t *__restrict__ out_end)
+{
+	const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint64_t p0 = off[r];
+	const int len = (int)(off[r + 1] - p0) - 1;
+	unsigned long long mx = 0, t = 0;
+	for (int i = 0; i < len; ++i) { // correct.c:483-495 on the flag stream: a hit extends the run, anything else restarts it after i
+		if (flags[p0 + i] == 2) t += 1ULL << 32; else t = (unsigned long long)i + 1;
+		mx = mx > t ? mx : t;
+	}
+	int st = -1, en = -1;
+	if ((mx >> 32) && (double)((mx >> 32) + (unsigned long long)k) / len > min_frac) { // correct.c:557 (min_frac is a float, bfc.h:21)
+		st = (int)(uint32_t)mx; en = st + (int)(mx >> 32); st -= k - 1;
+	}
+	out_start[r] = st; out_end[r] = en;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage, used by bfcg_ctx.hip)
 
 namespace bfcg {
@@ -1160,6 +1215,19 @@ hipError_t set_bloom_lds_attr(const KParams &P)
 	if (P.k == 32) return set_attr_t<uint32_t, 4>(lds);
 	if (P.k <= 47) return set_attr_t<uint64_t, 4>(lds);
 	return set_attr_t<uint64_t, 6>(lds);
+}
+
+void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *bloom, uint8_t *flags, hipStream_t st)
+{
+	const int64_t tiles = (n_pos + TILE1 - 1) / TILE1;
+	const unsigned g = (unsigned)(((tiles + 7) / 8) * 8);
+	if (P.k <= 32) hipLaunchKernelGGL((k_query<uint32_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+	else hipLaunchKernelGGL((k_query<uint64_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+}
+void run_streak(int k, float min_frac, const uint8_t *flags, const uint64_t *off, uint64_t n_reads, int32_t *out_start, int32_t *out_end, hipStream_t st)
+{
+	if (n_reads == 0) return;
+	hipLaunchKernelGGL(k_streak, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, k, min_frac, flags, off, n_reads, out_start, out_end);
 }
 
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st)

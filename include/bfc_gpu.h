@@ -142,6 +142,19 @@ bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (calle
 int      bfc_ch_get_lpre(const bfc_ch_t *ch);
 uint64_t bfc_ch_export_sorted(const bfc_ch_t *ch, uint32_t *sizes, uint64_t *slots);
 
+/* Trim pass of `bfc -1` (BASELINE config c5: bloom query-only kernel): replaces, for a whole batch of reads, the per-read
+ * max_streak (correct.c:478-497: one bfc_bf_get per k-mer, bbf.c:47-63) and the keep/trim rule (correct.c:557-569).
+ * `bf` is the filter bfc_count returned in filter mode; it is uploaded once.  The stream is the batch format of PART 2
+ * (one separator byte after each read); off[n_reads+1] are the reads' stream offsets.  start[r] = -1: read dropped;
+ * otherwise keep bases [start[r], end[r]) -- exactly correct.c's memmove window. */
+typedef struct bfcg_trim bfcg_trim_t;
+bfcg_trim_t *bfcg_trim_create(int k, const bfc_bf_t *bf, int device, uint64_t max_pos, uint64_t max_reads);
+void bfcg_trim_destroy(bfcg_trim_t *t);
+int bfcg_trim_batch(bfcg_trim_t *t, const uint8_t *h_seq, const uint8_t *d_seq, uint64_t n_pos, const uint64_t *h_off, uint64_t n_reads,
+                    float min_frac, int32_t *start, int32_t *end);
+float bfcg_trim_last_ms(bfcg_trim_t *t);   /* GPU time of the last batch's query + streak kernels (HIP events) */
+void *bfcg_trim_dev_seq(bfcg_trim_t *t);   /* the context's device staging buffer (max_pos bytes) */
+
 /* unit-test hooks: K1 only.  out = 3 u64 per position: y0, y1, flags (bit0 k-mer ends here, bit1 high) */
 int bfcg_hash_positions(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos, uint64_t *out);
 /* per-position seen flags of the last batch (debug_seen): 0 none, 1 not seen, 2 seen */

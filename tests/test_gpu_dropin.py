@@ -113,3 +113,67 @@ def test_dropin_dump_restores_in_reference(g1_fq, tmp_path):
     ref = os.path.join(oracle.REF_DIR, "bfc-ref")
     r = subprocess.run([ref, "-r", dump, "-t", "2", g1_fq], capture_output=True, timeout=600)
     assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == "06a4284e5010e34a1645d1d8015d6da9"
+
+
+def test_gpu_trim_pass_matches_reference(gpu_lib, g1):
+    """Config c5's query kernel: count in filter mode on the GPU, then the GPU trim pass (bloom query + max_streak + keep rule)
+    per read equals the oracle's correct.c:478-497,557-569 restatement, and the formatted output has the md5 of
+    `bfc -1 -k51 -b26 -t1 g1.fq` (golden from the reference binary)."""
+    import ctypes as C
+    rs, (seq, qual, off) = g1
+    k, b = 51, 26
+    g = gpu_lib.GpuCounter(k, b, filter_mode=1, max_batch_pos=len(seq) + rs.n_reads + 64)
+    s_seq, s_qual = gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off)
+    g.count_host(s_seq, s_qual)
+    bf = g.export_bloom(1)
+    g.close()
+    soff = off + np.arange(rs.n_reads + 1, dtype=np.uint64)  # stream offsets (one separator per read)
+    tr = gpu_lib.GpuTrimmer(k, bf, max_pos=len(s_seq) + 64, max_reads=rs.n_reads)
+    start, end = tr.trim(s_seq, soff, 0.9)
+    L = oracle.lib()
+    oc = oracle.Counter(k, b, filter_mode=1)
+    oc.count(seq, qual, off)
+    obf = L.orc_state_bf_high(oc.st)
+    out = []
+    for r in range(rs.n_reads):
+        s = seq[int(off[r]):int(off[r + 1])]
+        mx = L.orc_max_streak(k, obf, s.ctypes.data, len(s))
+        a, e = C.c_int(), C.c_int()
+        if L.orc_trim_decide(mx, k, len(s), 0.9, C.byref(a), C.byref(e)):
+            assert (int(start[r]), int(end[r])) == (a.value, e.value), r
+            q = qual[int(off[r]):int(off[r + 1])]
+            out.append(b"@r%d\n%s\n+\n%s\n" % (r, s[a.value:e.value].tobytes(), q[a.value:e.value].tobytes()))
+        else:
+            assert start[r] == -1, r
+    assert hashlib.md5(b"".join(out)).hexdigest() == "f751f7b1aa28fd74b23194bc7f70158c"
+    tr.close(); bf.close(); oc.close()
+
+
+GPUTRIM = os.path.join(oracle.REF_DIR, "bfc-dropin-gputrim")
+
+
+@pytest.mark.skipif(not os.path.exists(GPUTRIM), reason="oracle/_ref/bfc-dropin-gputrim not built")
+def test_dropin_gpu_trim_binary(g1_fq, tmp_path):
+    """`bfc -1` with BOTH phases on the GPU (bfc_count + bfc_correct from libbfc_gpu.so, reference main() unmodified):
+    stdout byte-identical to the reference; in table mode the same binary forwards to the reference's corrector."""
+    r = subprocess.run([GPUTRIM, "-1", "-k", "51", "-b", "26", "-t", "2", g1_fq], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert hashlib.md5(r.stdout).hexdigest() == "f751f7b1aa28fd74b23194bc7f70158c"
+    r = subprocess.run([GPUTRIM, "-1", "-k", "51", "-b", "26", "-L", "200000", g1_fq], capture_output=True, timeout=600)  # several batches
+    assert hashlib.md5(r.stdout).hexdigest() == "f751f7b1aa28fd74b23194bc7f70158c"
+    r = subprocess.run([GPUTRIM, "-k", "31", "-b", "26", "-t", "4", g1_fq], capture_output=True, timeout=600)
+    assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == "06a4284e5010e34a1645d1d8015d6da9"
+    # headers with comments and FASTA input: compare with the reference binary run on the same file
+    ref = os.path.join(oracle.REF_DIR, "bfc-ref")
+    fa = str(tmp_path / "c.fa")
+    with open(g1_fq) as f, open(fa, "w") as g:
+        for i, line in enumerate(f):
+            if i >= 8000:
+                break
+            if i % 4 == 0:
+                g.write(">" + line[1:].rstrip("\n") + (" comment %d x\n" % i if i % 8 == 0 else "\n"))
+            elif i % 4 == 1:
+                g.write(line)
+    a = subprocess.run([ref, "-1", "-k", "31", "-b", "22", fa], capture_output=True, timeout=600)
+    b = subprocess.run([GPUTRIM, "-1", "-k", "31", "-b", "22", fa], capture_output=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0 and len(a.stdout) > 0 and a.stdout == b.stdout
