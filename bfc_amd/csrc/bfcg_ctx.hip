@@ -90,6 +90,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.R > 10) P.R = 10;
 		if (P.R < 4) P.R = 4;
 		if (P.R > P.bf_shift - 9) P.R = P.bf_shift - 9;
+		while (P.bf_shift - 9 - P.R > 18 && P.R < 10) ++P.R; // two scatter levels of at most 512 buckets: big filters (-b36/-b37, `-s 3g`) take bigger regions
 		P.F = P.bf_shift - 9 - P.R;
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
