@@ -56,6 +56,7 @@ SYMBOLS = {
     "bfc_ch_get_k": (C.c_int, [C.c_void_p]),
     "bfc_ch_kmer_occ": (C.c_int, [C.c_void_p, C.POINTER(BfcKmer)]),
     "bfc_count": (C.c_void_p, [C.c_char_p, C.POINTER(BfcOpt)]),
+    "bfc_correct": (None, [C.c_char_p, C.POINTER(BfcOpt), C.c_void_p]),
     "bfcg_params_default": (None, [C.POINTER(BfcgParams)]),
     "bfcg_create": (C.c_void_p, [C.POINTER(BfcgParams)]),
     "bfcg_destroy": (None, [C.c_void_p]),

@@ -76,6 +76,13 @@ typedef struct {
  * bfc_ch_destroy / bfc_bf_destroy (bfc.c:146,149).  fn may be "-" (stdin) or gzip'd. */
 void *bfc_count(const char *fn, const bfc_opt_t *opt);
 
+/* the second phase's entry point -- bfc.h:40 / correct.c:620.  Provided ONLY for the trim pass of `bfc -1`
+ * (opt->filter_mode, ptr = the bfc_bf_t* bfc_count returned): bloom queries (bbf.c:47-63), longest streak
+ * (correct.c:478-497) and the keep/trim rule (correct.c:557-569) run on the GPU, output as correct.c:595-611.
+ * With filter_mode off it forwards to bfc_correct_cpu(), i.e. the reference's correct.c compiled with
+ * -Dbfc_correct=bfc_correct_cpu; error correction itself is not part of this library. */
+void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr);
+
 /* ============================================================ PART 2: device-level API */
 
 typedef struct bfcg_ctx bfcg_ctx_t;
