@@ -36,7 +36,7 @@ class BfcKmer(C.Structure):
 class BfcgParams(C.Structure):
     _fields_ = [("k", C.c_int), ("q", C.c_int), ("bf_shift", C.c_int), ("n_hashes", C.c_int), ("l_pre", C.c_int),
                 ("filter_mode", C.c_int), ("device", C.c_int), ("max_batch_pos", C.c_uint64),
-                ("region_shift", C.c_int), ("tab_cshift", C.c_int), ("debug_seen", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int)]
+                ("region_shift", C.c_int), ("tab_cshift", C.c_int), ("debug_seen", C.c_int), ("track_order", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int)]
 
 
 # every symbol include/bfc_gpu.h declares: name -> (restype, argtypes)

@@ -89,6 +89,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	prm.k = opt->k; prm.q = opt->q; prm.bf_shift = opt->bf_shift; prm.n_hashes = opt->n_hashes;
 	prm.l_pre = opt->l_pre; prm.filter_mode = opt->filter_mode;
 	prm.device = (env = getenv("BFC_GPU_DEVICE")) ? atoi(env) : 0;
+	prm.track_order = (env = getenv("BFC_GPU_EXACT_DUMP")) ? atoi(env) : 0; /* byte-identical -d dump (costs one u64 per table slot) */
 	/* a batch holds one reference chunk (opt->chunk_size bases, bfc.c:20,-L) plus separators;
 	 * BFC_GPU_BATCH overrides the number of positions per GPU batch */
 	cap = (uint64_t)(opt->chunk_size > 0 ? opt->chunk_size : 100000000);

@@ -90,6 +90,10 @@ struct bfc_ch_s {
 	uint64_t *slots;
 	uint64_t n_keys;
 	pthread_rwlock_t grow_lock; /* inserts share it, growth owns it */
+	/* optional order stamps from the GPU build (bfcg_params_t.track_order): first[slot] = (batch << 32 | file index) of the
+	 * bfc_ch_insert call that created the key, sub_last[sub] = stamp of the last call of any kind on that sub-table.  They let
+	 * bfc_ch_dump replay khash and write `bfc -t1 -d`'s bytes.  Dropped as soon as the host inserts or restores. */
+	uint64_t *first, *sub_last;
 };
 
 static int clamp_lpre(int k, int l_pre)
@@ -109,6 +113,15 @@ bfc_ch_t *bfc_ch_alloc_raw(int k, int l_pre, int cshift)
 	return ch;
 }
 uint64_t *bfc_ch_raw_slots(bfc_ch_t *ch) { return ch->slots; }
+int bfc_ch_raw_order(bfc_ch_t *ch, uint64_t **first, uint64_t **sub_last)
+{
+	ch->first = (uint64_t*)malloc((size_t)8 << (ch->l_pre + ch->cshift));
+	ch->sub_last = (uint64_t*)malloc((size_t)8 << ch->l_pre);
+	if (!ch->first || !ch->sub_last) { free(ch->first); free(ch->sub_last); ch->first = ch->sub_last = 0; return -1; }
+	*first = ch->first; *sub_last = ch->sub_last;
+	return 0;
+}
+static void drop_order(bfc_ch_t *ch) { free(ch->first); free(ch->sub_last); ch->first = ch->sub_last = 0; }
 void bfc_ch_raw_recount(bfc_ch_t *ch)
 {
 	uint64_t i, n = (uint64_t)1 << (ch->l_pre + ch->cshift), c = 0;
@@ -126,6 +139,7 @@ void bfc_ch_destroy(bfc_ch_t *ch)
 {
 	if (!ch) return;
 	pthread_rwlock_destroy(&ch->grow_lock);
+	free(ch->first); free(ch->sub_last);
 	free(ch->slots); free(ch);
 }
 int bfc_ch_get_k(const bfc_ch_t *ch) { return ch->k; }
@@ -148,6 +162,7 @@ static inline uint32_t subkey(const bfc_ch_t *ch, const uint64_t x[2], uint64_t 
 
 static void grow(bfc_ch_t *ch) /* caller holds the write lock */
 {
+	drop_order(ch); /* host-side growth does not carry the GPU's stamps */
 	int nc = ch->cshift + 1;
 	uint64_t n = (uint64_t)1 << (ch->l_pre + ch->cshift), i;
 	uint64_t *ns = (uint64_t*)calloc((size_t)1 << (ch->l_pre + nc), 8);
@@ -193,6 +208,7 @@ int bfc_ch_insert(bfc_ch_t *ch, const uint64_t x[2], int is_high, int forced)
 	uint64_t key;
 	uint32_t sub = subkey(ch, x, &key);
 	(void)forced; /* lock-free upsert never has to give up (htab.c:67-72 returns -1 only on lock contention) */
+	if (ch->first) { pthread_rwlock_wrlock(&ch->grow_lock); drop_order(ch); pthread_rwlock_unlock(&ch->grow_lock); }
 	for (;;) {
 		int r;
 		pthread_rwlock_rdlock(&ch->grow_lock);
@@ -255,28 +271,84 @@ uint64_t bfc_ch_export_sorted(const bfc_ch_t *ch, uint32_t *sizes, uint64_t *slo
 	return n;
 }
 
-/* dump in the reference's format (htab.c:129-149): u32 k, u32 l_pre, then per sub-table
- * u32 n_buckets, u32 size and the occupied slots.  n_buckets follows khash's growth rule
- * (smallest power of two >= 4 whose 0.75 load the size stays below), so the reference's
- * bfc_ch_restore (htab.c:151-176) rebuilds the same sets.  Slot ORDER inside a sub-table is this
- * implementation's, not khash's: parity level L1, not L2. */
+/* ---- khash layout replay (khash.h:219-336 restricted to the no-deletion case) --------------------
+ * Inside a sub-table the reference's bucket layout depends only on (i) the order in which distinct keys first arrive and
+ * (ii) when growth fires: before EVERY put -- new key or duplicate -- the table doubles if n_occupied >= 0.75 n_buckets
+ * (khash.h:298), starting from 4 buckets (khash.h:239); keys sit at (uint32)(key>>14) & mask with triangular probing
+ * i += ++step (khash.h:227,315); growth re-places elements in place with a kick-out chain (khash.h:257-283). */
+typedef struct { uint32_t nb, size; uint64_t *slot; uint8_t *used; } ksub_t;
+
+static void ksub_grow(ksub_t *t, uint32_t nb_new)
+{
+	uint32_t nm = nb_new - 1, j;
+	uint64_t *ns = (uint64_t*)calloc(nb_new, 8);
+	uint8_t *nu = (uint8_t*)calloc(nb_new, 1), *moved = (uint8_t*)calloc(t->nb ? t->nb : 1, 1);
+	for (j = 0; j < t->nb; ++j) { /* same order as the in-place rehash: walk old buckets, follow kick-outs */
+		uint64_t cur;
+		if (!t->used[j] || moved[j]) continue;
+		cur = t->slot[j]; moved[j] = 1;
+		for (;;) {
+			uint32_t i = (uint32_t)(cur >> 14) & nm, step = 0;
+			while (nu[i]) i = (i + (++step)) & nm;
+			nu[i] = 1;
+			if (i < t->nb && t->used[i] && !moved[i]) { uint64_t ev = t->slot[i]; moved[i] = 1; ns[i] = cur; cur = ev; }
+			else { ns[i] = cur; break; }
+		}
+	}
+	free(moved); free(t->slot); free(t->used);
+	t->slot = ns; t->used = nu; t->nb = nb_new;
+}
+static void ksub_put_new(ksub_t *t, uint64_t v) /* v's key is known to be absent */
+{
+	uint32_t mask, i, step = 0;
+	if (t->size >= (t->nb >> 2) + (t->nb >> 1)) ksub_grow(t, t->nb ? t->nb << 1 : 4);
+	mask = t->nb - 1;
+	for (i = (uint32_t)(v >> 14) & mask; t->used[i]; i = (i + (++step)) & mask);
+	t->slot[i] = v; t->used[i] = 1; ++t->size;
+}
+
+typedef struct { uint64_t stamp, v; } ord_t;
+static int cmp_ord(const void *a, const void *b) { uint64_t x = ((const ord_t*)a)->stamp, y = ((const ord_t*)b)->stamp; return x < y ? -1 : x > y; }
+
+/* dump in the reference's format (htab.c:129-149): u32 k, u32 l_pre, then per sub-table u32 n_buckets, u32 size and the
+ * occupied slots in bucket order.  With order stamps (GPU build with track_order) every sub-table is replayed through the
+ * khash rules above: the file is byte-identical to `bfc -t1 -d` (parity level L2).  Without them n_buckets follows khash's
+ * growth rule and the slot order is this implementation's (level L1; the reference's -r restores either). */
 int bfc_ch_dump(const bfc_ch_t *ch, const char *fn)
 {
 	FILE *fp;
 	uint32_t t[2], c = 1u << ch->cshift, j;
 	uint64_t s, n_sub = (uint64_t)1 << ch->l_pre;
-	if ((fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout) == 0) return -1;
+	ord_t *ord = ch->first ? (ord_t*)malloc((size_t)c * sizeof(ord_t)) : 0;
+	if ((fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout) == 0) { free(ord); return -1; }
 	t[0] = (uint32_t)ch->k; t[1] = (uint32_t)ch->l_pre;
 	fwrite(t, 4, 2, fp);
 	for (s = 0; s < n_sub; ++s) {
 		const uint64_t *reg = ch->slots + (s << ch->cshift);
 		uint32_t size = 0, nb = 0;
 		for (j = 0; j < c; ++j) size += reg[j] != 0;
+		if (ord && size) {
+			ksub_t kt = {0, 0, 0, 0};
+			uint32_t n = 0;
+			uint64_t last_new = 0;
+			for (j = 0; j < c; ++j) if (reg[j]) { ord[n].stamp = ch->first[(s << ch->cshift) + j]; ord[n].v = reg[j]; ++n; }
+			qsort(ord, n, sizeof(ord_t), cmp_ord);
+			for (j = 0; j < n; ++j) ksub_put_new(&kt, ord[j].v);
+			last_new = ord[n - 1].stamp;
+			/* a call after the last new key still runs the 0.75 check (khash.h:298 is evaluated on every put) */
+			if (ch->sub_last[s] > last_new && kt.size >= (kt.nb >> 2) + (kt.nb >> 1)) ksub_grow(&kt, kt.nb << 1);
+			t[0] = kt.nb; t[1] = kt.size;
+			fwrite(t, 4, 2, fp);
+			for (j = 0; j < kt.nb; ++j) if (kt.used[j]) fwrite(&kt.slot[j], 8, 1, fp);
+			free(kt.slot); free(kt.used);
+			continue;
+		}
 		if (size) for (nb = 4; size >= (nb >> 2) + (nb >> 1); nb <<= 1);
 		t[0] = nb; t[1] = size;
 		fwrite(t, 4, 2, fp);
 		for (j = 0; j < c; ++j) if (reg[j]) fwrite(&reg[j], 8, 1, fp);
 	}
+	free(ord);
 	fprintf(stderr, "[M::%s] dumpped the hash table to file '%s'.\n", __func__, fn);
 	if (fp != stdout) fclose(fp);
 	return 0;

@@ -106,7 +106,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (region + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
 		// per k-mer with clear bits: one list entry (record + mask) and n_hashes first-setter entries at <= 50 % load
 		const size_t rwb = 8; // list entry: file-order index + (record index | mask)
-		size_t left = budget - region - (size_t)P.ag_cap * (P.k > 32 ? 24 : 16) - 16;
+		size_t left = budget - region - (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + ((prm->track_order && !prm->filter_mode) ? 8 : 0)) - 16;
 		uint32_t fs = 512; while ((size_t)(fs * 2) * 4 + (size_t)(fs * 2 / (2 * P.n_hashes)) * rwb <= left && fs < 32768) fs <<= 1;
 		if ((e = getenv("BFCG_FS")) != 0) fs = (uint32_t)atoi(e);
 		P.fs_cap = fs;
@@ -114,6 +114,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
+	P.track = (prm->track_order && !prm->filter_mode) ? 1 : 0;
 	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 24;
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
@@ -152,9 +153,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
 	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
+	if (P.track) { HIPCKN(hipMalloc(&B.tab_first, 8ULL << (P.l_pre + P.tab_cshift))); HIPCKN(hipMalloc(&B.sub_last, 8ULL << P.l_pre)); }
 	HIPCKN(hipMalloc(&B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1))); // last row: unslotted words
 	B.tab_ovf_cap = 1u << 20;
-	HIPCKN(hipMalloc(&B.tab_ovf, (uint64_t)B.tab_ovf_cap * 24));
+	HIPCKN(hipMalloc(&B.tab_ovf, (uint64_t)B.tab_ovf_cap * 40));
 	// global first-setter pool for regions whose LDS table overflows: worst case every bucket overflows
 	// with cap = pow2 >= 2*n_hashes*n  =>  <= 4*n_hashes*max_kmers entries (+1024 per bucket)
 	B.pool_cap = 4ULL * P.n_hashes * B.max_kmers + 1024ULL * nfine;
@@ -162,7 +164,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	HIPCKN(hipMalloc(&B.pool, (B.pool_cap + 1) * 8));
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
 	if (!getenv("BFCG_INLINE_COMMIT")) {
-		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * 24));
+		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
 		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
 	}
 	for (int b = 0; b < 2; ++b) { HIPCKN(hipMalloc(&c->d_seq2[b], prm->max_batch_pos)); HIPCKN(hipMalloc(&c->d_qual2[b], prm->max_batch_pos)); }
@@ -180,7 +182,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipDeviceSynchronize();
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
-	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats);
+	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -198,6 +200,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
 	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
 	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
+	if (c->B.tab_first) { HIPCK(hipMemsetAsync(c->B.tab_first, 0xff, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st)); HIPCK(hipMemsetAsync(c->B.sub_last, 0, 8ULL << c->P.l_pre, c->st)); }
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
 	HIPCK(hipStreamSynchronize(c->st)); // stage A of the next batch runs on another stream: the zeroing must have landed
 	c->n_batches = 0;
@@ -263,18 +266,21 @@ static int table_maintain(bfcg_ctx_t *c)
 		int old_cshift = P.tab_cshift;
 		unsigned long long *nt = 0;
 		P.tab_cshift = old_cshift + 1;
+		unsigned long long *nf = 0;
 		HIPCK(hipMalloc(&nt, 8ULL << (P.l_pre + P.tab_cshift)));
 		HIPCK(hipMemsetAsync(nt, 0, 8ULL << (P.l_pre + P.tab_cshift), c->st));
-		run_table_rehash(P, B.table, old_cshift, nt, c->st);
+		if (B.tab_first) { HIPCK(hipMalloc(&nf, 8ULL << (P.l_pre + P.tab_cshift))); HIPCK(hipMemsetAsync(nf, 0xff, 8ULL << (P.l_pre + P.tab_cshift), c->st)); }
+		run_table_rehash(P, B.table, old_cshift, nt, B.tab_first, nf, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		HIPCK(hipFree(B.table));
 		B.table = nt;
+		if (B.tab_first) { HIPCK(hipFree(B.tab_first)); B.tab_first = nf; }
 		if (ovf) {
 			uint64_t *tmp = 0;
-			HIPCK(hipMalloc(&tmp, ovf * 24));
-			HIPCK(hipMemcpyAsync(tmp, B.tab_ovf, ovf * 24, hipMemcpyDeviceToDevice, c->st));
+			HIPCK(hipMalloc(&tmp, ovf * 40));
+			HIPCK(hipMemcpyAsync(tmp, B.tab_ovf, ovf * 40, hipMemcpyDeviceToDevice, c->st));
 			HIPCK(hipMemsetAsync(&B.stats[(size_t)ST_SLOTS * ST_N], 0, 8, c->st));
-			run_table_replay(P, B.table, tmp, ovf, B.stats, B.tab_ovf, B.tab_ovf_cap, c->st);
+			run_table_replay(P, B.table, tmp, ovf, B.stats, B.tab_ovf, B.tab_ovf_cap, B.tab_first, B.sub_last, c->st);
 			if (fetch_stats(c) != 0) return -1;
 			HIPCK(hipFree(tmp));
 		} else c->h_stats[ST_TAB_OVF] = 0;
@@ -346,6 +352,7 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
 	const uint32_t *d = c->d_seg;
+	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[0]);
 	return finish_batch(c);
 }
@@ -357,6 +364,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 {
 	const int b = c->cur, nb1 = 1 << c->P.F1;
 	BatchBufs Bt = c->B;
+	Bt.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1; Bt.recs1 = c->recs1[b];
 	if (c->used[b]) HIPCK(hipStreamWaitEvent(c->stA, c->evB[b], 0)); // stage B two batches ago has released this buffer set
 	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, c->stA, c->evt[b]);
@@ -463,6 +471,13 @@ extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
 	if (hipMemcpyAsync(bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
 	    hipStreamSynchronize(c->st) != hipSuccess) { set_err("D2H copy of the count table failed"); bfc_ch_destroy(ch); return NULL; }
+	if (c->B.tab_first && c->n_ranks == 1) { // order stamps travel with the table: bfc_ch_dump can then reproduce khash's layout byte for byte
+		uint64_t *hf = 0, *hl = 0;
+		if (bfc_ch_raw_order(ch, &hf, &hl) != 0 ||
+		    hipMemcpyAsync(hf, c->B.tab_first, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+		    hipMemcpyAsync(hl, c->B.sub_last, 8ULL << c->P.l_pre, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+		    hipStreamSynchronize(c->st) != hipSuccess) { set_err("D2H copy of the order stamps failed"); bfc_ch_destroy(ch); return NULL; }
+	}
 	bfc_ch_raw_recount(ch);
 	return ch;
 }

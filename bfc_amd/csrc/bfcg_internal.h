@@ -22,6 +22,7 @@ struct KParams {
 	uint32_t fs_cap, list_cap; // LDS first-setter table entries (pow2), unresolved-list entries
 	uint32_t ag_cap;            // LDS aggregation table entries (pow2)
 	uint32_t idx_rank;          // rank << (32 - rank_bits): prefixed to the in-batch position so file order is rank-major
+	int track;                  // 1: keep first/last insertion stamps for the byte-identical dump
 	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
 	int bloom_pf;               // records per thread kept in registers by the bloom kernel (2/4)
 	int bloom_bt;               // threads per workgroup of the bloom kernel (256/512/1024)
@@ -39,6 +40,8 @@ struct BatchBufs {
 	unsigned long long *pool; unsigned long long pool_cap;
 	uint8_t *seen_out;
 	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
+	unsigned long long *tab_first, *sub_last; // order stamps (NULL unless KParams.track)
+	unsigned long long batch_hi;              // batch number << 32
 };
 
 void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev);
@@ -50,7 +53,9 @@ hipError_t set_bloom_lds_attr(const KParams &P);
 void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *bloom, uint8_t *flags, hipStream_t st);
 void run_streak(int k, float min_frac, const uint8_t *flags, const uint64_t *off, uint64_t n_reads, int32_t *out_start, int32_t *out_end, hipStream_t st);
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st);
-void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
-void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab, hipStream_t st);
+void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap,
+                      unsigned long long *first, unsigned long long *sub_last, hipStream_t st);
+void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab,
+                      const unsigned long long *old_first, unsigned long long *new_first, hipStream_t st);
 
 } // namespace bfcg

@@ -520,6 +520,17 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	}
 }
 
+// Optional order bookkeeping for the byte-identical `-d` dump: per slot the stamp (batch << 32 | file index)
+// of the FIRST bfc_ch_insert call that created the key, per sub-table the stamp of the LAST call of any kind.  The host
+// replays khash's growth from them (bfc_host.c).  Both are order-independent (min / max), so parking and replay keep them exact.
+struct TabOrder {
+	unsigned long long *first, *sub_last; // NULL: not tracked
+	__device__ __forceinline__ void note(uint32_t sub, uint64_t slot, unsigned long long sf, unsigned long long sl) const
+	{
+		if (first) { atomicMin(&first[slot], sf); atomicMax(&sub_last[sub], sl); }
+	}
+};
+
 // ------------------------------------------------------------------------------------------
 // count table in HBM: 2^l_pre regions of 2^tab_cshift u64 slots, slot = key(50)<<14|high(6)<<8|count(8)
 // exactly as htab.c:7-17 stores it; empty = 0.  Home slot = low bits of key>>14 (as khash does),
@@ -530,7 +541,8 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 
 __device__ __forceinline__ void table_upsert(const KParams &P, unsigned long long *__restrict__ tab, uint64_t y0, uint64_t y1,
                                              uint32_t c, uint32_t h, unsigned long long *__restrict__ stats,
-                                             uint64_t *__restrict__ ovf, uint32_t ovf_cap, unsigned long long *__restrict__ ovf_cnt)
+                                             uint64_t *__restrict__ ovf, uint32_t ovf_cap, unsigned long long *__restrict__ ovf_cnt,
+                                             const TabOrder &O, unsigned long long sf, unsigned long long sl)
 {
 	uint64_t key;
 	uint32_t sub = ch_subkey(P.k, P.l_pre, y0, y1, key);
@@ -542,34 +554,36 @@ __device__ __forceinline__ void table_upsert(const KParams &P, unsigned long lon
 		unsigned long long cur = __hip_atomic_load(&reg[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (cur == 0) {
 			cur = atomicCAS(&reg[pos], 0ULL, fresh);
-			if (cur == 0) { atomicAdd(&stats[ST_KEYS], 1ULL); return; } // stats already points at this workgroup's slot
+			if (cur == 0) { atomicAdd(&stats[ST_KEYS], 1ULL); O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; } // stats already points at this workgroup's slot
 		}
 		if ((cur >> 14) == (key >> 14)) {
 			for (;;) {
 				uint32_t nc = (uint32_t)(cur & 0xff) + c, nh = (uint32_t)((cur >> 8) & 0x3f) + h;
 				unsigned long long nv = (cur & ~0x3fffULL) | (nc < 255 ? nc : 255) | ((uint64_t)(nh < 63 ? nh : 63) << 8);
-				if (nv == cur) return;
+				if (nv == cur) { O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; }
 				unsigned long long old = atomicCAS(&reg[pos], cur, nv);
-				if (old == cur) return;
+				if (old == cur) { O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; }
 				cur = old;
 			}
 		}
 	}
 	// region full: park the k-mer; the host grows the table and replays (counts commute)
 	unsigned long long o = atomicAdd(ovf_cnt, 1ULL); // one chip-wide list index (rare path)
-	if (o < ovf_cap) { ovf[3 * o] = y0; ovf[3 * o + 1] = y1; ovf[3 * o + 2] = (uint64_t)c | ((uint64_t)h << 32); }
+	if (o < ovf_cap) { ovf[5 * o] = y0; ovf[5 * o + 1] = y1; ovf[5 * o + 2] = (uint64_t)c | ((uint64_t)h << 32); ovf[5 * o + 3] = sf; ovf[5 * o + 4] = sl; }
 }
 
 __global__ void k_table_replay(KParams P, unsigned long long *tab, const uint64_t *__restrict__ src, uint64_t n,
-                               unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, unsigned long long *ovf_cnt)
+                               unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, unsigned long long *ovf_cnt, TabOrder O)
 {
 	stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		table_upsert(P, tab, src[3 * i], src[3 * i + 1], (uint32_t)src[3 * i + 2], (uint32_t)(src[3 * i + 2] >> 32), stats, ovf, ovf_cap, ovf_cnt);
+		table_upsert(P, tab, src[5 * i], src[5 * i + 1], (uint32_t)src[5 * i + 2], (uint32_t)(src[5 * i + 2] >> 32), stats, ovf, ovf_cap, ovf_cnt,
+		             O, src[5 * i + 3], src[5 * i + 4]);
 }
 
 // grow: re-insert every occupied slot of the old table (cshift_old) into the new one (P.tab_cshift)
-__global__ void k_table_rehash(KParams P, const unsigned long long *__restrict__ old_tab, int cshift_old, unsigned long long *new_tab)
+__global__ void k_table_rehash(KParams P, const unsigned long long *__restrict__ old_tab, int cshift_old, unsigned long long *new_tab,
+                               const unsigned long long *__restrict__ old_first, unsigned long long *__restrict__ new_first)
 {
 	const uint64_t n = (uint64_t)1 << (P.l_pre + cshift_old);
 	const uint32_t cmask = (1u << P.tab_cshift) - 1;
@@ -582,6 +596,7 @@ __global__ void k_table_rehash(KParams P, const unsigned long long *__restrict__
 			if (atomicCAS(&reg[pos], 0ULL, v) == 0) break;
 			pos = (pos + 1) & cmask;
 		}
+		if (old_first) new_first[(uint64_t)(reg - new_tab) + pos] = old_first[i];
 	}
 }
 
@@ -633,14 +648,17 @@ struct BloomArgs {
 	uint64_t *agg_out;             // aggregated seen k-mers: three planes [y0 | y1 | count|high<<16] of [n_fine][ag_cap], or NULL = commit inline
 	uint32_t *agg_cnt;             // entries per fine bucket
 	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
+	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
+	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
 };
 
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
 template <typename W>
-__device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A, uint64_t y0, uint64_t y1, uint32_t c, uint32_t h)
+__device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A, uint64_t y0, uint64_t y1, uint32_t c, uint32_t h,
+                                            uint32_t idx_first, uint32_t idx_last)
 {
 	if (P.ablate & 1) return;
-	if (A.table) table_upsert(P, A.table, y0, y1, c, h, A.stats, A.tab_ovf, A.tab_ovf_cap, A.ovf_cnt);
+	if (A.table) table_upsert(P, A.table, y0, y1, c, h, A.stats, A.tab_ovf, A.tab_ovf_cap, A.ovf_cnt, A.ord, A.batch_hi | idx_first, A.batch_hi | idx_last);
 	else if (A.bloom_hi) { // count.c:67-68: second filter keeps k-mers seen at least twice (order independent)
 		uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, kmask<W>(P.k));
 		BloomAddr a = bloom_addr(hash, P.bf_shift);
@@ -656,10 +674,10 @@ __device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A
 // finds id0 equal but id1 not yet published cannot decide and simply takes the direct path
 // (always exact: updates commute).  cnt[2p] = occurrences, cnt[2p+1] = high-quality occurrences
 // (plain non-returning LDS adds; a batch has < 2^32 k-mers, so they cannot wrap).
-struct AggView { unsigned long long *id0, *id1; unsigned int *cnt; uint32_t mask; };
+struct AggView { unsigned long long *id0, *id1; unsigned int *cnt; unsigned int *imin, *imax; uint32_t mask; }; // imin/imax: first / last seen file index (NULL: not tracked)
 
 template <typename W>
-__device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint64_t y0, uint64_t y1, bool hi)
+__device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint64_t y0, uint64_t y1, bool hi, uint32_t idx)
 {
 	const bool two = sizeof(W) == 8;
 	const unsigned long long a = two ? y0 : ((y0 << P.k) | y1);
@@ -682,6 +700,7 @@ __device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint
 			}
 			__hip_atomic_fetch_add(&G.cnt[2 * p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (hi) __hip_atomic_fetch_add(&G.cnt[2 * p + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (G.imin) { atomicMin(&G.imin[p], idx); atomicMax(&G.imax[p], idx); }
 			return true;
 		}
 	}
@@ -689,10 +708,10 @@ __device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint
 }
 
 template <typename W>
-__device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, const AggView &G, uint64_t y0, uint64_t y1, bool hi)
+__device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, const AggView &G, uint64_t y0, uint64_t y1, bool hi, uint32_t idx)
 {
 	if (P.ablate & 2) return;
-	if (!agg_add<W>(P, G, y0, y1, hi)) commit_seen<W>(P, A, y0, y1, 1u, (uint32_t)hi);
+	if (!agg_add<W>(P, G, y0, y1, hi, idx)) commit_seen<W>(P, A, y0, y1, 1u, (uint32_t)hi, idx, idx);
 }
 
 // one k-mer record of the bloom kernel, decoded
@@ -776,6 +795,8 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	G.id1 = G.id0;
 	if (two) { G.id1 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8; }
 	G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 8;
+	G.imin = G.imax = nullptr;
+	if (A.ord.first) { G.imin = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; G.imax = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; }
 	G.mask = P.ag_cap - 1;
 	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.fs_cap * 4;
 	unsigned int *list_a = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4; // file-order index of the k-mer
@@ -804,7 +825,10 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS32_EMPTY;
-		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) { G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0; }
+		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) {
+			G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0;
+			if (G.imin) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
+		}
 		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = 0; }
 	}
 	__syncthreads();
@@ -854,7 +878,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			if (act[u] && um[u] == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
 				++n_seen;
 				if (A.seen_out) A.seen_out[r[u].idx] = 2;
-				emit_seen<W>(P, A, G, r[u].y0, r[u].y1, r[u].hi);
+				emit_seen<W>(P, A, G, r[u].y0, r[u].y1, r[u].hi, r[u].idx);
 			}
 			list_push(act[u] && um[u] != 0, r[u].idx, base + threadIdx.x + u * BT, um[u]);
 		}
@@ -921,7 +945,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 				}
 			}
 			if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-			if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi); }
+			if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
 		}
 		dirty = ln != 0;
 		__syncthreads();
@@ -966,7 +990,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			}
 			if (unresolved) {
 				if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-				if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi); }
+				if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
 			}
 		}
 		__syncthreads();
@@ -1000,7 +1024,8 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			if (A.agg_out) { // three planes (y0 | y1 | counts): every store instruction writes whole lines
 				const uint64_t slot = (uint64_t)f * P.ag_cap + o, plane = (uint64_t)A.n_fine * P.ag_cap;
 				A.agg_out[slot] = y0; A.agg_out[plane + slot] = y1; A.agg_out[2 * plane + slot] = c | (h << 16);
-			} else commit_seen<W>(P, A, y0, y1, c, h);
+				if (G.imin) A.agg_out[3 * plane + slot] = (uint64_t)G.imin[p] | ((uint64_t)G.imax[p] << 32);
+			} else commit_seen<W>(P, A, y0, y1, c, h, G.imin ? G.imin[p] : 0u, G.imin ? G.imax[p] : 0u);
 		}
 	}
 	for (int o = 32; o; o >>= 1) n_seen += __shfl_down(n_seen, o);
@@ -1028,7 +1053,8 @@ __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	const uint64_t plane = (uint64_t)A.n_fine * P.ag_cap;
 	const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
-	commit_seen<W>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16);
+	const uint64_t fl = A.ord.first ? A.agg_out[3 * plane + gid] : 0;
+	commit_seen<W>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1163,6 +1189,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine;
+	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.n_hashes == 4) {
 		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4>), dim3(nfine), dim3(1024), lds, st, P, A);
@@ -1195,7 +1222,7 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 
 int bloom_lds_bytes(const KParams &P)
 {
-	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + (size_t)P.ag_cap * (P.k > 32 ? 24 : 16) + (size_t)P.list_cap * 8 + 16);
+	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)) + (size_t)P.list_cap * 8 + 16);
 }
 
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
@@ -1237,14 +1264,17 @@ void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, in
 	else hipLaunchKernelGGL((k_hash_only<uint64_t, TILE1, BT1>), dim3(grid_for(tiles, 4096)), dim3(BT1), 0, st, P, seq, qual, n_pos, out);
 }
 
-void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
+void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap,
+                      unsigned long long *first, unsigned long long *sub_last, hipStream_t st)
 {
 	int g = (int)((n + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
-	hipLaunchKernelGGL(k_table_replay, dim3(g), dim3(256), 0, st, P, tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N);
+	TabOrder O; O.first = first; O.sub_last = sub_last;
+	hipLaunchKernelGGL(k_table_replay, dim3(g), dim3(256), 0, st, P, tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N, O);
 }
-void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab, hipStream_t st)
+void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab,
+                      const unsigned long long *old_first, unsigned long long *new_first, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_table_rehash, dim3(4096), dim3(256), 0, st, P, old_tab, cshift_old, new_tab);
+	hipLaunchKernelGGL(k_table_rehash, dim3(4096), dim3(256), 0, st, P, old_tab, cshift_old, new_tab, old_first, new_first);
 }
 
 } // namespace bfcg

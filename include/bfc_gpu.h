@@ -94,6 +94,7 @@ typedef struct {
 	int region_shift;           /* log2 bloom blocks per LDS region; 0 = default */
 	int tab_cshift;             /* initial log2 slots per sub-table; 0 = default */
 	int debug_seen;             /* allocate the per-position seen-flag buffer (tests) */
+	int track_order;            /* keep per-key first-insert / per-sub-table last-call stamps: bfc_ch_dump becomes byte-identical to `bfc -t1 -d` */
 	int rank, n_ranks;          /* multi-GPU, owner computes: this process is rank of n_ranks (0/0 or 0/1: single GPU) */
 } bfcg_params_t;
 

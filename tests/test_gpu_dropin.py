@@ -177,3 +177,13 @@ def test_dropin_gpu_trim_binary(g1_fq, tmp_path):
     a = subprocess.run([ref, "-1", "-k", "31", "-b", "22", fa], capture_output=True, timeout=600)
     b = subprocess.run([GPUTRIM, "-1", "-k", "31", "-b", "22", fa], capture_output=True, timeout=600)
     assert a.returncode == 0 and b.returncode == 0 and len(a.stdout) > 0 and a.stdout == b.stdout
+
+
+@needs_dropin
+def test_dropin_exact_dump_md5(g1_fq, tmp_path):
+    """`bfc -E -d` through the unmodified main(): with BFC_GPU_EXACT_DUMP=1 the dump file is byte-identical to the reference's."""
+    dump = str(tmp_path / "g1.hash")
+    r = subprocess.run([DROPIN, "-E", "-k", "31", "-b", "26", "-L", "300000", "-d", dump, g1_fq], capture_output=True, timeout=600,
+                       env=dict(os.environ, BFC_GPU_EXACT_DUMP="1"))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert oracle.md5_file(dump) == "d686549d10dd4c71243269013119784a"

@@ -224,3 +224,18 @@ def test_unaligned_device_streams_take_the_byte_path(gpu_lib, g1):
     osz, osl = oc.export()
     assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
     g.dev_free(d_s); g.dev_free(d_q); g.close()
+
+
+@pytest.mark.parametrize("k,b,md5", [(31, 26, "d686549d10dd4c71243269013119784a"), (33, 30, "61b259cfa3b666884c9f4993b5d5677c"),
+                                     (51, 26, "28e866f0bcd07c21e3f698827dd51c3a")])
+@pytest.mark.parametrize("n_batches,cshift", [(1, 0), (5, 0), (3, 1)])
+def test_exact_dump_is_byte_identical(gpu_lib, g1, tmp_path, k, b, md5, n_batches, cshift):
+    """Parity level L2: with order stamps the -d dump has the md5 of `bfc -E -t1 -d` (goldens captured from the
+    reference binary), whatever the batching, also across table growth and replay of parked k-mers (cshift=1)."""
+    rs, (seq, qual, off) = g1
+    g = _gpu_count(gpu_lib, k, b, seq, qual, off, n_batches, track_order=True, tab_cshift=cshift)
+    t = g.export_table()
+    fn = str(tmp_path / "d.hash")
+    assert t.dump(fn) == 0
+    assert oracle.md5_file(fn) == md5
+    g.close()
