@@ -215,13 +215,8 @@ def main():
                     xchg_s += time.perf_counter() - tx
             elif r1 > r0:
                 g.count_dev(d_seq + r0 * stride, d_qual + r0 * stride, (r1 - r0) * stride)
-            if acc and r1 > r0:
-                ms = g.last_batch_ms()
-                if os.environ.get("BFC_BENCH_VERBOSE"):
-                    log("[bench] batch %d (%d reads): %s" % (t, r1 - r0, {k_: round(v_, 3) for k_, v_ in ms.items()}))
-                for kk in stage:
-                    stage[kk] += ms[kk]
-                n_launch += 1
+            if acc and r1 > r0 and os.environ.get("BFC_BENCH_VERBOSE"):
+                log("[bench] batch %d (%d reads), last finalised batch: %s" % (t, r1 - r0, {k_: round(v_, 3) for k_, v_ in g.last_batch_ms().items()}))
 
     def fence():
         g.sync()
@@ -234,12 +229,15 @@ def main():
     for _ in range(args.warmup):
         step(False)
     fence()
+    g.stage_ms(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     fence()
     dt = time.perf_counter() - t0
     st = g.stats()
+    tot, n_launch = g.stage_ms()
+    stage.update(tot)
     if dist:
         import torch
         t = torch.tensor([dt], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libbfc_gpu.so")
+SO = os.environ.get("BFC_GPU_LIB") or os.path.join(HERE, "libbfc_gpu.so")  # BFC_GPU_LIB: A/B a differently built library
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
@@ -81,6 +81,7 @@ SYMBOLS = {
     "bfcg_host_free": (None, [C.c_void_p]),
     "bfcg_stats": (C.c_int, [C.c_void_p, u64p]),
     "bfcg_last_batch_ms": (C.c_int, [C.c_void_p, f32p]),
+    "bfcg_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), u64p, C.c_int]),
     "bfcg_bloom_to_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "bfcg_export_bloom": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),
     "bfcg_export_table": (C.c_void_p, [C.c_void_p]),

@@ -278,6 +278,13 @@ class GpuCounter:
         self.L.bfcg_last_batch_ms(self.ctx, out.ctypes.data_as(f32p))
         return dict(hist1=float(out[0]), scatter1=float(out[1]), level2=float(out[2]), bloom=float(out[3]), commit=float(out[4]), total=float(out[5]))
 
+    def stage_ms(self, reset=False):
+        """Cumulative per-stage GPU ms over all batches since the last reset, and their number (drains the pipeline)."""
+        out = (C.c_double * 6)()
+        n = C.c_uint64()
+        self._ck(self.L.bfcg_stage_ms(self.ctx, out, C.byref(n), int(reset)))
+        return dict(hist1=out[0], scatter1=out[1], level2=out[2], bloom=out[3], commit=out[4], total=out[5]), int(n.value)
+
     def bloom_bytes(self, which=0):
         out = np.empty((1 << (self.bf_shift - 3)) // self.n_ranks, dtype=np.uint8)  # the slice this rank owns
         self._ck(self.L.bfcg_bloom_to_host(self.ctx, which, out.ctypes.data))

@@ -40,6 +40,7 @@ struct bfcg_ctx {
 	unsigned long long *h_stats; // pinned mirror
 	uint64_t n_batches;
 	float last_ms[6];
+	double sum_ms[6]; uint64_t n_timed; // cumulative per-stage GPU time of finalised batches (bfcg_stage_ms)
 	int rw;                      // bytes per record: 12 (k <= 31), 16 (k <= 47), 24
 	uint64_t bloom_bytes;        // bytes of the bloom slice this rank owns
 	int n_ranks, rank, log2n;
@@ -95,7 +96,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
 		if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
-		P.bloom_bt = (e = getenv("BFCG_BT")) ? atoi(e) : 512;
+		P.bloom_bt = (prm->track_order && !prm->filter_mode) ? 512 : (e = getenv("BFCG_BT")) ? atoi(e) : 512;
 		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 512;
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
 		P.bloom_pf = (e = getenv("BFCG_PF")) ? atoi(e) : 4;
@@ -230,6 +231,8 @@ static int batch_times(bfcg_ctx_t *c, int b)
 {
 	for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->evt[b][i == 2 ? 6 : i], c->evt[b][i + 1]));
 	c->last_ms[5] = c->last_ms[0] + c->last_ms[1] + c->last_ms[2] + c->last_ms[3] + c->last_ms[4]; // GPU time of the stages (they overlap across batches)
+	for (int i = 0; i < 6; ++i) c->sum_ms[i] += c->last_ms[i];
+	++c->n_timed;
 	return 0;
 }
 static int check_health(bfcg_ctx_t *c)
@@ -309,7 +312,10 @@ extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_
 	const int nb1 = 1 << c->P.F1;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
-	if (n_pos == 0) { memset(counts, 0, sizeof(uint32_t) * nb1); return 0; }
+	if (n_pos == 0) { // nothing to contribute to this global batch: keep the timing events defined
+		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[0][i], c->st));
+		memset(counts, 0, sizeof(uint32_t) * nb1); return 0;
+	}
 	if (drain(c) != 0) return -1;
 	run_stage_a(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->st, c->evt[0]);
 	HIPCK(hipGetLastError());
@@ -440,6 +446,16 @@ extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
 	for (int i = 0; i < BFCG_ST_N; ++i) out[i] = c->h_stats[i];
 	out[BFCG_ST_TAB_CSHIFT] = (uint64_t)c->P.tab_cshift;
 	out[BFCG_ST_BATCHES] = c->n_batches;
+	return 0;
+}
+
+// cumulative stage times over all batches finalised since the last call with reset != 0 (drains the pipeline first)
+extern "C" int bfcg_stage_ms(bfcg_ctx_t *c, double out[6], uint64_t *n_batches, int reset)
+{
+	if (drain(c) != 0) return -1;
+	for (int i = 0; i < 6; ++i) out[i] = c->sum_ms[i];
+	if (n_batches) *n_batches = c->n_timed;
+	if (reset) { for (int i = 0; i < 6; ++i) c->sum_ms[i] = 0; c->n_timed = 0; }
 	return 0;
 }
 

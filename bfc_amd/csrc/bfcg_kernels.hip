@@ -539,6 +539,7 @@ struct TabOrder {
 // count = min(255, #calls), high = min(63, #high calls) whatever the order (the first call stores
 // count 1 and high = is_high, htab.c:73-75), so pre-aggregated increments are exact.
 
+template <bool TRACK>
 __device__ __forceinline__ void table_upsert(const KParams &P, unsigned long long *__restrict__ tab, uint64_t y0, uint64_t y1,
                                              uint32_t c, uint32_t h, unsigned long long *__restrict__ stats,
                                              uint64_t *__restrict__ ovf, uint32_t ovf_cap, unsigned long long *__restrict__ ovf_cnt,
@@ -554,15 +555,15 @@ __device__ __forceinline__ void table_upsert(const KParams &P, unsigned long lon
 		unsigned long long cur = __hip_atomic_load(&reg[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (cur == 0) {
 			cur = atomicCAS(&reg[pos], 0ULL, fresh);
-			if (cur == 0) { atomicAdd(&stats[ST_KEYS], 1ULL); O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; } // stats already points at this workgroup's slot
+			if (cur == 0) { atomicAdd(&stats[ST_KEYS], 1ULL); if (TRACK) O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; } // stats already points at this workgroup's slot
 		}
 		if ((cur >> 14) == (key >> 14)) {
 			for (;;) {
 				uint32_t nc = (uint32_t)(cur & 0xff) + c, nh = (uint32_t)((cur >> 8) & 0x3f) + h;
 				unsigned long long nv = (cur & ~0x3fffULL) | (nc < 255 ? nc : 255) | ((uint64_t)(nh < 63 ? nh : 63) << 8);
-				if (nv == cur) { O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; }
+				if (nv == cur) { if (TRACK) O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; }
 				unsigned long long old = atomicCAS(&reg[pos], cur, nv);
-				if (old == cur) { O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; }
+				if (old == cur) { if (TRACK) O.note(sub, (uint64_t)(reg - tab) + pos, sf, sl); return; }
 				cur = old;
 			}
 		}
@@ -577,7 +578,7 @@ __global__ void k_table_replay(KParams P, unsigned long long *tab, const uint64_
 {
 	stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		table_upsert(P, tab, src[5 * i], src[5 * i + 1], (uint32_t)src[5 * i + 2], (uint32_t)(src[5 * i + 2] >> 32), stats, ovf, ovf_cap, ovf_cnt,
+		table_upsert<true>(P, tab, src[5 * i], src[5 * i + 1], (uint32_t)src[5 * i + 2], (uint32_t)(src[5 * i + 2] >> 32), stats, ovf, ovf_cap, ovf_cnt,
 		             O, src[5 * i + 3], src[5 * i + 4]);
 }
 
@@ -653,12 +654,12 @@ struct BloomArgs {
 };
 
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
-template <typename W>
+template <typename W, bool TRACK>
 __device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A, uint64_t y0, uint64_t y1, uint32_t c, uint32_t h,
                                             uint32_t idx_first, uint32_t idx_last)
 {
 	if (P.ablate & 1) return;
-	if (A.table) table_upsert(P, A.table, y0, y1, c, h, A.stats, A.tab_ovf, A.tab_ovf_cap, A.ovf_cnt, A.ord, A.batch_hi | idx_first, A.batch_hi | idx_last);
+	if (A.table) table_upsert<TRACK>(P, A.table, y0, y1, c, h, A.stats, A.tab_ovf, A.tab_ovf_cap, A.ovf_cnt, A.ord, A.batch_hi | idx_first, A.batch_hi | idx_last);
 	else if (A.bloom_hi) { // count.c:67-68: second filter keeps k-mers seen at least twice (order independent)
 		uint64_t hash = bloom_hash<W>(P.k, (W)y0, (W)y1, kmask<W>(P.k));
 		BloomAddr a = bloom_addr(hash, P.bf_shift);
@@ -676,7 +677,7 @@ __device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A
 // (plain non-returning LDS adds; a batch has < 2^32 k-mers, so they cannot wrap).
 struct AggView { unsigned long long *id0, *id1; unsigned int *cnt; unsigned int *imin, *imax; uint32_t mask; }; // imin/imax: first / last seen file index (NULL: not tracked)
 
-template <typename W>
+template <typename W, bool TRACK>
 __device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint64_t y0, uint64_t y1, bool hi, uint32_t idx)
 {
 	const bool two = sizeof(W) == 8;
@@ -700,18 +701,18 @@ __device__ __forceinline__ bool agg_add(const KParams &P, const AggView &G, uint
 			}
 			__hip_atomic_fetch_add(&G.cnt[2 * p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (hi) __hip_atomic_fetch_add(&G.cnt[2 * p + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (G.imin) { atomicMin(&G.imin[p], idx); atomicMax(&G.imax[p], idx); }
+			if (TRACK) { atomicMin(&G.imin[p], idx); atomicMax(&G.imax[p], idx); }
 			return true;
 		}
 	}
 	return false;
 }
 
-template <typename W>
+template <typename W, bool TRACK>
 __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, const AggView &G, uint64_t y0, uint64_t y1, bool hi, uint32_t idx)
 {
 	if (P.ablate & 2) return;
-	if (!agg_add<W>(P, G, y0, y1, hi, idx)) commit_seen<W>(P, A, y0, y1, 1u, (uint32_t)hi, idx, idx);
+	if (!agg_add<W, TRACK>(P, G, y0, y1, hi, idx)) commit_seen<W, TRACK>(P, A, y0, y1, 1u, (uint32_t)hi, TRACK ? idx : 0u, TRACK ? idx : 0u);
 }
 
 // one k-mer record of the bloom kernel, decoded
@@ -775,7 +776,7 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 //  * pass 2 (dense) decides seen <=> not the first setter of any of its bits, sets the bits, aggregates;
 //  * the region goes back to HBM, the aggregated k-mers are streamed to k_commit (no returning atomics here).
 // Buckets whose list or first-setter table overflow take the HBM-pool path (exact, slow).
-template <typename W, int RW, int BT, int PF, int NH>
+template <typename W, int RW, int BT, int PF, int NH, bool TRACK>
 __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 	if (two) { G.id1 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8; }
 	G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 8;
 	G.imin = G.imax = nullptr;
-	if (A.ord.first) { G.imin = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; G.imax = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; }
+	if (TRACK) { G.imin = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; G.imax = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; }
 	G.mask = P.ag_cap - 1;
 	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.fs_cap * 4;
 	unsigned int *list_a = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4; // file-order index of the k-mer
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS32_EMPTY;
 		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) {
 			G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0;
-			if (G.imin) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
+			if (TRACK) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
 		}
 		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = 0; }
 	}
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			if (act[u] && um[u] == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
 				++n_seen;
 				if (A.seen_out) A.seen_out[r[u].idx] = 2;
-				emit_seen<W>(P, A, G, r[u].y0, r[u].y1, r[u].hi, r[u].idx);
+				emit_seen<W, TRACK>(P, A, G, r[u].y0, r[u].y1, r[u].hi, r[u].idx);
 			}
 			list_push(act[u] && um[u] != 0, r[u].idx, base + threadIdx.x + u * BT, um[u]);
 		}
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 				}
 			}
 			if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-			if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
+			if (!first) { ++n_seen; emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
 		}
 		dirty = ln != 0;
 		__syncthreads();
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			}
 			if (unresolved) {
 				if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-				if (!first) { ++n_seen; emit_seen<W>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
+				if (!first) { ++n_seen; emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
 			}
 		}
 		__syncthreads();
@@ -1024,8 +1025,8 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 			if (A.agg_out) { // three planes (y0 | y1 | counts): every store instruction writes whole lines
 				const uint64_t slot = (uint64_t)f * P.ag_cap + o, plane = (uint64_t)A.n_fine * P.ag_cap;
 				A.agg_out[slot] = y0; A.agg_out[plane + slot] = y1; A.agg_out[2 * plane + slot] = c | (h << 16);
-				if (G.imin) A.agg_out[3 * plane + slot] = (uint64_t)G.imin[p] | ((uint64_t)G.imax[p] << 32);
-			} else commit_seen<W>(P, A, y0, y1, c, h, G.imin ? G.imin[p] : 0u, G.imin ? G.imax[p] : 0u);
+				if (TRACK) A.agg_out[3 * plane + slot] = (uint64_t)G.imin[p] | ((uint64_t)G.imax[p] << 32);
+			} else commit_seen<W, TRACK>(P, A, y0, y1, c, h, TRACK ? G.imin[p] : 0u, TRACK ? G.imax[p] : 0u);
 		}
 	}
 	for (int o = 32; o; o >>= 1) n_seen += __shfl_down(n_seen, o);
@@ -1044,7 +1045,7 @@ __global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
 }
 
 // apply the aggregated k-mers of every bucket: one thread per slot of agg_out, full occupancy
-template <typename W>
+template <typename W, bool TRACK>
 __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 {
 	const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
@@ -1053,8 +1054,8 @@ __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	const uint64_t plane = (uint64_t)A.n_fine * P.ag_cap;
 	const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
-	const uint64_t fl = A.ord.first ? A.agg_out[3 * plane + gid] : 0;
-	commit_seen<W>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
+	const uint64_t fl = TRACK ? A.agg_out[3 * plane + gid] : 0;
+	commit_seen<W, TRACK>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1191,15 +1192,19 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
-	if (P.n_hashes == 4) {
-		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4>), dim3(nfine), dim3(1024), lds, st, P, A);
-		else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4>), dim3(nfine), dim3(512), lds, st, P, A);
-		else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4, 4>), dim3(nfine), dim3(256), lds, st, P, A);
-	} else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0>), dim3(nfine), dim3(512), lds, st, P, A);
+	if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
+		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, true>), dim3(nfine), dim3(512), lds, st, P, A);
+	} else if (P.n_hashes == 4) {
+		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false>), dim3(nfine), dim3(1024), lds, st, P, A);
+		else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4, 4, false>), dim3(nfine), dim3(256), lds, st, P, A);
+	} else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false>), dim3(nfine), dim3(512), lds, st, P, A);
 	if (ev) hipEventRecord(ev[4], st);
 	if (B.agg_out) {
 		const uint64_t slots = (uint64_t)nfine * P.ag_cap;
-		hipLaunchKernelGGL((k_commit<W>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, P, A);
+		if (P.track) hipLaunchKernelGGL((k_commit<W, true>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, P, A);
+		else hipLaunchKernelGGL((k_commit<W, false>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, P, A);
 	}
 	if (ev) hipEventRecord(ev[5], st);
 }
@@ -1230,10 +1235,12 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	hipError_t e;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, TILE1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE1 * (RW * 4 + 2)); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2)); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 hipError_t set_bloom_lds_attr(const KParams &P)
 {

@@ -140,6 +140,8 @@ int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
 /* per-stage GPU time of the last batch, HIP events on the context's stream (ms):
  * [0] hist1+scans [1] scatter1 [2] hist2+scan2+scatter2 [3] bloom regions [4] table commit [5] total */
 int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[6]);
+/* the same, summed over every batch finalised since the last reset != 0 call; drains the pipeline first */
+int bfcg_stage_ms(bfcg_ctx_t *c, double out[6], uint64_t *n_batches, int reset);
 
 /* results */
 int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *dst);   /* 2^(bf_shift-3) / n_ranks bytes: the owned slice */

@@ -38,6 +38,7 @@ def _worker(rank, world, port, tmp):
     rs = gen.ReadSet(seed=11, G=20000, cov=6)
     seq, qual, off = rs.reads()
     eng = CpuEngine(rank, world, K, B)
+    bdist.CHUNK = 4099  # force several point-to-point messages per peer
     for row in _shares(seq, qual, off, rs.n_reads, 3, world):
         seg = bdist.count_batch(eng, row[rank], None, 0)
         assert seg.shape == (world, eng.nb1 // world)
