@@ -776,8 +776,9 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 //  * pass 2 (dense) decides seen <=> not the first setter of any of its bits, sets the bits, aggregates;
 //  * the region goes back to HBM, the aggregated k-mers are streamed to k_commit (no returning atomics here).
 // Buckets whose list or first-setter table overflow take the HBM-pool path (exact, slow).
+// 512-thread workgroups run three per CU (LDS), i.e. 6 waves per SIMD: allow the registers that go with it (no scratch)
 template <typename W, int RW, int BT, int PF, int NH, bool TRACK>
-__global__ __launch_bounds__(BT, 8) void k_bloom(KParams P, BloomArgs A)
+__global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1197,6 +1198,8 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else if (P.n_hashes == 4) {
 		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false>), dim3(nfine), dim3(1024), lds, st, P, A);
+		else if (P.bloom_bt == 512 && P.bloom_pf == 2) hipLaunchKernelGGL((k_bloom<W, RW, 512, 2, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
+		else if (P.bloom_bt == 512 && P.bloom_pf == 3) hipLaunchKernelGGL((k_bloom<W, RW, 512, 3, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
 		else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4, 4, false>), dim3(nfine), dim3(256), lds, st, P, A);
 	} else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false>), dim3(nfine), dim3(512), lds, st, P, A);
@@ -1237,6 +1240,8 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2)); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 3, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
