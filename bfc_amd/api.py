@@ -347,3 +347,47 @@ class GpuTrimmer:
 
     def last_ms(self):
         return float(self.L.bfcg_trim_last_ms(self.t))
+
+
+class GpuKcov:
+    """bfc_ec_kcov (correct.c:96-117) for whole batches on the GPU (bfcg_kcov_*): table probe per k-mer + coverage sums.
+    `table` is a HostTable (uploaded once) or a GpuCounter whose device table is used in place."""
+
+    LCOV, HCOV, SOLID_END, HIGH_END = 0x3f, 0x3f << 6, 1 << 12, 1 << 13
+
+    def __init__(self, table, device=0, max_pos=1 << 24):
+        self.L = _lib.load()
+        self._keep = table
+        if isinstance(table, GpuCounter):
+            self.t = self.L.bfcg_kcov_attach(table.ctx, int(max_pos))
+        else:
+            self.t = self.L.bfcg_kcov_create(table.ptr, device, int(max_pos))
+        if not self.t:
+            raise BfcGpuError("bfcg_kcov_create failed: " + self.L.bfcg_last_error().decode())
+
+    def close(self):
+        if self.t:
+            self.L.bfcg_kcov_destroy(self.t)
+            self.t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kcov(self, seq_stream, min_occ=3, d_seq=None, n_pos=None, fetch=True):
+        """One packed u16 per stream position: lcov | hcov<<6 | solid_end<<12 | high_end<<13."""
+        s = np.ascontiguousarray(seq_stream, dtype=np.uint8) if seq_stream is not None else None
+        n = len(s) if s is not None else int(n_pos)
+        out = np.empty(n, dtype=np.uint16) if fetch else None
+        rc = self.L.bfcg_kcov_batch(self.t, s.ctypes.data if s is not None else None, d_seq, n, int(min_occ), out.ctypes.data if fetch else None)
+        if rc != 0:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return out
+
+    def last_ms(self):
+        return float(self.L.bfcg_kcov_last_ms(self.t))
+
+    def dev_seq(self):
+        return self.L.bfcg_kcov_dev_seq(self.t)

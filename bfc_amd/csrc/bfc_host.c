@@ -113,6 +113,7 @@ bfc_ch_t *bfc_ch_alloc_raw(int k, int l_pre, int cshift)
 	return ch;
 }
 uint64_t *bfc_ch_raw_slots(bfc_ch_t *ch) { return ch->slots; }
+int bfc_ch_raw_cshift(const bfc_ch_t *ch) { return ch->cshift; }
 int bfc_ch_raw_order(bfc_ch_t *ch, uint64_t **first, uint64_t **sub_last)
 {
 	ch->first = (uint64_t*)malloc((size_t)8 << (ch->l_pre + ch->cshift));

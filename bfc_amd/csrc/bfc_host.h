@@ -8,6 +8,7 @@ extern "C" {
 bfc_ch_t *bfc_ch_alloc_raw(int k, int l_pre_clamped, int cshift);
 uint64_t *bfc_ch_raw_slots(bfc_ch_t *ch);
 void bfc_ch_raw_recount(bfc_ch_t *ch);
+int bfc_ch_raw_cshift(const bfc_ch_t *ch); /* log2 of a sub-table's slot count */
 /* attach order stamps (first[slots], sub_last[2^l_pre]); returns their buffers to fill */
 int bfc_ch_raw_order(bfc_ch_t *ch, uint64_t **first, uint64_t **sub_last);
 #ifdef __cplusplus

@@ -605,3 +605,89 @@ extern "C" int bfcg_trim_batch(bfcg_trim_t *t, const uint8_t *h_seq, const uint8
 }
 extern "C" float bfcg_trim_last_ms(bfcg_trim_t *t) { return t->last_ms; }
 extern "C" void *bfcg_trim_dev_seq(bfcg_trim_t *t) { return t->d_seq; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// k-mer coverage for the corrector: bfc_ec_kcov (correct.c:96-117) for a whole batch of reads against the count
+// table resident in HBM -- either uploaded from a host bfc_ch_t or borrowed from a counting context that still holds it
+
+struct bfcg_kcov {
+	KParams P;
+	int device, owns_table;
+	hipStream_t st;
+	unsigned long long *table;
+	uint8_t *d_seq, *d_flags;
+	uint16_t *d_out;
+	uint64_t max_pos;
+	hipEvent_t e0, e1;
+	float last_ms;
+};
+
+static bfcg_kcov_t *kcov_new(int k, int l_pre, int cshift, int device, uint64_t max_pos)
+{
+	HIPCKN(hipSetDevice(device));
+	bfcg_kcov_t *t = (bfcg_kcov_t *)calloc(1, sizeof(bfcg_kcov_t));
+	memset(&t->P, 0, sizeof(t->P));
+	t->P.k = k; t->P.l_pre = l_pre; t->P.tab_cshift = cshift; t->P.q = 0;
+	t->device = device; t->max_pos = max_pos;
+	HIPCKN(hipStreamCreate(&t->st));
+	HIPCKN(hipEventCreate(&t->e0)); HIPCKN(hipEventCreate(&t->e1));
+	HIPCKN(hipMalloc(&t->d_seq, max_pos)); HIPCKN(hipMalloc(&t->d_flags, max_pos)); HIPCKN(hipMalloc(&t->d_out, max_pos * 2));
+	return t;
+}
+
+extern "C" bfcg_kcov_t *bfcg_kcov_create(const bfc_ch_t *ch, int device, uint64_t max_pos)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("no HIP device available: the k-mer coverage pass has no CPU fallback here"); return NULL; }
+	if (!ch || max_pos == 0) { set_err("bad arguments to bfcg_kcov_create"); return NULL; }
+	bfcg_kcov_t *t = kcov_new(bfc_ch_get_k(ch), bfc_ch_get_lpre(ch), bfc_ch_raw_cshift(ch), device, max_pos);
+	if (!t) return NULL;
+	const uint64_t bytes = 8ULL << (t->P.l_pre + t->P.tab_cshift);
+	t->owns_table = 1;
+	HIPCKN(hipMalloc(&t->table, bytes));
+	HIPCKN(hipMemcpy(t->table, bfc_ch_raw_slots((bfc_ch_t *)ch), bytes, hipMemcpyHostToDevice));
+	return t;
+}
+
+// the table stays where the count kernels built it; the context must outlive the returned object and must not count meanwhile
+extern "C" bfcg_kcov_t *bfcg_kcov_attach(bfcg_ctx_t *c, uint64_t max_pos)
+{
+	if (!c || !c->B.table || max_pos == 0) { set_err("bfcg_kcov_attach needs a table-mode context"); return NULL; }
+	if (drain(c) != 0) return NULL;
+	bfcg_kcov_t *t = kcov_new(c->P.k, c->P.l_pre, c->P.tab_cshift, c->prm.device, max_pos);
+	if (!t) return NULL;
+	t->table = c->B.table;
+	return t;
+}
+
+extern "C" void bfcg_kcov_destroy(bfcg_kcov_t *t)
+{
+	if (!t) return;
+	(void)hipSetDevice(t->device);
+	(void)hipStreamSynchronize(t->st);
+	if (t->owns_table) (void)hipFree(t->table);
+	(void)hipFree(t->d_seq); (void)hipFree(t->d_flags); (void)hipFree(t->d_out);
+	(void)hipEventDestroy(t->e0); (void)hipEventDestroy(t->e1);
+	(void)hipStreamDestroy(t->st);
+	free(t);
+}
+
+// stream = batch format of PART 2; out[p] (host, may be NULL) / the device buffer of bfcg_kcov_dev_out() get one packed u16 per position
+extern "C" int bfcg_kcov_batch(bfcg_kcov_t *t, const uint8_t *h_seq, const uint8_t *d_seq, uint64_t n_pos, int min_occ, uint16_t *out)
+{
+	if (n_pos > t->max_pos) return set_err("k-mer coverage batch exceeds the capacity given at creation");
+	if (n_pos == 0) return 0;
+	HIPCK(hipSetDevice(t->device));
+	if (!d_seq) { HIPCK(hipMemcpyAsync(t->d_seq, h_seq, n_pos, hipMemcpyHostToDevice, t->st)); d_seq = t->d_seq; }
+	HIPCK(hipEventRecord(t->e0, t->st));
+	run_kcov(t->P, d_seq, (int64_t)n_pos, min_occ, t->table, t->d_flags, t->d_out, t->st);
+	HIPCK(hipEventRecord(t->e1, t->st));
+	HIPCK(hipGetLastError());
+	if (out) HIPCK(hipMemcpyAsync(out, t->d_out, n_pos * 2, hipMemcpyDeviceToHost, t->st));
+	HIPCK(hipStreamSynchronize(t->st));
+	HIPCK(hipEventElapsedTime(&t->last_ms, t->e0, t->e1));
+	return 0;
+}
+extern "C" float bfcg_kcov_last_ms(bfcg_kcov_t *t) { return t->last_ms; }
+extern "C" void *bfcg_kcov_dev_seq(bfcg_kcov_t *t) { return t->d_seq; }
+extern "C" void *bfcg_kcov_dev_out(bfcg_kcov_t *t) { return t->d_out; }

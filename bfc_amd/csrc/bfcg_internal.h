@@ -51,6 +51,7 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 int bloom_lds_bytes(const KParams &P);
 hipError_t set_bloom_lds_attr(const KParams &P);
 void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *bloom, uint8_t *flags, hipStream_t st);
+void run_kcov(const KParams &P, const uint8_t *seq, int64_t n_pos, int min_occ, const void *tab, uint8_t *flags, uint16_t *out, hipStream_t st);
 void run_streak(int k, float min_frac, const uint8_t *flags, const uint64_t *off, uint64_t n_reads, int32_t *out_start, int32_t *out_end, hipStream_t st);
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st);
 void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap,

@@ -1140,6 +1140,86 @@ __global__ __launch_bounds__(256) void k_streak(int k, float min_frac, const uin
 }
 
 // ------------------------------------------------------------------------------------------
+// k-mer coverage of the corrector, bfc_ec_kcov (correct.c:96-117), for every read of a batch against the count table in HBM
+//   k_occ : K1 + bfc_ch_kmer_occ (htab.c:85-99) for the k-mer ENDING at every position -> flag byte: bit0 solid_end
+//           (count >= min_occ), bit1 high_end (high count >= min_occ+1) ; absent k-mers and non-k-mer positions give 0
+//   k_cov : lcov / hcov of every base = number of solid (solid and high) k-mers covering it = the k flags that follow it;
+//           packed like ecbase_t's bit-fields (correct.c:14-19): lcov | hcov<<6 | solid_end<<12 | high_end<<13
+
+// bfc_ch_get on the device layout: probe the sub-table's region from the key's home slot until the key or an empty slot
+__device__ __forceinline__ int table_get(const KParams &P, const unsigned long long *__restrict__ tab, uint64_t y0, uint64_t y1)
+{
+	uint64_t key;
+	const uint32_t sub = ch_subkey(P.k, P.l_pre, y0, y1, key);
+	const uint32_t cmask = (1u << P.tab_cshift) - 1;
+	const unsigned long long *reg = tab + ((uint64_t)sub << P.tab_cshift);
+	uint32_t pos = (uint32_t)(key >> 14) & cmask;
+	for (uint32_t probe = 0; probe <= cmask; ++probe, pos = (pos + 1) & cmask) {
+		const unsigned long long cur = reg[pos];
+		if (cur == 0) return -1;
+		if ((cur >> 14) == (key >> 14)) return (int)(cur & 0x3fff);
+	}
+	return -1;
+}
+
+template <typename W, int TILE, int BT>
+__global__ __launch_bounds__(BT) void k_occ(KParams P, const uint8_t *__restrict__ seq, int64_t n_pos, int min_occ,
+                                            const unsigned long long *__restrict__ tab, uint8_t *__restrict__ flags)
+{
+	constexpr int PW = (TILE + 64) / 32 + 2;
+	__shared__ uint32_t planes[4 * PW];
+	const W m = kmask<W>(P.k);
+	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
+	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	build_planes<TILE, BT>(seq, nullptr, n_pos, tile * TILE, P.q, planes);
+	__syncthreads();
+#pragma unroll 4
+	for (int j = 0; j < TILE / BT; ++j) {
+		const int r = j * BT + threadIdx.x;
+		const int64_t e = tile * TILE + r;
+		if (e >= n_pos) continue;
+		W y0, y1; bool hi;
+		uint8_t fl = 0;
+		if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
+			const int occ = table_get(P, tab, (uint64_t)y0, (uint64_t)y1);
+			if (occ >= 0) fl = (uint8_t)(((occ & 0xff) >= min_occ ? 1 : 0) | ((occ >> 8 & 0x3f) >= min_occ + 1 ? 2 : 0));
+		}
+		flags[e] = fl;
+	}
+}
+
+// TILE positions per workgroup; the flags of the TILE+64 positions from the tile's start become two bit rows in LDS
+template <int TILE, int BT>
+__global__ __launch_bounds__(BT) void k_cov(int k, const uint8_t *__restrict__ flags, int64_t n_pos, uint16_t *__restrict__ out)
+{
+	constexpr int NW = TILE / 64 + 1;
+	__shared__ unsigned long long solid[NW + 1], high[NW + 1];
+	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
+	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	const int64_t t0 = tile * TILE;
+	for (int r = threadIdx.x; r < NW * 64; r += BT) { // a wave's 64 flags -> one word of each row
+		const int64_t e = t0 + r;
+		const uint8_t fl = e < n_pos ? flags[e] : 0;
+		const unsigned long long bs = __ballot(fl & 1), bh = __ballot((fl & 3) == 3);
+		if ((threadIdx.x & 63) == 0) { solid[r >> 6] = bs; high[r >> 6] = bh; }
+	}
+	if (threadIdx.x == 0) { solid[NW] = 0; high[NW] = 0; }
+	__syncthreads();
+	const unsigned long long wm = k >= 64 ? ~0ULL : (1ULL << k) - 1;
+	for (int r = threadIdx.x; r < TILE; r += BT) {
+		const int64_t e = t0 + r;
+		if (e >= n_pos) break;
+		const int w = r >> 6, sh = r & 63;
+		unsigned long long a = solid[w] >> sh, b = high[w] >> sh;
+		if (sh) { a |= solid[w + 1] << (64 - sh); b |= high[w + 1] << (64 - sh); }
+		const uint8_t fl = flags[e];
+		out[e] = (uint16_t)(__popcll(a & wm) | __popcll(b & wm) << 6 | (fl & 1) << 12 | (fl >> 1 & 1) << 13);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage, used by bfcg_ctx.hip)
 
 namespace bfcg {
@@ -1267,6 +1347,15 @@ void run_streak(int k, float min_frac, const uint8_t *flags, const uint64_t *off
 {
 	if (n_reads == 0) return;
 	hipLaunchKernelGGL(k_streak, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, k, min_frac, flags, off, n_reads, out_start, out_end);
+}
+
+void run_kcov(const KParams &P, const uint8_t *seq, int64_t n_pos, int min_occ, const void *tab, uint8_t *flags, uint16_t *out, hipStream_t st)
+{
+	const int64_t tiles = (n_pos + TILE1 - 1) / TILE1;
+	const unsigned g = (unsigned)(((tiles + 7) / 8) * 8);
+	if (P.k <= 32) hipLaunchKernelGGL((k_occ<uint32_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, min_occ, (const unsigned long long *)tab, flags);
+	else hipLaunchKernelGGL((k_occ<uint64_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, min_occ, (const unsigned long long *)tab, flags);
+	hipLaunchKernelGGL((k_cov<TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P.k, flags, n_pos, out);
 }
 
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st)

@@ -165,6 +165,21 @@ int bfcg_trim_batch(bfcg_trim_t *t, const uint8_t *h_seq, const uint8_t *d_seq, 
 float bfcg_trim_last_ms(bfcg_trim_t *t);   /* GPU time of the last batch's query + streak kernels (HIP events) */
 void *bfcg_trim_dev_seq(bfcg_trim_t *t);   /* the context's device staging buffer (max_pos bytes) */
 
+/* k-mer coverage of the corrector: replaces, for a whole batch of reads, bfc_ec_kcov (correct.c:96-117) as
+ * bfc_ec1 first calls it on the unmodified read (correct.c:403) -- one bfc_ch_kmer_occ (htab.c:94-99) per k-mer.  The table
+ * is uploaded once from the host bfc_ch_t that bfc_count / bfc_ch_restore returned (bfcg_kcov_create), or borrowed in place
+ * from a counting context (bfcg_kcov_attach: no export).  Output: one u16 per stream position, packed like ecbase_t's
+ * bit-fields (correct.c:17): lcov (bits 0-5) | hcov (6-11) | solid_end (12) | high_end (13); 0 for separators.
+ * min_occ is opt->min_cov (bfc.h:20, correct.c:403). */
+typedef struct bfcg_kcov bfcg_kcov_t;
+bfcg_kcov_t *bfcg_kcov_create(const bfc_ch_t *ch, int device, uint64_t max_pos);
+bfcg_kcov_t *bfcg_kcov_attach(bfcg_ctx_t *ctx, uint64_t max_pos);
+void bfcg_kcov_destroy(bfcg_kcov_t *t);
+int bfcg_kcov_batch(bfcg_kcov_t *t, const uint8_t *h_seq, const uint8_t *d_seq, uint64_t n_pos, int min_occ, uint16_t *out);
+float bfcg_kcov_last_ms(bfcg_kcov_t *t);   /* GPU time of the last batch's two kernels (HIP events) */
+void *bfcg_kcov_dev_seq(bfcg_kcov_t *t);   /* device staging buffer for the stream (max_pos bytes) */
+void *bfcg_kcov_dev_out(bfcg_kcov_t *t);   /* device result of the last batch (max_pos u16) */
+
 /* unit-test hooks: K1 only.  out = 3 u64 per position: y0, y1, flags (bit0 k-mer ends here, bit1 high) */
 int bfcg_hash_positions(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos, uint64_t *out);
 /* per-position seen flags of the last batch (debug_seen): 0 none, 1 not seen, 2 seen */

@@ -98,6 +98,8 @@ def lib():
         L.orc_max_streak.restype = C.c_uint64
         L.orc_max_streak.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trim_decide.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_kcov.restype = None
+        L.orc_kcov.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -107,6 +109,25 @@ def have_ref():
 
 
 _ref = None
+_ref_ec = None
+
+
+def have_ref_ec():
+    return os.path.exists(os.path.join(REF_DIR, "libbfcref_ec.so"))
+
+
+def ref_ec():
+    """The reference with its corrector's private bfc_ec_kcov reachable (libbfcref_ec.so, ref_shim_ec.c)."""
+    global _ref_ec
+    if _ref_ec is None:
+        R = C.CDLL(os.path.join(REF_DIR, "libbfcref_ec.so"))
+        R.bfc_ch_restore.restype = C.c_void_p
+        R.bfc_ch_restore.argtypes = [C.c_char_p]
+        R.bfc_ch_destroy.argtypes = [C.c_void_p]
+        R.ref_kcov.restype = None
+        R.ref_kcov.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p]
+        _ref_ec = R
+    return _ref_ec
 
 
 def ref():

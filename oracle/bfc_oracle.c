@@ -442,3 +442,36 @@ int orc_trim_decide(uint64_t max, int k, int len, float min_frac, int *start, in
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------ k-mer coverage of the corrector
+ * bfc_ec_kcov (correct.c:96-117) on one read: for the k-mer ending at base i, r = bfc_ch_kmer_occ (htab.c:94-99);
+ * high_end if the high count (r>>8&0x3f) >= min_occ+1, solid_end if the count (r&0xff) >= min_occ, and every base of a
+ * solid k-mer gets ++lcov, hcov += high_end.  lcov/hcov are 6-bit fields of ecbase_t (correct.c:17) -- k <= 63 cannot
+ * wrap them.  out[i] = lcov | hcov<<6 | solid_end<<12 | high_end<<13. */
+void orc_kcov(const orc_ch_t *ch, int min_occ, const uint8_t *seq, int len, uint16_t *out)
+{
+	int i, j, l = 0, k = ch->k;
+	uint64_t p[4] = {0, 0, 0, 0};
+	uint8_t *lc = (uint8_t*)calloc(len + 1, 1), *hc = (uint8_t*)calloc(len + 1, 1);
+	for (i = 0; i < len; ++i) out[i] = 0;
+	for (i = 0; i < len; ++i) {
+		int c = orc_base_code(seq[i]);
+		if (c < 4) {
+			orc_kmer_push(k, p, c);
+			if (++l >= k) {
+				uint64_t y[2]; int r;
+				orc_kmer_hash(k, p, y);
+				if ((r = orc_ch_get(ch, y)) >= 0) {
+					int high_end = (r >> 8 & 0x3f) >= min_occ + 1;
+					if (high_end) out[i] |= 1u << 13;
+					if ((r & 0xff) >= min_occ) {
+						out[i] |= 1u << 12;
+						for (j = i - k + 1; j <= i; ++j) lc[j] = (lc[j] + 1) & 63, hc[j] = (hc[j] + high_end) & 63;
+					}
+				}
+			}
+		} else { l = 0; p[0] = p[1] = p[2] = p[3] = 0; }
+	}
+	for (i = 0; i < len; ++i) out[i] |= lc[i] | hc[i] << 6;
+	free(lc); free(hc);
+}

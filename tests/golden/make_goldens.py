@@ -122,10 +122,42 @@ def fixtures():
     return out, runs
 
 
+def kcov_goldens():
+    """bfc_ec_kcov of the reference (correct.c:96-117, reached through oracle/ref_shim_ec.c) on every read of g1 against the
+    table the reference binary dumped: digest + sums of the packed u16 stream (lcov | hcov<<6 | solid_end<<12 | high_end<<13)."""
+    R = oracle.ref_ec()
+    ref = os.path.join(oracle.REF_DIR, "bfc-ref")
+    rs = gen.fixture("g1")
+    seq, qual, off = rs.reads()
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        fq = os.path.join(d, "g1.fq")
+        rs.fastq(fq)
+        for k, b, min_occ in ((31, 26, 3), (31, 26, 1), (51, 26, 3), (63, 28, 2), (21, 22, 3)):
+            dump = os.path.join(d, "t.hash")
+            subprocess.run([ref, "-E", "-k", str(k), "-b", str(b), "-t", "1", "-d", dump, fq], check=True, capture_output=True)
+            ch = R.bfc_ch_restore(dump.encode())
+            vals = np.zeros(int(off[-1]), dtype=np.uint16)
+            for r in range(rs.n_reads):
+                a, e = int(off[r]), int(off[r + 1])
+                buf = np.zeros(e - a, dtype=np.uint16)
+                R.ref_kcov(ch, k, min_occ, 20, seq[a:e].tobytes(), None, buf.ctypes.data)
+                vals[a:e] = buf
+            R.bfc_ch_destroy(ch)
+            e = dict(fixture="g1", k=k, b=b, min_occ=min_occ, md5=hashlib.md5(vals.tobytes()).hexdigest(),
+                     sum_lcov=int((vals & 0x3f).sum()), sum_hcov=int((vals >> 6 & 0x3f).sum()),
+                     n_solid_end=int((vals >> 12 & 1).sum()), n_high_end=int((vals >> 13 & 1).sum()),
+                     read0_head=[int(v) for v in vals[:int(off[1])][:48]])
+            print(e, file=sys.stderr)
+            out.append(e)
+    return out
+
+
 if __name__ == "__main__":
     assert oracle.have_ref(), "build oracle/_ref first (make -C oracle)"
     k = kat_bloom_and_key(kat())
     json.dump(k, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
     fx, runs = fixtures()
-    json.dump(dict(fixtures=fx, binary_runs=runs), open(os.path.join(HERE, "fixtures.json"), "w"), indent=1)
+    kc = kcov_goldens()
+    json.dump(dict(fixtures=fx, binary_runs=runs, kcov=kc), open(os.path.join(HERE, "fixtures.json"), "w"), indent=1)
     print("wrote kat.json (%d), fixtures.json (%d)" % (len(k), len(fx)))
