@@ -46,6 +46,7 @@ struct bfcg_ctx {
 	int n_ranks, rank, log2n;
 	uint32_t *d_seg, *h_seg;     // multi-GPU: seg_beg | seg_end | row_base | bucket_start (device / pinned host)
 	uint64_t recv_cap;           // records the level-2 buffers can take
+	uint64_t keys_last, grow[2]; // distinct keys at the last finalised batch; keys added by the last two batches (growth forecast)
 };
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
@@ -156,13 +157,18 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
 	if (P.track) { HIPCKN(hipMalloc(&B.tab_first, 8ULL << (P.l_pre + P.tab_cshift))); HIPCKN(hipMalloc(&B.sub_last, 8ULL << P.l_pre)); }
 	HIPCKN(hipMalloc(&B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1))); // last row: unslotted words
-	B.tab_ovf_cap = 1u << 20;
+	// parked k-mers of a batch that outruns the table (the host grows it and replays them): a batch cannot create more keys than
+	// half its k-mers, bloom false positives aside
+	{ uint64_t cap = prm->max_batch_pos / 2; if (cap < (1u << 20)) cap = 1u << 20; if (cap > (1u << 28)) cap = 1u << 28; B.tab_ovf_cap = (uint32_t)cap; }
 	HIPCKN(hipMalloc(&B.tab_ovf, (uint64_t)B.tab_ovf_cap * 40));
-	// global first-setter pool for regions whose LDS table overflows: worst case every bucket overflows
-	// with cap = pow2 >= 2*n_hashes*n  =>  <= 4*n_hashes*max_kmers entries (+1024 per bucket)
-	B.pool_cap = 4ULL * P.n_hashes * B.max_kmers + 1024ULL * nfine;
-	if (B.pool_cap > (1ULL << 31)) B.pool_cap = 1ULL << 31; // 16 GiB ceiling; exhaustion is reported, never silent
-	HIPCKN(hipMalloc(&B.pool, (B.pool_cap + 1) * 8));
+	// HBM first-setter pool for regions whose LDS tables overflow: 1024 slices (more than the workgroups resident at once) of
+	// 2 entries per region bit (the most a region can need), each behind a lock word -- no input can exhaust it
+	B.pool_slices = 1024;
+	{
+		const uint64_t pool_words = (uint64_t)B.pool_slices + (uint64_t)B.pool_slices * ((uint64_t)1024 << P.R);
+		HIPCKN(hipMalloc(&B.pool, pool_words * 8));
+		HIPCKN(hipMemset(B.pool, 0, (size_t)B.pool_slices * 8));
+	}
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
 	if (!getenv("BFCG_INLINE_COMMIT")) {
 		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
@@ -205,6 +211,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
 	HIPCK(hipStreamSynchronize(c->st)); // stage A of the next batch runs on another stream: the zeroing must have landed
 	c->n_batches = 0;
+	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
 	return 0;
 }
 
@@ -226,6 +233,7 @@ static int fetch_stats_on(bfcg_ctx_t *c, hipStream_t s)
 static int fetch_stats(bfcg_ctx_t *c) { return fetch_stats_on(c, c->st); }
 
 static int table_maintain(bfcg_ctx_t *c);
+static void note_growth(bfcg_ctx_t *c);
 
 static int batch_times(bfcg_ctx_t *c, int b)
 {
@@ -251,24 +259,45 @@ static int drain(bfcg_ctx_t *c)
 	c->pend = 0;
 	if (batch_times(c, c->cur ^ 1) != 0) return -1;
 	if (fetch_stats(c) != 0) return -1;
+	note_growth(c);
 	return check_health(c);
 }
 
 extern "C" int bfcg_sync(bfcg_ctx_t *c) { return drain(c); }
 
-// grow the table by one doubling and replay parked k-mers until none is left
+// keys the next batch is expected to add: the smaller of the last two batches' additions (one batch alone says nothing:
+// the first batch of a high-coverage read set brings nearly all keys, the following ones almost none)
+static uint64_t growth_forecast(const bfcg_ctx_t *c) { return c->grow[0] < c->grow[1] ? c->grow[0] : c->grow[1]; }
+static void note_growth(bfcg_ctx_t *c)
+{
+	const uint64_t keys = c->h_stats[ST_KEYS];
+	c->grow[1] = c->grow[0]; c->grow[0] = keys > c->keys_last ? keys - c->keys_last : 0; c->keys_last = keys;
+}
+// sub-table size the table should have now: load <= 1/2 counting parked k-mers and the forecast
+static int table_target_cshift(const bfcg_ctx_t *c)
+{
+	const KParams &P = c->P;
+	const uint64_t need = c->h_stats[ST_KEYS] + c->h_stats[ST_TAB_OVF], g = growth_forecast(c);
+	int t = P.tab_cshift;
+	if ((need + g) * 2 > (1ULL << (P.l_pre + t)))
+		while ((need + 2 * g) * 2 > (1ULL << (P.l_pre + t)) && P.l_pre + t < 36) ++t;
+	if (c->h_stats[ST_TAB_OVF] && t == P.tab_cshift) ++t; // a full sub-table under a low overall load
+	return t;
+}
+
+// grow the table (any number of doublings in one rehash) and replay parked k-mers until none is left
 static int table_maintain(bfcg_ctx_t *c)
 {
 	KParams &P = c->P; BatchBufs &B = c->B;
 	for (;;) {
-		uint64_t slots = 1ULL << (P.l_pre + P.tab_cshift);
-		uint64_t ovf = c->h_stats[ST_TAB_OVF], keys = c->h_stats[ST_KEYS];
-		if (ovf == 0 && keys * 2 <= slots) return 0;
+		const uint64_t ovf = c->h_stats[ST_TAB_OVF];
+		const int target = table_target_cshift(c);
+		if (ovf == 0 && target == P.tab_cshift) return 0;
 		if (ovf > B.tab_ovf_cap) return set_err("count table overflow list exhausted (%llu parked k-mers)", (unsigned long long)ovf);
-		if (P.l_pre + P.tab_cshift + 1 > 36) return set_err("count table cannot grow beyond 2^36 slots");
+		if (P.l_pre + target > 36) return set_err("count table cannot grow beyond 2^36 slots");
 		int old_cshift = P.tab_cshift;
 		unsigned long long *nt = 0;
-		P.tab_cshift = old_cshift + 1;
+		P.tab_cshift = target;
 		unsigned long long *nf = 0;
 		HIPCK(hipMalloc(&nt, 8ULL << (P.l_pre + P.tab_cshift)));
 		HIPCK(hipMemsetAsync(nt, 0, 8ULL << (P.l_pre + P.tab_cshift), c->st));
@@ -296,6 +325,7 @@ static int finish_batch(bfcg_ctx_t *c) // synchronous batches (multi-GPU stages)
 	if (fetch_stats(c) != 0) return -1;
 	++c->n_batches;
 	if (batch_times(c, 0) != 0) return -1;
+	note_growth(c);
 	return check_health(c);
 }
 
@@ -355,7 +385,6 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
 	HIPCK(hipEventRecord(c->evt[0][6], c->st));
 	HIPCK(hipMemcpyAsync(c->d_seg, c->h_seg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
 	const uint32_t *d = c->d_seg;
 	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
@@ -377,7 +406,6 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	HIPCK(hipEventRecord(c->evA[b], c->stA));
 	HIPCK(hipStreamWaitEvent(c->st, c->evA[b], 0));
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
-	HIPCK(hipMemsetAsync(c->B.pool, 0, 8, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
 	run_stage_b(c->P, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
 	HIPCK(hipEventRecord(c->evB[b], c->st));
@@ -390,8 +418,8 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 		HIPCK(hipEventSynchronize(c->evB[pb]));
 		if (batch_times(c, pb) != 0) return -1;
 		if (fetch_stats_on(c, c->stC) != 0) return -1; // counters may already include part of the running batch: fine for the checks below
-		const uint64_t slots = 1ULL << (c->P.l_pre + c->P.tab_cshift);
-		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->B.table && c->h_stats[ST_KEYS] * 2 > slots)) {
+		note_growth(c);
+		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->B.table && table_target_cshift(c) != c->P.tab_cshift)) {
 			c->pend = 1; c->cur = b ^ 1; // make drain() see the batch just enqueued
 			return drain(c);
 		}

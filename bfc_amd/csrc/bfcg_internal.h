@@ -37,7 +37,7 @@ struct BatchBufs {
 	unsigned long long *bloom, *bloom_hi, *table;
 	unsigned long long *stats;
 	uint64_t *tab_ovf; uint32_t tab_ovf_cap;
-	unsigned long long *pool; unsigned long long pool_cap;
+	unsigned long long *pool; uint32_t pool_slices; // slow-path first-setter pool (locked slices, see k_bloom)
 	uint8_t *seen_out;
 	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
 	unsigned long long *tab_first, *sub_last; // order stamps (NULL unless KParams.track)

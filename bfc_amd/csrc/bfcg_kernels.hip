@@ -644,7 +644,7 @@ struct BloomArgs {
 	unsigned long long *table;     // count table or NULL
 	unsigned long long *stats;
 	uint64_t *tab_ovf; uint32_t tab_ovf_cap; unsigned long long *ovf_cnt;
-	unsigned long long *pool; unsigned long long pool_cap; // global first-setter pool (entries)
+	unsigned long long *pool; uint32_t pool_slices;        // slow-path first-setter pool: pool_slices lock words, then pool_slices slices of 2^(R+10) entries
 	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
 	uint64_t *agg_out;             // aggregated seen k-mers: three planes [y0 | y1 | count|high<<16] of [n_fine][ag_cap], or NULL = commit inline
 	uint32_t *agg_cnt;             // entries per fine bucket
@@ -754,6 +754,24 @@ __device__ __forceinline__ bool fs32_insert(unsigned int *fs, uint32_t mask, uin
 	}
 	return false;
 }
+// a k-mer that touches a bit which HAS an entry competes for it (no entry is created: the bit is uncontended)
+__device__ __forceinline__ void fs32_compete(unsigned int *fs, uint32_t mask, uint32_t bitoff, uint32_t li, uint32_t idx, const unsigned int *list_idx)
+{
+	const uint32_t e = (bitoff << 13) | li;
+	uint32_t p = fs32_slot(bitoff, mask);
+	for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
+		uint32_t cur = fs[p];
+		if (cur == FS32_EMPTY) return;
+		if ((cur >> 13) == bitoff) {
+			while (list_idx[cur & 0x1fffu] > idx) {
+				uint32_t old = atomicCAS(&fs[p], cur, e);
+				if (old == cur) break;
+				cur = old;
+			}
+			return;
+		}
+	}
+}
 // list index of the first setter of a bit, or FS32_EMPTY if the bit has no entry
 __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t mask, uint32_t bitoff)
 {
@@ -782,7 +800,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 {
 	if (P.ablate & 8) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_seen, s_agg_n, s_pad[3];
+	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_seen, s_agg_n, s_fs_used, s_pad[2];
 	const uint32_t f = blockIdx.x;
 	const uint32_t rs = A.start[f], n = A.start[f + 1] - rs;
 	if (n == 0) { if (threadIdx.x == 0 && A.agg_cnt) A.agg_cnt[f] = 0; return; }
@@ -831,7 +849,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0;
 			if (TRACK) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
 		}
-		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = 0; }
+		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = 0; s_fs_used = 0; }
 	}
 	__syncthreads();
 	if (timing) tq[1] = clock64();
@@ -896,8 +914,9 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	if (timing) tq[2] = clock64();
 	const uint32_t ln = s_list_n;
 	if (ln > P.list_cap || ln > 8191 || n >= (1u << 20)) s_ovf = 1; // benign race: every writer stores 1
-	// ---- pass 1.5: dense over the list -- enter every clear bit into the first-setter table.
-	// A thread keeps the records of its first LK list entries in registers for pass 2.
+	// ---- pass A (dense over the list): set every clear bit.  The returning atomicOr tells whether another k-mer of this
+	// batch got there first: only such CONTENDED bits need a first-setter entry (file order decides them); a bit only one k-mer
+	// touches is trivially set first by that k-mer.  A thread keeps the records of its first LK list entries in registers.
 	constexpr int LK = 2;
 	RecW<RW> lw[LK];
 	if (!*v_ovf) {
@@ -920,7 +939,14 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			for (int j = 0; j < (NH ? NH : 12); ++j) {
 				if (j >= nh) break;
 				uint32_t b = bloom_next(z, r.h2);
-				if (((um >> j) & 1u) && !fs32_insert(fs, fs_mask, r.bl * 512 + b, li, r.idx, list_a)) *v_ovf = 1;
+				if ((um >> j) & 1u) {
+					const uint32_t bit = 1u << (b & 31);
+					const uint32_t old = atomicOr(&region[r.bl * 16 + (b >> 5)], bit);
+					if (old & bit) { // contended
+						*(volatile uint32_t *)&s_fs_used = 1;
+						if (!fs32_insert(fs, fs_mask, r.bl * 512 + b, li, r.idx, list_a)) *v_ovf = 1;
+					}
+				}
 			}
 		}
 	}
@@ -929,21 +955,42 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 
 	bool dirty = true;
 	if (!s_ovf) {
-		// ---- pass 2: dense over the list -- seen iff an earlier k-mer of the batch sets each clear bit; set the bits
+		// ---- pass B: the k-mer that set a contended bit first IN EXECUTION ORDER has not entered the competition yet:
+		// every toucher of a bit that has an entry competes for it (earliest in file order wins)
+		if (s_fs_used) {
+			for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
+				RecW<RW> w;
+				if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
+				else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
+				KRec r = decode_rec<W, RW>(P, w, m, rmask);
+				const uint32_t um = list_b[li] >> 20;
+				uint32_t z = r.h1;
+#pragma unroll
+				for (int j = 0; j < (NH ? NH : 12); ++j) {
+					if (j >= nh) break;
+					uint32_t b = bloom_next(z, r.h2);
+					if ((um >> j) & 1u) fs32_compete(fs, fs_mask, r.bl * 512 + b, li, r.idx, list_a);
+				}
+			}
+			__syncthreads();
+		}
+		// ---- pass C: seen iff an earlier k-mer of the batch is the first setter of each of its clear bits
 		for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
 			RecW<RW> w;
 			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
 			KRec r = decode_rec<W, RW>(P, w, m, rmask);
 			const uint32_t um = list_b[li] >> 20;
-			uint32_t z = r.h1; bool first = false;
+			uint32_t z = r.h1; bool first = !s_fs_used;
+			if (!first) {
 #pragma unroll
-			for (int j = 0; j < (NH ? NH : 12); ++j) {
-				if (j >= nh) break;
-				uint32_t b = bloom_next(z, r.h2);
-				if ((um >> j) & 1u) {
-					first |= fs32_lookup(fs, fs_mask, r.bl * 512 + b) == li;
-					atomicOr(&region[r.bl * 16 + (b >> 5)], 1u << (b & 31));
+				for (int j = 0; j < (NH ? NH : 12); ++j) {
+					if (j >= nh) break;
+					uint32_t b = bloom_next(z, r.h2);
+					if ((um >> j) & 1u) {
+						const uint32_t h = fs32_lookup(fs, fs_mask, r.bl * 512 + b);
+						first |= (h == FS32_EMPTY) | (h == li); // uncontended, or this k-mer won
+					}
 				}
 			}
 			if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
@@ -952,20 +999,26 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		dirty = ln != 0;
 		__syncthreads();
 	} else {
-		// ---- slow path: first-setter table in HBM (slice of the pool), sized by the region's bit count
+		// ---- slow path: first-setter table in HBM.  The pool is A.pool_slices slices (a power of two, more than the workgroups
+		// that can be resident at once) of 2 entries per bit of a region -- the most a region can ever need -- each guarded by a
+		// lock word: a workgroup takes any free slice, so the path cannot run out of memory whatever the input.
 		uint64_t want = (uint64_t)n * nh * 2;
-		uint64_t lim = (uint64_t)region_blocks * 512 * 2;
+		const uint64_t lim = (uint64_t)region_blocks * 512 * 2;
 		if (want > lim) want = lim;
 		uint32_t cap = 1024; while (cap < want) cap <<= 1;
 		if (threadIdx.x == 0) {
-			unsigned long long off = atomicAdd(&A.pool[0], (unsigned long long)cap); // pool[0] is the bump cursor; entries start at pool[1]
-			if (off + cap > A.pool_cap) { atomicAdd(&A.stats[ST_ERR_POOL], 1ULL); s_pool_off = 0xffffffffu; }
-			else s_pool_off = (uint32_t)(off >> 10);
+			uint32_t sl = f & (A.pool_slices - 1);
+			while (atomicCAS(&A.pool[sl], 0ULL, 1ULL) != 0ULL) sl = (sl + 1) & (A.pool_slices - 1);
+			s_pool_off = sl;
 			atomicAdd(&A.stats[ST_SLOW_BUCKETS], 1ULL);
 		}
+		{ // pass A may have set bits already: start again from the pre-batch region
+			const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
+			uint4 *dst = reinterpret_cast<uint4 *>(region);
+			for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
+		}
 		__syncthreads();
-		if (s_pool_off == 0xffffffffu) return; // batch abandoned: the host sees ST_ERR_POOL and aborts
-		unsigned long long *gfs = A.pool + 1 + ((uint64_t)s_pool_off << 10);
+		unsigned long long *gfs = A.pool + A.pool_slices + (uint64_t)s_pool_off * lim;
 		for (uint32_t i = threadIdx.x; i < cap; i += BT) gfs[i] = FS_EMPTY;
 		__threadfence();
 		__syncthreads();
@@ -996,6 +1049,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			}
 		}
 		__syncthreads();
+		if (threadIdx.x == 0) { __threadfence(); atomicExch(&A.pool[s_pool_off], 0ULL); } // release the slice
 	}
 	if (timing) tq[3] = clock64();
 	if (dirty) { // write the region back
@@ -1269,7 +1323,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	if (ev) hipEventRecord(ev[3], st);
 	BloomArgs A;
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
-	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_cap = B.pool_cap; A.seen_out = B.seen_out;
+	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_slices = B.pool_slices; A.seen_out = B.seen_out;
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
