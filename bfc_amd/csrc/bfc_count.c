@@ -81,7 +81,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	void *ret;
 	const char *env;
 	double t0 = (&bfc_real_time && bfc_real_time > 0.) ? bfc_real_time : now_real();
-	uint64_t cap;
+	uint64_t cap, bases;
 	int i, cur = 0;
 	uint64_t st[BFCG_ST_N];
 
@@ -93,8 +93,13 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	/* a batch holds one reference chunk (opt->chunk_size bases, bfc.c:20,-L) plus separators;
 	 * BFC_GPU_BATCH overrides the number of positions per GPU batch */
 	cap = (uint64_t)(opt->chunk_size > 0 ? opt->chunk_size : 100000000);
+	/* a batch streams the whole bitmap through the CUs once, and a 16 KiB region handles ~1000 k-mers per batch at full speed:
+	 * batches grow with the filter (x4 for -b35, x16 for -b37 as `-s 3g` sets it); batch boundaries never change results */
+	if (opt->bf_shift > 33) cap <<= opt->bf_shift - 33;
 	if ((env = getenv("BFC_GPU_BATCH")) != 0) cap = strtoull(env, 0, 10);
 	if (cap < (1u << 16)) cap = 1u << 16;
+	if (cap > (1ULL << 32) - (1ULL << 27)) cap = (1ULL << 32) - (1ULL << 27);
+	bases = cap;
 	cap += cap / 64 + (1u << 20);
 	if (cap >= (1ULL << 32)) cap = (1ULL << 32) - 1;
 	prm.max_batch_pos = cap;
@@ -102,8 +107,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	if (ctx == 0) { fprintf(stderr, "[E::%s] cannot set up the GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
 
 	memset(&ps, 0, sizeof(ps));
-	ps.chunk_size = (uint64_t)(opt->chunk_size > 0 ? opt->chunk_size : 100000000);
-	if (ps.chunk_size > cap - cap / 32) ps.chunk_size = cap - cap / 32;
+	ps.chunk_size = bases;
 	ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
 	if (ps.rd.fp == 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
 	gzbuffer(ps.rd.fp, 1 << 18);
