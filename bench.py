@@ -124,6 +124,10 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    # stdout carries exactly ONE line, the JSON: libraries that print there (RCCL's version banner at communicator creation) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     use_dist = world > 1 or bool(os.environ.get("BFC_BENCH_FORCE_DIST"))
     dist = None
     if use_dist:
@@ -277,7 +281,7 @@ def main():
                 log("[bench] cpu_baseline failed:", e)
                 cb = None
             res["cpu_baseline"] = cb
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     g.dev_free(d_seq); g.dev_free(d_qual); g.close()
     if dist:
         dist.barrier()

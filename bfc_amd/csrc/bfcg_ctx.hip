@@ -44,7 +44,8 @@ struct bfcg_ctx {
 	int rw;                      // bytes per record: 12 (k <= 31), 16 (k <= 47), 24
 	uint64_t bloom_bytes;        // bytes of the bloom slice this rank owns
 	int n_ranks, rank, log2n;
-	uint32_t *d_seg, *h_seg;     // multi-GPU: seg_beg | seg_end | row_base | bucket_start (device / pinned host)
+	uint32_t *d_seg, *h_seg;     // multi-GPU: seg_beg | seg_end | row_base | bucket_start (device / pinned host), one set per in-flight batch
+	size_t seg_words;
 	uint64_t recv_cap;           // records the level-2 buffers can take
 	uint64_t keys_last, grow[2]; // distinct keys at the last finalised batch; keys added by the last two batches (growth forecast)
 };
@@ -151,7 +152,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], B.max_kmers * c->rw));
 	B.recs1 = c->recs1[0];
 	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw));
-	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * (4 * nb1 + 8))); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * (4 * nb1 + 8))); }
+	c->seg_words = (size_t)4 * nb1 + 8;
+	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * 2 * c->seg_words)); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * 2 * c->seg_words)); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
 	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
@@ -234,6 +236,8 @@ static int fetch_stats(bfcg_ctx_t *c) { return fetch_stats_on(c, c->st); }
 
 static int table_maintain(bfcg_ctx_t *c);
 static void note_growth(bfcg_ctx_t *c);
+static int finalise_previous(bfcg_ctx_t *c, int b);
+static int table_target_cshift(const bfcg_ctx_t *c);
 
 static int batch_times(bfcg_ctx_t *c, int b)
 {
@@ -319,16 +323,6 @@ static int table_maintain(bfcg_ctx_t *c)
 	}
 }
 
-static int finish_batch(bfcg_ctx_t *c) // synchronous batches (multi-GPU stages) on stream st with event set 0
-{
-	HIPCK(hipGetLastError());
-	if (fetch_stats(c) != 0) return -1;
-	++c->n_batches;
-	if (batch_times(c, 0) != 0) return -1;
-	note_growth(c);
-	return check_health(c);
-}
-
 // ---- multi-GPU (owner computes): stage A on every rank, exchange by the caller, stage B on the owner
 
 extern "C" int bfcg_mg_info(bfcg_ctx_t *c, int out[4])
@@ -337,59 +331,84 @@ extern "C" int bfcg_mg_info(bfcg_ctx_t *c, int out[4])
 	return 0;
 }
 
+// Stage A of a global batch on stream stA: it runs UNDER stage B of the previous batch (stream st), which bfcg_mg_process left
+// running.  Returns when the records are in d_send and their per-bucket counts on the host; the caller may start the exchange.
 extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts)
 {
-	const int nb1 = 1 << c->P.F1;
+	const int nb1 = 1 << c->P.F1, b = c->cur;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
 	if (n_pos == 0) { // nothing to contribute to this global batch: keep the timing events defined
-		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[0][i], c->st));
+		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], c->stA));
 		memset(counts, 0, sizeof(uint32_t) * nb1); return 0;
 	}
-	if (drain(c) != 0) return -1;
-	run_stage_a(c->P, c->B, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->st, c->evt[0]);
+	BatchBufs Bt = c->B;
+	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1;
+	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
 	HIPCK(hipGetLastError());
-	uint32_t *h = (uint32_t *)(c->h_stats + ST_N * (ST_SLOTS + 1)); // pinned scratch behind the statistics mirror
-	(void)h;
 	uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (nb1 + 1));
-	hipError_t e = hipMemcpyAsync(tmp, c->B.start1, sizeof(uint32_t) * (nb1 + 1), hipMemcpyDeviceToHost, c->st);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+	hipError_t e = hipMemcpyAsync(tmp, Bt.start1, sizeof(uint32_t) * (nb1 + 1), hipMemcpyDeviceToHost, c->stA);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stA);
 	if (e != hipSuccess) { free(tmp); return set_err("reading the level-1 bucket starts failed: %s", hipGetErrorString(e)); }
-	for (int b = 0; b < nb1; ++b) counts[b] = tmp[b + 1] - tmp[b];
+	for (int i = 0; i < nb1; ++i) counts[i] = tmp[i + 1] - tmp[i];
 	free(tmp);
 	return 0;
 }
 
 // d_recv: records for the owned level-1 buckets, source-major (rank 0's block, rank 1's block, ...), inside each block
-// grouped by bucket; seg_cnt[s * nb_loc + b] = records from source s for owned bucket b
+// grouped by bucket; seg_cnt[s * nb_loc + b] = records from source s for owned bucket b.
+// Stage B is ENQUEUED (stream st) and left running: the call returns once the PREVIOUS batch is finalised (statistics read,
+// table maintained), so the caller's next bfcg_mg_scatter and exchange overlap with it.  d_recv must stay untouched until the
+// next bfcg_mg_process (or bfcg_sync) returns: callers alternate between two receive buffers.
 extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt)
 {
-	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, n_seg = nb_loc * N;
+	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, n_seg = nb_loc * N, b = c->cur;
 	HIPCK(hipSetDevice(c->prm.device));
-	if (drain(c) != 0) return -1;
-	uint32_t *seg_beg = c->h_seg, *seg_end = seg_beg + n_seg, *row_base = seg_end + n_seg, *bucket_start = row_base + n_seg + 1;
+	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
+	uint32_t *seg_beg = c->h_seg + (size_t)b * c->seg_words, *seg_end = seg_beg + n_seg, *row_base = seg_end + n_seg, *bucket_start = row_base + n_seg + 1;
 	uint64_t off = 0, rows = 0, tot = 0;
 	for (int s = 0; s < N; ++s)
-		for (int b = 0; b < nb_loc; ++b) { // position of (source s, bucket b) in the receive buffer
-			int seg = b * N + s;
-			seg_beg[seg] = (uint32_t)off; off += seg_cnt[s * nb_loc + b]; seg_end[seg] = (uint32_t)off;
+		for (int k = 0; k < nb_loc; ++k) { // position of (source s, bucket k) in the receive buffer
+			int seg = k * N + s;
+			seg_beg[seg] = (uint32_t)off; off += seg_cnt[s * nb_loc + k]; seg_end[seg] = (uint32_t)off;
 		}
 	if (off > c->recv_cap) return set_err("received %llu records for this rank's buckets, capacity %llu", (unsigned long long)off, (unsigned long long)c->recv_cap);
 	for (int seg = 0; seg < n_seg; ++seg) { row_base[seg] = (uint32_t)rows; rows += (seg_end[seg] - seg_beg[seg] + BFCG_TILE2 - 1) / BFCG_TILE2; }
 	row_base[n_seg] = (uint32_t)rows;
-	for (int b = 0; b < nb_loc; ++b) {
-		bucket_start[b] = (uint32_t)tot;
-		for (int s = 0; s < N; ++s) tot += seg_cnt[s * nb_loc + b];
+	for (int k = 0; k < nb_loc; ++k) {
+		bucket_start[k] = (uint32_t)tot;
+		for (int s = 0; s < N; ++s) tot += seg_cnt[s * nb_loc + k];
 	}
 	bucket_start[nb_loc] = (uint32_t)tot;
-	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
-	HIPCK(hipEventRecord(c->evt[0][6], c->st));
-	HIPCK(hipMemcpyAsync(c->d_seg, c->h_seg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
+	uint32_t *d = c->d_seg + (size_t)b * c->seg_words;
+	HIPCK(hipEventRecord(c->evt[b][6], c->st));
+	HIPCK(hipMemcpyAsync(d, seg_beg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
-	const uint32_t *d = c->d_seg;
 	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
-	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[0]);
-	return finish_batch(c);
+	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	HIPCK(hipEventRecord(c->evB[b], c->st));
+	HIPCK(hipGetLastError());
+	c->used[b] = 1;
+	++c->n_batches;
+	return finalise_previous(c, b);
+}
+
+// batch b has just been enqueued: finalise the one before it while b runs
+static int finalise_previous(bfcg_ctx_t *c, int b)
+{
+	if (c->pend) {
+		const int pb = b ^ 1;
+		HIPCK(hipEventSynchronize(c->evB[pb]));
+		if (batch_times(c, pb) != 0) return -1;
+		if (fetch_stats_on(c, c->stC) != 0) return -1; // counters may already include part of the running batch: fine for the checks below
+		note_growth(c);
+		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->B.table && table_target_cshift(c) != c->P.tab_cshift)) {
+			c->pend = 1; c->cur = b ^ 1; // make drain() see the batch just enqueued
+			return drain(c);
+		}
+	}
+	c->pend = 1; c->cur = b ^ 1;
+	return 0;
 }
 
 // One batch, software-pipelined over two streams: stage A of this batch (ALU-bound K1) is enqueued on stA and runs
@@ -412,20 +431,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	HIPCK(hipGetLastError());
 	c->used[b] = 1;
 	++c->n_batches;
-	// finalise the previous batch while this one runs
-	if (c->pend) {
-		const int pb = b ^ 1;
-		HIPCK(hipEventSynchronize(c->evB[pb]));
-		if (batch_times(c, pb) != 0) return -1;
-		if (fetch_stats_on(c, c->stC) != 0) return -1; // counters may already include part of the running batch: fine for the checks below
-		note_growth(c);
-		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->B.table && table_target_cshift(c) != c->P.tab_cshift)) {
-			c->pend = 1; c->cur = b ^ 1; // make drain() see the batch just enqueued
-			return drain(c);
-		}
-	}
-	c->pend = 1; c->cur = b ^ 1;
-	return 0;
+	return finalise_previous(c, b);
 }
 
 extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
@@ -463,9 +469,9 @@ extern "C" void *bfcg_dev_alloc(bfcg_ctx_t *c, uint64_t bytes)
 }
 extern "C" void bfcg_dev_free(bfcg_ctx_t *c, void *p) { (void)c; (void)hipFree(p); }
 extern "C" int bfcg_h2d(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes)
-{ HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->st)); HIPCK(hipStreamSynchronize(c->st)); return 0; }
+{ HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stC)); HIPCK(hipStreamSynchronize(c->stC)); return 0; }
 extern "C" int bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes)
-{ HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->st)); HIPCK(hipStreamSynchronize(c->st)); return 0; }
+{ HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stC)); HIPCK(hipStreamSynchronize(c->stC)); return 0; }
 
 extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
 {

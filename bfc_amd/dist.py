@@ -76,19 +76,27 @@ class GpuEngine:
         cap = int(counter.params.max_batch_pos)
         dev = torch.device("cuda", counter.params.device)
         self.send = torch.empty(cap * self.rec_words, dtype=torch.int32, device=dev)
-        self.recv = torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int32, device=dev)
+        # two receive buffers: stage B of batch t is left running on buffer t % 2 while batch t + 1 is scattered and exchanged
+        self._recv = [torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._cur = 0
+
+    @property
+    def recv(self):
+        return self._recv[self._cur]
 
     def scatter(self, d_seq, d_qual, n_pos):
         return self.g.mg_scatter(d_seq, d_qual, n_pos, self.send.data_ptr())  # synchronises the library's stream
 
     def process(self, seg_cnt):
         import torch
-        torch.cuda.synchronize(self.send.device)  # the all-to-all ran on torch's stream
-        self.g.mg_process(self.recv.data_ptr(), seg_cnt)
+        torch.cuda.current_stream(self.send.device).synchronize()  # the exchange ran on torch's stream; stage B of the previous batch keeps running
+        self.g.mg_process(self.recv.data_ptr(), seg_cnt)  # returns once the previous batch is finalised: its receive buffer is free again
+        self._cur ^= 1
 
 
 def count_batch(engine, d_seq, d_qual, n_pos, group=None):
-    """One global batch on this rank: stage A, exchange, stage B."""
+    """One global batch on this rank: stage A, exchange, stage B.  Stage B is left running (bfcg_mg_process): the next call's
+    stage A and exchange overlap with it; engine.g.sync() / stats() / exports drain the pipeline."""
     counts = engine.scatter(d_seq, d_qual, n_pos)
     seg_cnt = exchange(engine, counts, group)
     engine.process(seg_cnt)
@@ -106,7 +114,8 @@ class LocalCluster:
         self.rw, self.nb1, self.nb_loc = info["rec_bytes"] // 4, info["nb1"], info["nb_loc"]
         self.cap = max_batch_pos
         self.d_send = [c.dev_alloc(self.cap * self.rw * 4) for c in self.ctx]
-        self.d_recv = [c.dev_alloc((self.cap * 2 + 4096) * self.rw * 4) for c in self.ctx]
+        self.d_recv = [[c.dev_alloc((self.cap * 2 + 4096) * self.rw * 4) for _ in range(2)] for c in self.ctx]  # alternate: stage B runs asynchronously
+        self.t = 0
 
     def batch(self, shares):
         """shares[r] = (seq_stream, qual_stream or None) of rank r for this global batch."""
@@ -136,9 +145,11 @@ class LocalCluster:
                 parts.append(sends[s_][lo * self.rw:hi * self.rw])
                 seg[s_] = counts[s_][o * self.nb_loc:(o + 1) * self.nb_loc]
             recv = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
+            buf = self.d_recv[o][self.t & 1]
             if len(recv):
-                self.ctx[o].h2d(self.d_recv[o], recv)
-            self.ctx[o].mg_process(self.d_recv[o], seg)
+                self.ctx[o].h2d(buf, recv)
+            self.ctx[o].mg_process(buf, seg)
+        self.t += 1
 
     def bloom_bytes(self, which=0):
         return np.concatenate([c.bloom_bytes(which) for c in self.ctx])
@@ -170,4 +181,4 @@ class LocalCluster:
 
     def close(self):
         for c, a, b in zip(self.ctx, self.d_send, self.d_recv):
-            c.dev_free(a); c.dev_free(b); c.close()
+            c.sync(); c.dev_free(a); c.dev_free(b[0]); c.dev_free(b[1]); c.close()
