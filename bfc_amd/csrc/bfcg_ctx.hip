@@ -109,7 +109,9 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (region + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
 		// per k-mer with clear bits: one list entry (record + mask) and n_hashes first-setter entries at <= 50 % load
 		const size_t rwb = 8; // list entry: file-order index + (record index | mask)
-		size_t left = budget - region - (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + ((prm->track_order && !prm->filter_mode) ? 8 : 0)) - 16;
+		const size_t second = prm->filter_mode ? region : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (prm->track_order ? 8 : 0)); // second filter's slice, or the aggregation table
+		if (region + second + 12 * 1024 > budget) budget = 160 * 1024 - 1024;
+		size_t left = budget - region - second - 16;
 		uint32_t fs = 512; while ((size_t)(fs * 2) * 4 + (size_t)(fs * 2 / (2 * P.n_hashes)) * rwb <= left && fs < 32768) fs <<= 1;
 		if ((e = getenv("BFCG_FS")) != 0) fs = (uint32_t)atoi(e);
 		P.fs_cap = fs;
@@ -172,7 +174,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		HIPCKN(hipMemset(B.pool, 0, (size_t)B.pool_slices * 8));
 	}
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
-	if (!getenv("BFCG_INLINE_COMMIT")) {
+	if (!getenv("BFCG_INLINE_COMMIT") && !P.filter_mode) { // filter mode hands nothing over: both filters' slices are in LDS
 		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
 		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
 	}

@@ -795,7 +795,10 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 //  * the region goes back to HBM, the aggregated k-mers are streamed to k_commit (no returning atomics here).
 // Buckets whose list or first-setter table overflow take the HBM-pool path (exact, slow).
 // 512-thread workgroups run three per CU (LDS), i.e. 6 waves per SIMD: allow the registers that go with it (no scratch)
-template <typename W, int RW, int BT, int PF, int NH, bool TRACK>
+// FM (filter mode, `bfc -1`): the second bloom filter takes the k-mers seen before (count.c:67-68).  It is addressed by the same hash,
+// so its blocks for this region's k-mers are the same 2^R blocks: that slice sits in LDS next to the first filter's (instead of the
+// aggregation table) and a seen k-mer costs n_hashes LDS ORs -- no global atomics, no hand-over to k_commit.
+template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false>
 __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
@@ -811,19 +814,24 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	unsigned char *sp = smem;
 	unsigned int *region = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
 	AggView G;
-	G.id0 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8;
-	G.id1 = G.id0;
-	if (two) { G.id1 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8; }
-	G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 8;
-	G.imin = G.imax = nullptr;
-	if (TRACK) { G.imin = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; G.imax = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; }
-	G.mask = P.ag_cap - 1;
+	unsigned int *region_hi = nullptr;
+	if (FM) { region_hi = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4; G.id0 = G.id1 = nullptr; G.cnt = G.imin = G.imax = nullptr; G.mask = 0; }
+	else {
+		G.id0 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8;
+		G.id1 = G.id0;
+		if (two) { G.id1 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8; }
+		G.cnt = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 8;
+		G.imin = G.imax = nullptr;
+		if (TRACK) { G.imin = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; G.imax = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.ag_cap * 4; }
+		G.mask = P.ag_cap - 1;
+	}
 	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.fs_cap * 4;
 	unsigned int *list_a = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4; // file-order index of the k-mer
 	unsigned int *list_b = reinterpret_cast<unsigned int *>(sp);                                // record index in the bucket | clear-bit mask << 20
 	const uint32_t fs_mask = P.fs_cap - 1;
 	const uint32_t *recs = A.recs + (uint64_t)rs * RW;
 	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
+	unsigned int *g_region_hi = FM ? reinterpret_cast<unsigned int *>(A.bloom_hi) + (uint64_t)f * region_dw : nullptr;
 	const W m = kmask<W>(P.k);
 	const uint32_t rmask = region_blocks - 1;
 	const int nh = NH ? NH : P.n_hashes;
@@ -845,9 +853,15 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS32_EMPTY;
-		for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) {
-			G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0;
-			if (TRACK) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
+		if (FM) {
+			const uint4 *src2 = reinterpret_cast<const uint4 *>(g_region_hi);
+			uint4 *dst2 = reinterpret_cast<uint4 *>(region_hi);
+			for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst2[i] = src2[i];
+		} else {
+			for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) {
+				G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0;
+				if (TRACK) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
+			}
 		}
 		if (threadIdx.x == 0) { s_list_n = 0; s_seen = 0; s_agg_n = 0; s_ovf = 0; s_fs_used = 0; }
 	}
@@ -868,6 +882,18 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			um |= (((region[r.bl * 16 + (b >> 5)] >> (b & 31)) & 1u) ^ 1u) << j;
 		}
 		return um;
+	};
+	// what happens to a seen k-mer: into the second filter's LDS slice (FM) or the aggregation table / count table
+	auto emit = [&](const KRec &r) {
+		if constexpr (FM) {
+			uint32_t z = r.h1;
+#pragma unroll
+			for (int j = 0; j < (NH ? NH : 12); ++j) {
+				if (j >= nh) break;
+				uint32_t b = bloom_next(z, r.h2);
+				__hip_atomic_fetch_or(&region_hi[r.bl * 16 + (b >> 5)], 1u << (b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		} else emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx);
 	};
 	// append a k-mer with clear bits to the LDS list: one LDS atomic per wave
 	auto list_push = [&](bool want, uint32_t idx, uint32_t i, uint32_t um) {
@@ -898,7 +924,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			if (act[u] && um[u] == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
 				++n_seen;
 				if (A.seen_out) A.seen_out[r[u].idx] = 2;
-				emit_seen<W, TRACK>(P, A, G, r[u].y0, r[u].y1, r[u].hi, r[u].idx);
+				emit(r[u]);
 			}
 			list_push(act[u] && um[u] != 0, r[u].idx, base + threadIdx.x + u * BT, um[u]);
 		}
@@ -994,7 +1020,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 				}
 			}
 			if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-			if (!first) { ++n_seen; emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
+			if (!first) { ++n_seen; emit(r); }
 		}
 		dirty = ln != 0;
 		__syncthreads();
@@ -1045,7 +1071,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			}
 			if (unresolved) {
 				if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
-				if (!first) { ++n_seen; emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx); }
+				if (!first) { ++n_seen; emit(r); }
 			}
 		}
 		__syncthreads();
@@ -1058,8 +1084,14 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 	}
 	if (timing) tq[4] = clock64();
+	if (FM) { // the second filter's slice goes back whole (every workgroup of a batch sees some k-mer again, except in the first batches)
+		uint4 *dst = reinterpret_cast<uint4 *>(g_region_hi);
+		const uint4 *src = reinterpret_cast<const uint4 *>(region_hi);
+		if (__syncthreads_or(n_seen != 0))
+			for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
+	}
 	// ---- hand the aggregated k-mers over: compacted into this bucket's slice of agg_out (k_commit applies them)
-	for (uint32_t p0 = 0; p0 < P.ag_cap; p0 += BT) {
+	for (uint32_t p0 = 0; p0 < (FM ? 0u : P.ag_cap); p0 += BT) {
 		const uint32_t p = p0 + threadIdx.x;
 		unsigned long long a = p < P.ag_cap ? G.id0[p] : FS_EMPTY;
 		const bool used = a != FS_EMPTY;
@@ -1327,7 +1359,10 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
-	if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
+	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
+		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+	} else if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
 		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else if (P.n_hashes == 4) {
@@ -1364,7 +1399,8 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 
 int bloom_lds_bytes(const KParams &P)
 {
-	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)) + (size_t)P.list_cap * 8 + 16);
+	const size_t second = P.filter_mode ? ((size_t)64 << P.R) : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)); // second filter's slice or aggregation table
+	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + second + (size_t)P.list_cap * 8 + 16);
 }
 
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
@@ -1378,6 +1414,8 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 3, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }

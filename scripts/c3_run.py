@@ -21,6 +21,7 @@ ap.add_argument("--G", type=int, default=248_000_000)
 ap.add_argument("--cov", type=float, default=30.0)
 ap.add_argument("--seed", type=int, default=3)
 ap.add_argument("--batch-reads", default="4194304,8388608")
+ap.add_argument("--filter-mode", type=int, default=0, help="1: `bfc -1` count pass (two bloom filters, no table)")
 ap.add_argument("--digest", type=int, default=1, help="bring bloom + table to the host and compare across batch sizes")
 args = ap.parse_args()
 K = args.k
@@ -30,7 +31,7 @@ stride = rs.L + 1
 n_reads = rs.n_reads
 print("[c3] %d reads of %d bp, genome %d bp (%.1fs)" % (n_reads, rs.L, args.G, time.time() - t0), flush=True)
 sizes = [int(v) for v in args.batch_reads.split(",")]
-g = bfc_amd.GpuCounter(K, args.b, max_batch_pos=max(sizes) * stride)
+g = bfc_amd.GpuCounter(K, args.b, filter_mode=args.filter_mode, max_batch_pos=max(sizes) * stride)
 d_seq = g.dev_alloc(n_reads * stride); d_qual = g.dev_alloc(n_reads * stride)
 bad_tab = np.ones(256, dtype=bool); bad_tab[np.frombuffer(b"ACGTacgt", dtype=np.uint8)] = False
 n_kmers = 0
@@ -72,15 +73,21 @@ for br in sizes:
         res["bloom_popcount"] = int(oracle.lib().orc_popcount_bytes(bits.ctypes.data, len(bits)))
         res["bloom_fnv1a64"] = "%016x" % int(oracle.lib().orc_fnv1a64(bits.ctypes.data, len(bits)))
         del bits
-        t = g.export_table()
-        mode, cnt, high = t.hist()
-        assert t.count() == st["n_keys"]
-        res.update(hist_mode=int(mode), cnt_sat=int(cnt[255]), sum_i_cnt=int((np.arange(256, dtype=np.uint64) * cnt).sum()),
-                   cnt_head=[int(v) for v in cnt[1:6]], high_head=[int(v) for v in high[0:4]], hist_digest="%016x" % (hash((cnt.tobytes(), high.tobytes())) & (2**64 - 1)))
-        res["hist_bytes"] = (cnt.tobytes() + high.tobytes()).hex()
-        if res["cnt_sat"] == 0:
-            assert res["sum_i_cnt"] == st["n_seen"], (res["sum_i_cnt"], st["n_seen"])
-        t.close()
+        if args.filter_mode:
+            bits = g.bloom_bytes(1)
+            res["bloom_hi_popcount"] = int(oracle.lib().orc_popcount_bytes(bits.ctypes.data, len(bits)))
+            res["hist_bytes"] = "%016x" % int(oracle.lib().orc_fnv1a64(bits.ctypes.data, len(bits)))
+            del bits
+        else:
+            t = g.export_table()
+            mode, cnt, high = t.hist()
+            assert t.count() == st["n_keys"]
+            res.update(hist_mode=int(mode), cnt_sat=int(cnt[255]), sum_i_cnt=int((np.arange(256, dtype=np.uint64) * cnt).sum()),
+                       cnt_head=[int(v) for v in cnt[1:6]], high_head=[int(v) for v in high[0:4]], hist_digest="%016x" % (hash((cnt.tobytes(), high.tobytes())) & (2**64 - 1)))
+            res["hist_bytes"] = (cnt.tobytes() + high.tobytes()).hex()
+            if res["cnt_sat"] == 0:
+                assert res["sum_i_cnt"] == st["n_seen"], (res["sum_i_cnt"], st["n_seen"])
+            t.close()
         res["digest_s"] = round(time.time() - t2, 1)
     results.append(res)
     print(json.dumps({k_: v for k_, v in res.items() if k_ != "hist_bytes"}), flush=True)

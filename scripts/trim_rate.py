@@ -9,7 +9,7 @@ rs = gen.ReadSet(seed=2, G=4_600_000, cov=100)
 seq, qual, off = rs.reads()
 s_seq, s_qual = bfc_amd.to_stream(seq, off), bfc_amd.to_stream(qual, off)
 stride = rs.L + 1
-br = 786432
+br = 655360  # two bloom slices per region in LDS: ~1100 k-mers per region and batch
 g = bfc_amd.GpuCounter(k, b, filter_mode=1, max_batch_pos=br * stride)
 t0 = time.time()
 for r0 in range(0, rs.n_reads, br):
