@@ -239,3 +239,45 @@ def test_exact_dump_is_byte_identical(gpu_lib, g1, tmp_path, k, b, md5, n_batche
     assert t.dump(fn) == 0
     assert oracle.md5_file(fn) == md5
     g.close()
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_long_and_degenerate_reads(gpu_lib, k):
+    """Reads far longer than a kernel tile (4096 positions: every tile boundary cuts k-mers), empty reads (two separators in a row),
+    reads shorter than k, all-N reads, lower case, a read ending exactly on a tile boundary -- in several batches, vs the oracle."""
+    rng = np.random.default_rng(7 + k)
+    genome = rng.integers(0, 4, 60000)
+    lens = [0, 1, k - 1, k, 4096 - 1, 4096, 4097, 20011, 0, 0, 12288, 33333, 5, 0, 8191, 50000, 2 * k, 1, 0]
+    lens = lens + [int(v) for v in rng.integers(0, 9000, 30)]
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    seq = np.empty(int(off[-1]), dtype=np.uint8)
+    for r, n in enumerate(lens):
+        p = int(rng.integers(0, 60000 - n)) if n < 60000 else 0
+        seq[int(off[r]):int(off[r + 1])] = np.frombuffer(b"ACGT", dtype=np.uint8)[genome[p:p + n]]
+    seq[int(off[4]):int(off[5])][100:400] = ord("N")             # an N run inside a read
+    seq[int(off[10]):int(off[11])] = ord("N")                    # an all-N read of 12288 bases
+    seq[rng.integers(0, len(seq), 200)] = ord("N")
+    seq[rng.integers(0, len(seq), 500)] |= 0x20
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    # every read twice, so that k-mers are seen and the table fills
+    seq2, qual2 = np.concatenate([seq, seq]), np.concatenate([qual, qual])
+    off2 = np.concatenate([off, off[1:] + off[-1]])
+    oc = oracle.Counter(k, 24)
+    oc.count(seq2, qual2, off2)
+    n = len(off2) - 1
+    g = gpu_lib.GpuCounter(k, 24, max_batch_pos=len(seq2) + n + 64)
+    cuts = [0, 7, 8, 9, 25, n // 2, n]  # batches cut at read boundaries, some of them tiny
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        o = off2[a:e + 1] - off2[a]
+        s = gpu_lib.to_stream(seq2[int(off2[a]):int(off2[e])], o)
+        q = gpu_lib.to_stream(qual2[int(off2[a]):int(off2[e])], o)
+        g.count_host(s, q)
+    ost, st = oc.stats(), g.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert st["n_kmers"] > 300000 and st["n_seen"] > 100000
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.close(); oc.close()
