@@ -43,7 +43,7 @@ static double now_cpu(void)
 /* ------------------------------------------------------------------ reader thread, one batch ahead */
 
 typedef struct {
-	parser_t *ps;
+	ingest_t *ps;
 	batch_t b[2];
 	int ready[2];   /* filled and not yet consumed */
 	int done;
@@ -58,7 +58,7 @@ static void *reader_main(void *arg)
 		pthread_mutex_lock(&pp->mtx);
 		while (pp->ready[i]) pthread_cond_wait(&pp->cv, &pp->mtx);
 		pthread_mutex_unlock(&pp->mtx);
-		fill_batch(pp->ps, &pp->b[i]);
+		ingest_fill(pp->ps, &pp->b[i]);
 		pthread_mutex_lock(&pp->mtx);
 		pp->ready[i] = 1;
 		pthread_cond_broadcast(&pp->cv);
@@ -75,14 +75,15 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 {
 	bfcg_params_t prm;
 	bfcg_ctx_t *ctx;
-	parser_t ps;
+	ingest_t ps;
 	pipe_t pp;
 	pthread_t tid;
 	void *ret;
 	const char *env;
 	double t0 = (&bfc_real_time && bfc_real_time > 0.) ? bfc_real_time : now_real();
 	uint64_t cap, bases;
-	int i, cur = 0;
+	int i, cur = 0, io_threads, timing;
+	double tt, t_wait = 0, t_submit = 0;
 	uint64_t st[BFCG_ST_N];
 
 	bfcg_params_default(&prm);
@@ -103,15 +104,15 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	cap += cap / 64 + (1u << 20);
 	if (cap >= (1ULL << 32)) cap = (1ULL << 32) - 1;
 	prm.max_batch_pos = cap;
+	timing = getenv("BFC_GPU_TIMING") != 0; /* phase times on stderr */
+	tt = now_real();
 	ctx = bfcg_create(&prm);
+	if (timing) fprintf(stderr, "[T::bfc_count] GPU context (buffers for %llu positions per batch): %.3f s\n", (unsigned long long)cap, now_real() - tt);
 	if (ctx == 0) { fprintf(stderr, "[E::%s] cannot set up the GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
 
-	memset(&ps, 0, sizeof(ps));
-	ps.chunk_size = bases;
-	ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
-	if (ps.rd.fp == 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
-	gzbuffer(ps.rd.fp, 1 << 18);
-	ps.rd.buf = (uint8_t*)malloc(RD_BUF);
+	/* parser threads: -t (the count itself needs no host threads), BFC_GPU_IO_THREADS overrides; 0 = serial parser only */
+	io_threads = (env = getenv("BFC_GPU_IO_THREADS")) ? atoi(env) : opt->n_threads > 1 ? opt->n_threads : 0;
+	if (ingest_open(&ps, fn, bases, io_threads) != 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
 
 	memset(&pp, 0, sizeof(pp));
 	pp.ps = &ps;
@@ -121,16 +122,19 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap);
 		if (!pp.b[i].seq || !pp.b[i].qual) { fprintf(stderr, "[E::%s] cannot pin %llu bytes of host memory\n", __func__, (unsigned long long)cap); abort(); }
 	}
+	if (timing) fprintf(stderr, "[T::bfc_count] input opened (%s), pinned buffers: %.3f s\n", ps.fast.active ? "mapped, multi-threaded fast path" : "serial parser", now_real() - tt);
 	if (!opt->no_mt_io) pthread_create(&tid, 0, reader_main, &pp);
 
 	for (;;) {
 		batch_t *b = &pp.b[cur];
-		if (opt->no_mt_io) fill_batch(&ps, b);
+		tt = now_real();
+		if (opt->no_mt_io) ingest_fill(&ps, b);
 		else {
 			pthread_mutex_lock(&pp.mtx);
 			while (!pp.ready[cur]) pthread_cond_wait(&pp.cv, &pp.mtx);
 			pthread_mutex_unlock(&pp.mtx);
 		}
+		t_wait += now_real() - tt; tt = now_real();
 		if (b->n_seqs) {
 			double rt, eff;
 			fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs);
@@ -144,6 +148,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 			else
 				fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, b->n_seqs);
 		}
+		t_submit += now_real() - tt;
 		if (b->last) break;
 		if (!opt->no_mt_io) {
 			pthread_mutex_lock(&pp.mtx);
@@ -155,12 +160,41 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	}
 	if (!opt->no_mt_io) pthread_join(tid, 0);
 
+	tt = now_real();
 	ret = opt->filter_mode ? (void*)bfcg_export_bloom(ctx, 1) : (void*)bfcg_export_table(ctx);
+	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
 	for (i = 0; i < 2; ++i) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); }
 	pthread_mutex_destroy(&pp.mtx); pthread_cond_destroy(&pp.cv);
-	gzclose(ps.rd.fp);
-	free(ps.rd.buf); free(ps.rd.line); free(ps.seq); free(ps.qual);
+	ingest_close(&ps);
 	bfcg_destroy(ctx); /* the first bloom filter dies here, as in count.c:155 */
 	return ret;
+}
+
+/* Ingest only (no GPU): parses `fn` into batches exactly as bfc_count does and digests them.  out[0] batches, out[1] reads,
+ * out[2] stream positions, out[3] FNV-1a over all sequence streams, out[4] over all quality streams (FASTA: '~'), out[5] over the
+ * per-batch read counts (the batch boundaries), out[6] batches that came from the parallel fast path.  n_threads = 0: serial parser. */
+int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, uint64_t out[7])
+{
+	ingest_t in;
+	batch_t b;
+	uint64_t hs = 0xcbf29ce484222325ULL, hq = hs, hb = hs, i;
+	const int no_hash = getenv("BFC_INGEST_NOHASH") != 0; /* timing the parsers alone (scripts/ingest_rate.py) */
+	memset(out, 0, 7 * sizeof(uint64_t));
+	if (ingest_open(&in, fn, chunk_size, n_threads) != 0) return -1;
+	memset(&b, 0, sizeof(b));
+	b.cap = cap; b.seq = (uint8_t*)malloc(cap); b.qual = (uint8_t*)malloc(cap);
+	for (;;) {
+		ingest_fill(&in, &b);
+		if (b.n_seqs) {
+			++out[0]; out[1] += (uint64_t)b.n_seqs; out[2] += b.n_pos;
+			if (!no_hash) for (i = 0; i < b.n_pos; ++i) { hs = (hs ^ b.seq[i]) * 0x100000001b3ULL; hq = (hq ^ b.qual[i]) * 0x100000001b3ULL; }
+			for (i = 0; i < 4; ++i) hb = (hb ^ (((uint64_t)b.n_seqs >> (8 * i)) & 0xff)) * 0x100000001b3ULL;
+		}
+		if (b.last) break;
+	}
+	out[3] = hs; out[4] = hq; out[5] = hb; out[6] = (uint64_t)in.fast_batches;
+	free(b.seq); free(b.qual);
+	ingest_close(&in);
+	return 0;
 }

@@ -100,21 +100,226 @@ static inline int next_record(parser_t *ps)
 	}
 	r->pending = 0;
 	ps->l_seq = ps->l_qual = 0; ps->rec_has_qual = 0;
-	if (ps->keep_hdr) { ps->l_hdr = 0; app(&ps->hdr, &ps->l_hdr, &ps->m_hdr, r->line + 1, r->l_line - 1); ps->hdr[ps->l_hdr] = 0; }
+	if (ps->keep_hdr) {
+		ps->l_hdr = 0; app(&ps->hdr, &ps->l_hdr, &ps->m_hdr, r->line + 1, r->l_line - 1);
+		if (ps->l_hdr > 1 && ps->hdr[ps->l_hdr - 1] == '\r') --ps->l_hdr;
+		ps->hdr[ps->l_hdr] = 0;
+	}
 	for (;;) { /* sequence lines */
 		if (!rd_line(r)) return 1; /* FASTA record ended by EOF */
 		if (r->l_line == 0) continue;
 		if (r->line[0] == '>' || r->line[0] == '@') { r->pending = 1; return 1; }
 		if (r->line[0] == '+') break;
 		app(&ps->seq, &ps->l_seq, &ps->m_seq, r->line, r->l_line);
+		if (ps->l_seq > 1 && ps->seq[ps->l_seq - 1] == '\r') --ps->l_seq; /* kseq.h:138 ("\r\n" line ends), on the accumulated string */
 	}
 	ps->rec_has_qual = 1;
 	while (ps->l_qual < ps->l_seq) { /* quality lines (the '+' line itself is already consumed) */
 		if (!rd_line(r)) break;
 		app(&ps->qual, &ps->l_qual, &ps->m_qual, r->line, r->l_line);
+		if (ps->l_qual > 1 && ps->qual[ps->l_qual - 1] == '\r') --ps->l_qual;
 	}
 	if (ps->l_qual != ps->l_seq) { r->failed = 1; return 0; } /* kseq: -2, bseq_read stops */
 	return 1;
+}
+
+/* ------------------------------------------------------------------ fast path: uncompressed 4-line FASTQ in memory, several threads
+ *
+ * A plain (not gzip) regular file is mapped; a batch is cut out of a byte window that starts on a record boundary.  Every thread takes
+ * a slice of the window, finds the first line in it that begins a STRICT record -- '@' line, one non-empty sequence line, '+' line, one
+ * quality line of the same length: the shape on which kseq's grammar (above) and a line walk cannot differ -- and walks strict records
+ * from there.  The walks are then chained: the first thread starts on the window start (a true boundary by induction) and every thread
+ * must have started exactly where its predecessor stopped, so the window is ONE strict walk from a true boundary, i.e. what kseq_read
+ * returns.  Anything else (multi-line records, FASTA, an empty sequence, a length mismatch, junk between records, a guessed start that
+ * does not chain) sends this batch and the rest of the file through the serial parser above, from the window start.  The threads then
+ * copy their records into the batch at offsets known from the per-thread totals. */
+#include <pthread.h>
+
+typedef struct { uint64_t hdr; uint32_t len, seq_delta; } fq_rec_t; /* '@' position in the file; bases (CR stripped); sequence line - '@' */
+
+enum { FQ_OK = 0, FQ_CUT = 1, FQ_BAD = 2 };
+#define FQ_MAX_THREADS 64
+
+static inline const uint8_t *fq_eol(const uint8_t *p, const uint8_t *e) { const uint8_t *q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); return q ? q : e; }
+
+/* one strict record at s inside [.., e); at_eof: e is the end of the file, so the last line may lack its '\n'.
+ * FQ_OK: *nx = position after the record; FQ_CUT: e comes before the record is complete; FQ_BAD: not a strict record */
+static inline int fq_strict(const uint8_t *s, const uint8_t *e, int at_eof, fq_rec_t *rec, const uint8_t *base, const uint8_t **nx)
+{
+	const uint8_t *h, *q, *r, *t;
+	size_t ls, lq;
+	if (s >= e) return FQ_CUT;
+	if (*s != '@') return FQ_BAD;
+	h = fq_eol(s, e); if (h >= e) return at_eof ? FQ_BAD : FQ_CUT;
+	q = fq_eol(h + 1, e); if (q >= e) return at_eof ? FQ_BAD : FQ_CUT;
+	ls = (size_t)(q - (h + 1));
+	if (ls > 1 && q[-1] == '\r') --ls;
+	if (ls == 0 || h[1] == '>' || h[1] == '@' || h[1] == '+' || ls > 0x7fffffffu) return FQ_BAD;
+	if (q + 1 >= e) return at_eof ? FQ_BAD : FQ_CUT;
+	if (q[1] != '+') return FQ_BAD;
+	r = fq_eol(q + 1, e); if (r >= e) return at_eof ? FQ_BAD : FQ_CUT;
+	t = fq_eol(r + 1, e);
+	if (t >= e && !at_eof) return FQ_CUT;
+	lq = (size_t)(t - (r + 1));
+	if (lq > 1 && t[-1] == '\r') --lq;
+	if (lq != ls) return FQ_BAD;
+	if (rec) { rec->hdr = (uint64_t)(s - base); rec->len = (uint32_t)ls; rec->seq_delta = (uint32_t)(h + 1 - s); }
+	*nx = t < e ? t + 1 : e;
+	return FQ_OK;
+}
+
+typedef struct {
+	const uint8_t *base; uint64_t lo, hi, win_end; int first, at_eof; /* slice [lo,hi) of the window that ends at win_end */
+	fq_rec_t *rec; uint64_t n_rec, m_rec, bases; /* strict records whose '@' lies in the slice */
+	uint64_t start, end; int found, status;      /* where the walk began / stopped, and why (FQ_OK: ran into the slice end) */
+	uint8_t *oseq, *oqual; uint64_t n_copy;      /* copy phase */
+} fq_job_t;
+
+static void *fq_scan(void *arg)
+{
+	fq_job_t *j = (fq_job_t*)arg;
+	const uint8_t *base = j->base, *e = base + j->win_end, *s = base + j->lo, *lim = base + j->hi, *nx;
+	j->n_rec = 0; j->bases = 0; j->found = 0; j->status = FQ_OK;
+	if (!j->first) { /* first line start in the slice that begins a strict (or window-cut) record */
+		if (s[-1] != '\n') { s = fq_eol(s, e); if (s < e) ++s; }
+		while (s < lim && !(*s == '@' && fq_strict(s, e, j->at_eof, 0, base, &nx) != FQ_BAD)) { s = fq_eol(s, e); if (s < e) ++s; }
+		if (s >= lim) return 0; /* no record starts in this slice */
+	}
+	j->found = 1; j->start = (uint64_t)(s - base);
+	while (s < lim) {
+		fq_rec_t rc;
+		int st = fq_strict(s, e, j->at_eof, &rc, base, &nx);
+		if (st != FQ_OK) {
+			if (st == FQ_BAD && j->at_eof) { /* only line ends left before the end of the file? (kseq skips them looking for a header) */
+				const uint8_t *t = s;
+				while (t < e && (*t == '\n' || *t == '\r')) ++t;
+				if (t == e) { s = e; st = FQ_CUT; }
+			}
+			j->status = st; break;
+		}
+		if (j->n_rec == j->m_rec) { j->m_rec = j->m_rec ? j->m_rec * 2 : 1 << 16; j->rec = (fq_rec_t*)realloc(j->rec, j->m_rec * sizeof(fq_rec_t)); }
+		j->rec[j->n_rec++] = rc; j->bases += rc.len;
+		s = nx;
+	}
+	j->end = (uint64_t)(s - base);
+	return 0;
+}
+
+static void *fq_copy(void *arg)
+{
+	fq_job_t *j = (fq_job_t*)arg;
+	uint8_t *os = j->oseq, *oq = j->oqual;
+	uint64_t i;
+	for (i = 0; i < j->n_copy; ++i) {
+		const uint8_t *sq = j->base + j->rec[i].hdr + j->rec[i].seq_delta;
+		const uint32_t l = j->rec[i].len;
+		const uint8_t *pl = sq + l + (sq[l] == '\r' ? 2 : 1);                               /* the '+' line */
+		const uint8_t *ql = fq_eol(pl, j->base + j->win_end) + 1;                            /* fq_strict saw its '\n' */
+		memcpy(os, sq, l); os[l] = '\n'; os += l + 1;
+		memcpy(oq, ql, l); oq[l] = '!'; oq += l + 1;
+	}
+	return 0;
+}
+
+typedef struct {
+	const uint8_t *map; uint64_t size, pos; /* pos: next record boundary */
+	int n_threads, active;
+	double bytes_per_base; /* of the batches so far: sizes the next window */
+	fq_job_t *job;
+} fq_fast_t;
+
+static inline void fq_run(fq_fast_t *f, void *(*fn)(void*), int n)
+{
+	pthread_t tid[FQ_MAX_THREADS];
+	int i;
+	for (i = 1; i < n; ++i) pthread_create(&tid[i], 0, fn, &f->job[i]);
+	fn(&f->job[0]);
+	for (i = 1; i < n; ++i) pthread_join(tid[i], 0);
+}
+
+/* one batch out of the mapped file: 1 = done (b filled, f->pos advanced), 0 = not strict here: the caller falls back to the serial
+ * parser from f->pos.  Batch boundary as in bseq_read (bseq.c:52-76): the read that brings the batch to >= chunk_size bases is its last. */
+static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
+{
+	uint64_t win = (uint64_t)((double)chunk_size * (f->bytes_per_base > 0 ? f->bytes_per_base * 1.02 : 3.0)) + (1u << 18);
+	const uint64_t pos0 = f->pos;
+	b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0;
+	for (;;) {
+		const uint64_t wend = f->pos + win < f->size ? f->pos + win : f->size;
+		const int at_eof = wend == f->size;
+		int T = f->n_threads, i, n_used = 0, cut = 0, bad = 0;
+		uint64_t slice, cur = f->pos, bases = 0, npos = 0, nseq = 0;
+		if (wend - f->pos < (uint64_t)T * 65536) T = 1;
+		slice = (wend - f->pos + T - 1) / T;
+		for (i = 0; i < T; ++i) {
+			fq_job_t *j = &f->job[i];
+			j->base = f->map; j->lo = f->pos + i * slice; j->hi = j->lo + slice < wend ? j->lo + slice : wend; j->win_end = wend;
+			j->first = i == 0; j->at_eof = at_eof;
+			if (j->lo >= wend) { T = i; break; }
+		}
+		if (T == 0) { b->last = 1; return 1; } /* nothing left */
+		fq_run(f, fq_scan, T);
+		/* chain the walks */
+		for (i = 0; i < T && !cut; ++i) { /* records before the first thing that is not strict are still one chained walk */
+			fq_job_t *j = &f->job[i];
+			if (!j->found) { if (cur < j->hi) { bad = 1; break; } continue; }  /* a record should have started in this slice */
+			if (j->start != cur) { bad = 1; break; }
+			cur = j->end; n_used = i + 1;
+			if (j->status == FQ_CUT) cut = 1;
+			if (j->status == FQ_BAD) { bad = 1; cut = 1; }
+		}
+		/* where does the batch end? */
+		{
+			int done = 0;
+			for (i = 0; i < n_used && !done; ++i) {
+				fq_job_t *j = &f->job[i];
+				j->n_copy = 0;
+				if (bases + j->bases < chunk_size && npos + j->bases + j->n_rec <= b->cap) { /* the whole slice goes in */
+					j->n_copy = j->n_rec; bases += j->bases; npos += j->bases + j->n_rec; nseq += j->n_rec;
+				} else {
+					uint64_t k;
+					for (k = 0; k < j->n_rec; ++k) {
+						if (npos + j->rec[k].len + 1 > b->cap) { done = 1; break; }
+						bases += j->rec[k].len; npos += j->rec[k].len + 1; ++nseq; ++j->n_copy;
+						if (bases >= chunk_size) { done = 1; break; }
+					}
+				}
+			}
+			for (; i < n_used; ++i) f->job[i].n_copy = 0;
+			if (!done && bad) return 0; /* the batch would have to run through something that is not strict 4-line FASTQ */
+			if (!done && !at_eof && bases < chunk_size) { win *= 2; continue; } /* the window held less than one chunk: look further */
+		}
+		if (nseq == 0 && f->job[0].n_rec > 0) return 0; /* the first read does not fit the batch: the serial path reports it */
+		if (nseq == 0 && cur < f->size && !at_eof) { /* not even one record inside the window */
+			if (win < f->size) { win *= 2; continue; }
+			return 0;
+		}
+		if (nseq > 0x7fffffffu) return 0;
+		/* copy */
+		{
+			uint64_t o = 0, last_hdr = 0; const fq_job_t *lastj = 0;
+			for (i = 0; i < n_used; ++i) {
+				fq_job_t *j = &f->job[i];
+				uint64_t k, bsum = 0;
+				j->oseq = b->seq + o; j->oqual = b->qual + o;
+				if (j->n_copy == j->n_rec) bsum = j->bases; else for (k = 0; k < j->n_copy; ++k) bsum += j->rec[k].len;
+				o += bsum + j->n_copy;
+				if (j->n_copy) { lastj = j; last_hdr = j->rec[j->n_copy - 1].hdr; }
+			}
+			fq_run(f, fq_copy, n_used > 0 ? n_used : 1);
+			b->n_pos = o; b->n_seqs = (int)nseq; b->has_qual = nseq > 0;
+			if (lastj) { /* the next batch starts after the last record taken */
+				const uint8_t *nx = 0;
+				int all = 1;
+				for (i = 0; i < n_used; ++i) if (f->job[i].n_copy != f->job[i].n_rec) all = 0;
+				if (all) f->pos = cur;
+				else { fq_strict(f->map + last_hdr, f->map + wend, at_eof, 0, f->map, &nx); f->pos = (uint64_t)(nx - f->map); }
+			} else f->pos = cur;
+		}
+		if (f->pos >= f->size) b->last = 1;
+		if (bases > 0) f->bytes_per_base = (double)(f->pos - pos0) / (double)bases;
+		return 1;
+	}
 }
 
 /* fill one batch: reads until at least chunk_size bases (bseq.c:52-76) or the buffer is full */
@@ -138,5 +343,66 @@ static inline void fill_batch(parser_t *ps, batch_t *b)
 	}
 }
 
+
+/* ------------------------------------------------------------------ one input: fast path when possible, serial parser otherwise */
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+typedef struct {
+	parser_t ps;
+	fq_fast_t fast;
+	int fast_batches, serial_batches;
+} ingest_t;
+
+/* 0 on success; the gz stream is always opened (it is the fallback and the only way for gzip / stdin / FASTA input) */
+static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size, int n_threads)
+{
+	memset(in, 0, sizeof(*in));
+	in->ps.chunk_size = chunk_size;
+	in->ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
+	if (in->ps.rd.fp == 0) return -1;
+	gzbuffer(in->ps.rd.fp, 1 << 18);
+	in->ps.rd.buf = (uint8_t*)malloc(RD_BUF);
+	if (n_threads > 0 && fn && strcmp(fn, "-")) { /* a regular, uncompressed file that starts like a FASTQ: map it */
+		struct stat st;
+		int fd = open(fn, O_RDONLY);
+		if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 4) {
+			void *m = mmap(0, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+			if (m != MAP_FAILED) {
+				const uint8_t *p = (const uint8_t*)m;
+				if (p[0] == '@' && !(p[0] == 0x1f && p[1] == 0x8b)) {
+					(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+					in->fast.map = p; in->fast.size = (uint64_t)st.st_size; in->fast.pos = 0; in->fast.active = 1;
+					in->fast.n_threads = n_threads > FQ_MAX_THREADS ? FQ_MAX_THREADS : n_threads;
+					in->fast.job = (fq_job_t*)calloc((size_t)in->fast.n_threads, sizeof(fq_job_t));
+				} else munmap(m, (size_t)st.st_size);
+			}
+		}
+		if (fd >= 0) close(fd);
+	}
+	return 0;
+}
+
+static inline void ingest_fill(ingest_t *in, batch_t *b)
+{
+	if (in->fast.active) {
+		if (fq_fill_batch(&in->fast, b, in->ps.chunk_size)) { ++in->fast_batches; return; }
+		in->fast.active = 0; /* not strict 4-line FASTQ from here on: the serial parser takes over at the last record boundary */
+		gzseek(in->ps.rd.fp, (z_off_t)in->fast.pos, SEEK_SET);
+	}
+	fill_batch(&in->ps, b);
+	++in->serial_batches;
+}
+
+static inline void ingest_close(ingest_t *in)
+{
+	int i;
+	if (in->fast.map) munmap((void*)in->fast.map, (size_t)in->fast.size);
+	if (in->fast.job) { for (i = 0; i < in->fast.n_threads; ++i) free(in->fast.job[i].rec); free(in->fast.job); }
+	gzclose(in->ps.rd.fp);
+	free(in->ps.rd.buf); free(in->ps.rd.line); free(in->ps.seq); free(in->ps.qual); free(in->ps.hdr);
+}
 
 #endif

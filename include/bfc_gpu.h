@@ -148,6 +148,12 @@ int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *
 bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which);   /* host bfc_bf_t (caller: bfc_bf_destroy) */
 bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (caller: bfc_ch_destroy) */
 
+/* Ingest only, no GPU: parses `fn` (FASTA/FASTQ, plain or gzip) into the batches bfc_count would submit -- kseq's grammar
+ * (kseq.h:185-224) and bseq_read's batch boundary (bseq.c:52-76) -- and digests them: out[0] batches, [1] reads, [2] stream positions,
+ * [3]/[4] FNV-1a of all sequence / quality streams, [5] FNV-1a of the per-batch read counts, [6] batches parsed by the multi-threaded
+ * fast path (uncompressed strict 4-line FASTQ; n_threads = 0 forces the serial parser).  Used to test that both parsers agree. */
+int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, uint64_t out[7]);
+
 /* L1 form of a host table: sizes[2^l_pre]; slots (may be NULL) = per sub-table sorted */
 int      bfc_ch_get_lpre(const bfc_ch_t *ch);
 uint64_t bfc_ch_export_sorted(const bfc_ch_t *ch, uint32_t *sizes, uint64_t *slots);

@@ -159,6 +159,7 @@ def ref():
         R.bfc_ch_count.restype = C.c_uint64
         R.bfc_ch_count.argtypes = [C.c_void_p]
         R.bfc_ch_hist.argtypes = [C.c_void_p, u64p, u64p]
+        R.ref_ingest_digest.argtypes = [C.c_char_p, C.c_int, u64p]
         R.bfc_ch_dump.argtypes = [C.c_void_p, C.c_char_p]
         R.bfc_ch_restore.restype = C.c_void_p
         R.bfc_ch_restore.argtypes = [C.c_char_p]

@@ -74,3 +74,32 @@ uint64_t ref_count_batch(ref_state_t *st, int k, int q, int n_hashes, const uint
 		n += ref_count_read(st, k, q, n_hashes, (const char*)seq + off[r], qual ? (const char*)qual + off[r] : 0, (int)(off[r+1] - off[r]), trace ? trace + 4 * n : 0);
 	return n;
 }
+
+/* The reference's own ingest (bseq_open / bseq_read = kseq, bseq.c:52-76) digested like bfc_ingest_digest of the product library:
+ * out[0] batches, [1] reads, [2] stream positions (bases + one separator per read), [3]/[4] FNV-1a of the sequence / quality streams
+ * (read + '\n'; quality + '!', '~' for records without qualities), [5] FNV-1a of the per-batch read counts. */
+#include "bseq.h"
+int ref_ingest_digest(const char *fn, int chunk_size, uint64_t out[7])
+{
+	bseq_file_t *fp = bseq_open(fn);
+	uint64_t hs = 0xcbf29ce484222325ULL, hq = hs, hb = hs;
+	int n, i, j;
+	bseq1_t *s;
+	memset(out, 0, 7 * sizeof(uint64_t));
+	if (fp == 0) return -1;
+	while ((s = bseq_read(fp, chunk_size, 0, &n)) != 0 && n > 0) {
+		++out[0]; out[1] += (uint64_t)n;
+		for (i = 0; i < n; ++i) {
+			for (j = 0; j < s[i].l_seq; ++j) { hs = (hs ^ (uint8_t)s[i].seq[j]) * 0x100000001b3ULL; hq = (hq ^ (uint8_t)(s[i].qual ? s[i].qual[j] : '~')) * 0x100000001b3ULL; }
+			hs = (hs ^ '\n') * 0x100000001b3ULL; hq = (hq ^ '!') * 0x100000001b3ULL;
+			out[2] += (uint64_t)s[i].l_seq + 1;
+			free(s[i].name); free(s[i].comment); free(s[i].seq); free(s[i].qual);
+		}
+		for (i = 0; i < 4; ++i) hb = (hb ^ (((uint64_t)n >> (8 * i)) & 0xff)) * 0x100000001b3ULL;
+		free(s);
+	}
+	if (s) free(s);
+	out[3] = hs; out[4] = hq; out[5] = hb;
+	bseq_close(fp);
+	return 0;
+}

@@ -1,0 +1,120 @@
+"""Host ingest, CPU only: the library's two parsers -- the serial kseq-grammar parser and the multi-threaded fast path for
+uncompressed strict 4-line FASTQ -- must cut the same batches out of any input, and both must agree with the reference's own
+bseq_read/kseq (through oracle/_ref/libbfcref.so when it is built).  bfc_ingest_digest parses without touching a GPU."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+u64p = C.POINTER(C.c_uint64)
+
+
+def _digest(gpu_lib, fn, chunk, threads, cap=1 << 24):
+    from bfc_amd import _lib
+    out = (C.c_uint64 * 7)()
+    assert _lib.load().bfc_ingest_digest(fn.encode(), chunk, cap, threads, out) == 0
+    return [int(v) for v in out]
+
+
+def _ref_digest(fn, chunk):
+    out = (C.c_uint64 * 7)()
+    assert oracle.ref().ref_ingest_digest(fn.encode(), chunk, out) == 0
+    return [int(v) for v in out]
+
+
+def _fastq(rng, n, lmin, lmax, crlf=False, qual_at=True, names=True):
+    eol = b"\r\n" if crlf else b"\n"
+    parts = []
+    for r in range(n):
+        l = int(rng.integers(lmin, lmax + 1))
+        s = rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), l).tobytes()
+        q = rng.integers(33, 74, l).astype(np.uint8)
+        if qual_at and l and r % 3 == 0:
+            q[0] = ord("@") if r % 2 else ord("+")   # quality lines that look like headers / separators
+        name = b"@r%d some comment/1" % r if names else b"@%d" % r
+        parts.append(name + eol + s + eol + b"+" + (name[1:] if r % 5 == 0 else b"") + eol + q.tobytes() + eol)
+    return b"".join(parts)
+
+
+CASES = ["plain", "crlf", "no_final_newline", "trailing_blank_lines", "one_read", "long_reads", "tiny_reads", "multiline", "strict_then_multiline",
+         "fasta", "truncated_quality", "empty", "blank_only", "garbage_tail"]
+
+
+def _make(case, path, rng):
+    if case == "plain":
+        data = _fastq(rng, 5000, 30, 250)
+    elif case == "crlf":
+        data = _fastq(rng, 3000, 1, 200, crlf=True)
+    elif case == "no_final_newline":
+        data = _fastq(rng, 2000, 50, 150)[:-1]
+    elif case == "trailing_blank_lines":
+        data = _fastq(rng, 2000, 50, 150) + b"\n\n\r\n\n"
+    elif case == "one_read":
+        data = _fastq(rng, 1, 100, 100)
+    elif case == "long_reads":
+        data = _fastq(rng, 40, 1, 300000)
+    elif case == "tiny_reads":
+        data = _fastq(rng, 20000, 1, 3, names=False)
+    elif case == "multiline":
+        recs = []
+        for r in range(1500):
+            l = int(rng.integers(61, 300))
+            s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), l).tobytes(); q = rng.integers(34, 74, l).astype(np.uint8).tobytes()
+            recs.append(b"@m%d\n" % r + b"\n".join(s[i:i + 60] for i in range(0, l, 60)) + b"\n+\n" + b"\n".join(q[i:i + 60] for i in range(0, l, 60)) + b"\n")
+        data = b"".join(recs)
+    elif case == "strict_then_multiline":
+        l = 130
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), l).tobytes(); q = rng.integers(34, 74, l).astype(np.uint8).tobytes()
+        data = _fastq(rng, 4000, 80, 120) + b"@wrapped\n" + s[:70] + b"\n" + s[70:] + b"\n+\n" + q[:70] + b"\n" + q[70:] + b"\n" + _fastq(rng, 1500, 80, 120)
+    elif case == "fasta":
+        data = b"".join(b">f%d\n" % r + rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 400))).tobytes() + b"\n" for r in range(2000))
+    elif case == "truncated_quality":
+        data = _fastq(rng, 3000, 100, 100)
+        data = data[:len(data) * 2 // 3]
+        data = data[:data.rindex(b"\n+")] + b"\n+\nIIII\n"   # a quality line shorter than its sequence: kseq returns -2 and the input ends there
+    elif case == "empty":
+        data = b""
+    elif case == "blank_only":
+        data = b"\n\n\n"
+    elif case == "garbage_tail":
+        data = _fastq(rng, 2500, 60, 90) + b"this is not a record\nnor is this\n"
+    open(path, "wb").write(data)
+    return len(data)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_parsers_agree(gpu_lib, tmp_path, case):
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    fn = str(tmp_path / (case + ".fq"))
+    size = _make(case, fn, rng)
+    for chunk in (20000, 1 << 30) if size < (1 << 22) else (500000,):
+        serial = _digest(gpu_lib, fn, chunk, 0)
+        assert serial[6] == 0
+        for threads in (1, 3, 8):
+            fast = _digest(gpu_lib, fn, chunk, threads)
+            assert fast[:6] == serial[:6], (case, chunk, threads)
+        if case in ("plain", "crlf", "no_final_newline", "trailing_blank_lines", "long_reads", "tiny_reads") and serial[0]:
+            assert fast[6] == serial[0], "every batch of a strict FASTQ comes from the fast path"
+        if case == "strict_then_multiline" and chunk == 20000:
+            assert 0 < fast[6] < serial[0], "fast path until the wrapped record, serial parser from there"
+        if case in ("multiline", "fasta"):
+            assert fast[6] == 0
+        if oracle.have_ref():
+            assert _ref_digest(fn, chunk)[:6] == serial[:6], "the reference's bseq_read cuts other batches"
+
+
+def test_gzip_and_small_batches(gpu_lib, tmp_path):
+    rng = np.random.default_rng(5)
+    data = _fastq(rng, 3000, 20, 180)
+    fn = str(tmp_path / "x.fq"); open(fn, "wb").write(data)
+    gz = str(tmp_path / "x.fq.gz"); gzip.open(gz, "wb").write(data)
+    a = _digest(gpu_lib, fn, 7777, 4)
+    b = _digest(gpu_lib, gz, 7777, 4)
+    assert a[:6] == b[:6] and a[6] == a[0] and b[6] == 0
+    # a batch buffer smaller than a chunk: the capacity cuts the batches, identically for both parsers
+    c0, c4 = _digest(gpu_lib, fn, 1 << 30, 0, cap=50000), _digest(gpu_lib, fn, 1 << 30, 4, cap=50000)
+    assert c0[:6] == c4[:6] and c0[0] > 5
