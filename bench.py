@@ -169,6 +169,15 @@ def main():
         try:
             g = make_counter(world)
             eng = bdist.GpuEngine(g)
+            # a real (small) exchange through the very code the timed loop uses: 5 records per level-1 bucket from every rank
+            nb1 = g.mg_info()["nb1"]
+            eng.send[:5 * nb1 * eng.rec_words].fill_(rank + 1)
+            seg = bdist.exchange(eng, np.full(nb1, 5, dtype=np.uint32))
+            torch.cuda.synchronize()
+            got = eng.recv[:5 * nb1 * eng.rec_words].view(world, -1)
+            want = torch.arange(1, world + 1, device=got.device, dtype=got.dtype).view(world, 1).expand_as(got)
+            if seg.shape != (world, nb1 // world) or int(seg.sum()) != 5 * nb1 or not bool((got == want).all()):
+                raise RuntimeError("exchange preflight delivered wrong data")
         except Exception as e:  # noqa: BLE001
             log("[bench] rank %d: exchange path unavailable: %r" % (rank, e))
             ok = 0

@@ -98,28 +98,36 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
 		if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
-		P.bloom_bt = (prm->track_order && !prm->filter_mode) ? 512 : (e = getenv("BFCG_BT")) ? atoi(e) : 512;
-		if (P.bloom_bt != 256 && P.bloom_bt != 512 && P.bloom_bt != 1024) P.bloom_bt = 512;
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
-		P.bloom_pf = (e = getenv("BFCG_PF")) ? atoi(e) : 4;
 		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 256;
-		// LDS budget: a third of a CU (3 workgroups of 512 threads resident = 24 waves) unless the region alone needs more
-		size_t region = (size_t)64 << P.R, budget = (e = getenv("BFCG_LDS")) ? (size_t)atoi(e) : (size_t)53000;
-		if (budget > 160 * 1024 - 1024) budget = 160 * 1024 - 1024;
-		if (region + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
-		// per k-mer with clear bits: one list entry (record + mask) and n_hashes first-setter entries at <= 50 % load
+		// LDS budget: a third of a CU (3 workgroups of 512 threads resident = 24 waves), else half, else all of it -- the first tier that
+		// leaves 16 KiB for the list and the first-setter table next to the region and the second slice / aggregation table
+		const size_t region = (size_t)64 << P.R;
 		const size_t rwb = 8; // list entry: file-order index + (record index | mask)
 		const size_t second = prm->filter_mode ? region : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (prm->track_order ? 8 : 0)); // second filter's slice, or the aggregation table
-		if (region + second + 12 * 1024 > budget) budget = 160 * 1024 - 1024;
+		size_t budget = (size_t)53000;
+		if (region + second + 16 * 1024 > budget) budget = 80 * 1024 - 1024;
+		if (region + second + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
+		if ((e = getenv("BFCG_LDS")) != 0 && (size_t)atoi(e) >= region + second + 4096 && (size_t)atoi(e) <= 160 * 1024 - 1024) budget = (size_t)atoi(e);
 		size_t left = budget - region - second - 16;
-		uint32_t fs = 512; while ((size_t)(fs * 2) * 4 + (size_t)(fs * 2 / (2 * P.n_hashes)) * rwb <= left && fs < 32768) fs <<= 1;
-		if ((e = getenv("BFCG_FS")) != 0) fs = (uint32_t)atoi(e);
+		// split: 8 B per k-mer with clear bits (list) and 4 B per first-setter entry (power of two).  Only contended bits get an entry;
+		// the worst realistic case (a genome at ~1x per batch: every new k-mer twice) has ~1.2 per list entry: list <= 3/4 of the table
+		uint32_t fs = 512, best_fs = 512, best_list = 0;
+		for (; fs <= 32768 && (size_t)fs * 4 + rwb * 64 <= left; fs <<= 1) {
+			uint32_t list = (uint32_t)((left - (size_t)fs * 4) / rwb);
+			if (list > fs / 4 * 3) list = fs / 4 * 3;
+			if (list > best_list) { best_list = list; best_fs = fs; }
+		}
+		fs = best_fs;
+		if ((e = getenv("BFCG_FS")) != 0) { fs = (uint32_t)atoi(e); best_list = (uint32_t)((left - (size_t)fs * 4) / rwb); }
 		P.fs_cap = fs;
-		P.list_cap = (uint32_t)((left - (size_t)fs * 4) / rwb);
+		P.list_cap = best_list;
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
 	P.track = (prm->track_order && !prm->filter_mode) ? 1 : 0;
+	// one workgroup per CU (regions of 32 KiB and more: -b36, -b37) runs 1024 threads so that the CU still has 16 waves; no such variant with order stamps
+	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
 	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 24;
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
@@ -174,7 +182,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		HIPCKN(hipMemset(B.pool, 0, (size_t)B.pool_slices * 8));
 	}
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
-	if (!getenv("BFCG_INLINE_COMMIT") && !P.filter_mode) { // filter mode hands nothing over: both filters' slices are in LDS
+	if (!P.filter_mode) { // filter mode hands nothing over: both filters' slices are in LDS
 		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
 		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
 	}

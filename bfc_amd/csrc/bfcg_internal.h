@@ -24,8 +24,7 @@ struct KParams {
 	uint32_t idx_rank;          // rank << (32 - rank_bits): prefixed to the in-batch position so file order is rank-major
 	int track;                  // 1: keep first/last insertion stamps for the byte-identical dump
 	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
-	int bloom_pf;               // records per thread kept in registers by the bloom kernel (2/4)
-	int bloom_bt;               // threads per workgroup of the bloom kernel (256/512/1024)
+	int bloom_bt;               // threads per workgroup of the bloom kernel: 512 (three workgroups per CU), 1024 when the LDS footprint allows one only
 };
 
 struct BatchBufs {

@@ -1360,17 +1360,15 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
-		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
+		else if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
 		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else if (P.n_hashes == 4) {
 		if (P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false>), dim3(nfine), dim3(1024), lds, st, P, A);
-		else if (P.bloom_bt == 512 && P.bloom_pf == 2) hipLaunchKernelGGL((k_bloom<W, RW, 512, 2, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
-		else if (P.bloom_bt == 512 && P.bloom_pf == 3) hipLaunchKernelGGL((k_bloom<W, RW, 512, 3, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
-		else if (P.bloom_bt == 512) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
-		else hipLaunchKernelGGL((k_bloom<W, RW, 256, 4, 4, false>), dim3(nfine), dim3(256), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false>), dim3(nfine), dim3(512), lds, st, P, A);
 	if (ev) hipEventRecord(ev[4], st);
 	if (B.agg_out) {
@@ -1410,14 +1408,13 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2)); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 3, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	return hipFuncSetAttribute((const void *)k_bloom<W, RW, 256, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	return hipSuccess;
 }
 hipError_t set_bloom_lds_attr(const KParams &P)
 {

@@ -227,6 +227,12 @@ class Counter:
         p = self.L.orc_bf_bits(self._bf(high)) if self.impl == "oracle" else self.L.ref_bf_bits(self._bf(high))
         return np.ctypeslib.as_array(C.cast(p, u8p), shape=(n,)).copy()
 
+    def bloom_view(self, high=False):
+        """the bitmap in place (no copy; valid until close())"""
+        n = 1 << (self.bf_shift - 3)
+        p = self.L.orc_bf_bits(self._bf(high)) if self.impl == "oracle" else self.L.ref_bf_bits(self._bf(high))
+        return np.ctypeslib.as_array(C.cast(p, u8p), shape=(n,))
+
     def bloom_checksums(self, high=False):
         n = 1 << (self.bf_shift - 3)
         p = self.L.orc_bf_bits(self._bf(high)) if self.impl == "oracle" else self.L.ref_bf_bits(self._bf(high))

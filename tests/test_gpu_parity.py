@@ -281,3 +281,30 @@ def test_long_and_degenerate_reads(gpu_lib, k):
     osz, osl = oc.export()
     assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
     g.close(); oc.close()
+
+
+@pytest.mark.parametrize("fm", [0, 1])
+def test_largest_filter_b37(gpu_lib, g1, fm):
+    """`-s 3g` (bfc.c:42-53) gives -b37: a 16 GiB filter, 64 KiB regions, one 1024-thread workgroup per CU -- table mode and filter mode.
+    Compared with the oracle through the set bits' positions (popcount + every word the oracle has set), statistics and the table."""
+    rs, (seq, qual, off) = g1
+    n = 4000
+    seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
+    k, b = 33, 37
+    oc = oracle.Counter(k, b, filter_mode=fm)
+    oc.count(seq, qual, off)
+    g = _gpu_count(gpu_lib, k, b, seq, qual, off, 2, filter_mode=fm)
+    ost, st = oc.stats(), g.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    for which in ([0, 1] if fm else [0]):
+        ob = oc.bloom_view(bool(which)).view(np.uint64)
+        gb = g.bloom_bytes(which).view(np.uint64)
+        nz = np.flatnonzero(ob)
+        assert len(nz) > 1000 and np.array_equal(gb[nz], ob[nz])
+        assert int(oracle.lib().orc_popcount_bytes(gb.ctypes.data, gb.nbytes)) == int(np.bitwise_count(ob[nz]).sum())
+        del ob, gb
+    if not fm:
+        sizes, slots = g.export_table().export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.close(); oc.close()
