@@ -93,11 +93,11 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.R > 10) P.R = 10;
 		if (P.R < 4) P.R = 4;
 		if (P.R > P.bf_shift - 9) P.R = P.bf_shift - 9;
-		while (P.bf_shift - 9 - P.R > 18 && P.R < 10) ++P.R; // two scatter levels of at most 512 buckets: big filters (-b36/-b37, `-s 3g`) take bigger regions
+		while (P.bf_shift - 9 - P.R > 20 && P.R < 10) ++P.R; // two scatter levels of at most 1024 buckets each: 16 KiB regions up to -b37
 		P.F = P.bf_shift - 9 - P.R;
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
-		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 9) P.F2 = 9; P.F1 = P.F - P.F2; }
-		if (P.F1 > 9) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
+		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 10) P.F2 = 10; P.F1 = P.F - P.F2; }
+		if (P.F1 > 10) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
 		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 256;
 		// LDS budget: a third of a CU (3 workgroups of 512 threads resident = 24 waves), else half, else all of it -- the first tier that
@@ -296,6 +296,15 @@ static int table_target_cshift(const bfcg_ctx_t *c)
 	if ((need + g) * 2 > (1ULL << (P.l_pre + t)))
 		while ((need + 2 * g) * 2 > (1ULL << (P.l_pre + t)) && P.l_pre + t < 36) ++t;
 	if (c->h_stats[ST_TAB_OVF] && t == P.tab_cshift) ++t; // a full sub-table under a low overall load
+	if (t > P.tab_cshift) { // the old table lives until the new one is filled: grow only as far as memory allows, and run fuller instead (<= 80 %)
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const uint64_t margin = 2ULL << 30;
+			while (t > P.tab_cshift && (8ULL << (P.l_pre + t)) + margin > (uint64_t)free_b) --t;
+			if (t == P.tab_cshift && !c->h_stats[ST_TAB_OVF] && need * 5 <= (4ULL << (P.l_pre + t))) return t; // cannot grow, need not yet
+			if (t == P.tab_cshift) return t + 1; // must grow and cannot: table_maintain reports it
+		}
+	}
 	return t;
 }
 
@@ -309,6 +318,11 @@ static int table_maintain(bfcg_ctx_t *c)
 		if (ovf == 0 && target == P.tab_cshift) return 0;
 		if (ovf > B.tab_ovf_cap) return set_err("count table overflow list exhausted (%llu parked k-mers)", (unsigned long long)ovf);
 		if (P.l_pre + target > 36) return set_err("count table cannot grow beyond 2^36 slots");
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (8ULL << (P.l_pre + target)) + (1ULL << 30) > (uint64_t)free_b)
+				return set_err("count table of %llu keys cannot grow to 2^%d slots: %.1f GiB of device memory free", (unsigned long long)c->h_stats[ST_KEYS], P.l_pre + target, free_b / 1073741824.0);
+		}
 		int old_cshift = P.tab_cshift;
 		unsigned long long *nt = 0;
 		P.tab_cshift = target;

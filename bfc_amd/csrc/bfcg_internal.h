@@ -4,6 +4,7 @@
 #define BFCG_TILE1 4096
 #define BFCG_TILE2 4096
 #define BFCG_SCAN_CH 64
+#define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */
 #include <stdint.h>
 
 namespace bfcg {

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(BT) void k_hist1(KParams P, const uint8_t *__restri
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	__shared__ uint32_t planes[4 * PW];
-	__shared__ uint32_t hist[512];
+	__shared__ uint32_t hist[BFCG_MAXB];
 	const int nb1 = 1 << P.F1;
 	const W m = kmask<W>(P.k);
 	const int shift2 = P.F2;
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) void k_colsum(const uint32_t *__restrict__ row
 }
 // one workgroup: bucket totals -> start[NB+1]; chunk sums -> chunk offsets (in place);
 // row_base[NB+1] = first level-2 histogram row of each bucket (ceil(total/tile2) rows per bucket)
-__global__ __launch_bounds__(512) void k_scan_top(uint32_t *__restrict__ chunk, int n_chunks, int NB, uint32_t *__restrict__ start,
+__global__ __launch_bounds__(BFCG_MAXB) void k_scan_top(uint32_t *__restrict__ chunk, int n_chunks, int NB, uint32_t *__restrict__ start,
                                                   uint32_t *__restrict__ row_base, int tile2)
 {
-	__shared__ uint32_t tot[512], rws[512];
+	__shared__ uint32_t tot[BFCG_MAXB], rws[BFCG_MAXB];
 	const int b = threadIdx.x;
 	uint32_t total = 0;
 	if (b < NB) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void k_scan_top(uint32_t *__restrict__ chunk, 
 	tot[b] = b < NB ? total : 0;
 	rws[b] = b < NB ? (total + tile2 - 1) / tile2 : 0;
 	__syncthreads();
-	for (int o = 1; o < 512; o <<= 1) {
+	for (int o = 1; o < NB; o <<= 1) {
 		uint32_t v = b >= o ? tot[b - o] : 0, w = b >= o ? rws[b - o] : 0;
 		__syncthreads();
 		tot[b] += v; rws[b] += w;
@@ -307,14 +307,14 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4); // bucket of each staged record
 	__shared__ uint32_t planes[4 * PW];
-	__shared__ uint32_t cnt[512], loff[512], gdelta[512];
 	__shared__ uint32_t s_total;
 	const int nb1 = 1 << P.F1;
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + 2)), *loff = cnt + nb1, *gdelta = loff + nb1; // 3 x nb1 counters behind the stage
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
 	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
-	for (int i = threadIdx.x; i < 512; i += BT) cnt[i] = 0;
+	for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0;
 	build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
 	__syncthreads();
 	RecW<RW> w[S];
@@ -332,19 +332,19 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 		}
 	}
 	__syncthreads();
-	{ // exclusive scan of the 512 counters (Hillis-Steele in LDS)
-		for (int i = threadIdx.x; i < 512; i += BT) loff[i] = cnt[i];
+	{ // exclusive scan of the bucket counters (Hillis-Steele in LDS)
+		for (int i = threadIdx.x; i < nb1; i += BT) loff[i] = cnt[i];
 		__syncthreads();
-		for (int o = 1; o < 512; o <<= 1) {
-			uint32_t v[512 / BT > 0 ? 512 / BT : 1];
+		for (int o = 1; o < nb1; o <<= 1) {
+			uint32_t v[BFCG_MAXB / BT > 0 ? BFCG_MAXB / BT : 1];
 			int q = 0;
-			for (int i = threadIdx.x; i < 512; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
+			for (int i = threadIdx.x; i < nb1; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
 			__syncthreads();
 			q = 0;
-			for (int i = threadIdx.x; i < 512; i += BT, ++q) loff[i] += v[q];
+			for (int i = threadIdx.x; i < nb1; i += BT, ++q) loff[i] += v[q];
 			__syncthreads();
 		}
-		if (threadIdx.x == 0) s_total = loff[511];
+		if (threadIdx.x == 0) s_total = loff[nb1 - 1];
 		for (int i = threadIdx.x; i < nb1; i += BT) {
 			const uint32_t ex = loff[i] - cnt[i];
 			gdelta[i] = rows1[tile * nb1 + i] - ex; // global record index = staged position + gdelta[bucket] (u32 modular)
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restr
                                               const uint32_t *__restrict__ seg_end, int n_seg,
                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2)
 {
-	__shared__ uint32_t hist[512];
+	__shared__ uint32_t hist[BFCG_MAXB];
 	const int nb2 = 1 << P.F2;
 	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
@@ -414,10 +414,10 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restr
 }
 
 // one workgroup per level-1 bucket: column totals -> fine starts; rows -> absolute offsets in place
-__global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__restrict__ bucket_start, int segs_per_bucket,
+__global__ __launch_bounds__(BFCG_MAXB) void k_scan2(KParams P, const uint32_t *__restrict__ bucket_start, int segs_per_bucket,
                                                const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2, uint32_t *__restrict__ start2)
 {
-	__shared__ uint32_t tot[512];
+	__shared__ uint32_t tot[BFCG_MAXB];
 	const int nb2 = 1 << P.F2, b1 = blockIdx.x, c = threadIdx.x;
 	const uint32_t r0 = row_base[b1 * segs_per_bucket], r1 = row_base[(b1 + 1) * segs_per_bucket];
 	uint32_t total = 0;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void k_scan2(KParams P, const uint32_t *__rest
 	}
 	tot[c] = c < nb2 ? total : 0;
 	__syncthreads();
-	for (int o = 1; o < 512; o <<= 1) {
+	for (int o = 1; o < nb2; o <<= 1) {
 		uint32_t v = c >= o ? tot[c - o] : 0;
 		__syncthreads();
 		tot[c] += v;
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem2);                              // TILE * RW dwords
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 4); // bucket of each staged record
-	__shared__ uint32_t cnt[512], loff[512], gdelta[512];
 	const int nb2 = 1 << P.F2;
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + 2)), *loff = cnt + nb2, *gdelta = loff + nb2; // 3 x nb2 counters behind the stage
 	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
 	if (row >= n_rows) return;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	const uint32_t tile = (uint32_t)row - row_base[b1];
 	const uint32_t s = seg_beg[b1], e = seg_end[b1];
 	const uint32_t *rowp = rows2 + (size_t)row * nb2;
-	for (int i = threadIdx.x; i < 512; i += BT) cnt[i] = 0;
+	for (int i = threadIdx.x; i < nb2; i += BT) cnt[i] = 0;
 	__syncthreads();
 	RecW<RW> w[S];
 	uint32_t br[S]; // bucket << 16 | rank inside (tile, bucket)
@@ -481,16 +481,16 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		}
 	}
 	__syncthreads();
-	{ // exclusive scan of the 512 counters (Hillis-Steele in LDS)
-		for (int i = threadIdx.x; i < 512; i += BT) loff[i] = cnt[i];
+	{ // exclusive scan of the bucket counters (Hillis-Steele in LDS)
+		for (int i = threadIdx.x; i < nb2; i += BT) loff[i] = cnt[i];
 		__syncthreads();
-		for (int o = 1; o < 512; o <<= 1) {
-			uint32_t v[512 / BT > 0 ? 512 / BT : 1];
+		for (int o = 1; o < nb2; o <<= 1) {
+			uint32_t v[BFCG_MAXB / BT > 0 ? BFCG_MAXB / BT : 1];
 			int q = 0;
-			for (int i = threadIdx.x; i < 512; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
+			for (int i = threadIdx.x; i < nb2; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
 			__syncthreads();
 			q = 0;
-			for (int i = threadIdx.x; i < 512; i += BT, ++q) loff[i] += v[q];
+			for (int i = threadIdx.x; i < nb2; i += BT, ++q) loff[i] += v[q];
 			__syncthreads();
 		}
 		for (int i = threadIdx.x; i < nb2; i += BT) {
@@ -1131,18 +1131,34 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	(void)s_pad;
 }
 
-// apply the aggregated k-mers of every bucket: one thread per slot of agg_out, full occupancy
-template <typename W, bool TRACK>
+// apply the aggregated k-mers of every bucket.  WALK = false: one thread per slot of agg_out (full occupancy; best up to ~2^18 regions);
+// WALK = true: a wave walks COMMIT_RPW regions, lane j takes entries j, j+64, ... (at 2^20 regions a thread per slot launches a million
+// nearly empty waves: 12.5 instead of 9 ms per batch on config c4)
+#define COMMIT_RPW 4
+template <typename W, bool TRACK, bool WALK>
 __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 {
-	const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
-	const uint32_t f = (uint32_t)(gid / P.ag_cap), j = (uint32_t)(gid % P.ag_cap);
-	if (f >= A.n_fine || j >= A.agg_cnt[f]) return;
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	const uint64_t plane = (uint64_t)A.n_fine * P.ag_cap;
-	const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
-	const uint64_t fl = TRACK ? A.agg_out[3 * plane + gid] : 0;
-	commit_seen<W, TRACK>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
+	if (!WALK) {
+		const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
+		const uint32_t f = (uint32_t)(gid / P.ag_cap), j = (uint32_t)(gid % P.ag_cap);
+		if (f >= A.n_fine || j >= A.agg_cnt[f]) return;
+		const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
+		const uint64_t fl = TRACK ? A.agg_out[3 * plane + gid] : 0;
+		commit_seen<W, TRACK>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
+	} else {
+		const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+		for (uint32_t f = wave * COMMIT_RPW; f < wave * COMMIT_RPW + COMMIT_RPW && f < A.n_fine; ++f) {
+			const uint32_t n = A.agg_cnt[f];
+			for (uint32_t j = lane; j < n; j += 64) {
+				const uint64_t gid = (uint64_t)f * P.ag_cap + j;
+				const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
+				const uint64_t fl = TRACK ? A.agg_out[3 * plane + gid] : 0;
+				commit_seen<W, TRACK>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
+			}
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1329,10 +1345,10 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	const unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8); // one block per tile, dealt XCD-contiguously
 	hipLaunchKernelGGL((k_hist1<W, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.stats);
 	hipLaunchKernelGGL(k_colsum, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(512), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4 + 2), st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4 + 2) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1348,8 +1364,8 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		// rows of level 2 <= records/TILE2 + one ragged row per segment; surplus blocks exit at once
 		const unsigned g2 = (unsigned)(((n_rec_bound / TILE2 + n_seg + 1 + 7) / 8) * 8);
 		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
-		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3(512), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4 + 2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
+		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4 + 2) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
@@ -1373,8 +1389,14 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	if (ev) hipEventRecord(ev[4], st);
 	if (B.agg_out) {
 		const uint64_t slots = (uint64_t)nfine * P.ag_cap;
-		if (P.track) hipLaunchKernelGGL((k_commit<W, true>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, P, A);
-		else hipLaunchKernelGGL((k_commit<W, false>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, P, A);
+		const unsigned gs = (unsigned)((slots + 255) / 256), gw = (unsigned)((nfine + 4 * COMMIT_RPW - 1) / (4 * COMMIT_RPW)); // 4 waves per workgroup
+		if (nfine > (1 << 18)) {
+			if (P.track) hipLaunchKernelGGL((k_commit<W, true, true>), dim3(gw), dim3(256), 0, st, P, A);
+			else hipLaunchKernelGGL((k_commit<W, false, true>), dim3(gw), dim3(256), 0, st, P, A);
+		} else {
+			if (P.track) hipLaunchKernelGGL((k_commit<W, true, false>), dim3(gs), dim3(256), 0, st, P, A);
+			else hipLaunchKernelGGL((k_commit<W, false, false>), dim3(gs), dim3(256), 0, st, P, A);
+		}
 	}
 	if (ev) hipEventRecord(ev[5], st);
 }
@@ -1404,8 +1426,8 @@ int bloom_lds_bytes(const KParams &P)
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, TILE1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE1 * (RW * 4 + 2)); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2)); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, TILE1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE1 * (RW * 4 + 2) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

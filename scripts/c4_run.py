@@ -1,0 +1,84 @@
+"""Configs c4 / c5 of BASELINE.json at full size on ONE MI355X: human-sized genome (3.1 Gbp, bfcgen seed 4) at 30x, 150 bp reads,
+`-s 3g` => k=33, -b37 (16 GiB filter).  190 GB of reads cannot be resident: batches are generated on the host (a thread one batch ahead)
+and submitted with bfcg_count_batch_host, so the wall time is the generator's; the GPU time is the sum of the batches' stage times.
+Checks: the GPU's k-mer count equals the host's formula; c4: table statistics; c5 (--filter-mode 1, k=51): both filters' popcounts.
+
+    python scripts/c4_run.py [--cov 30] [--batch-reads 4194304] [--filter-mode 0|1] [--k 33]
+"""
+import argparse, json, os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bfc_amd
+from bfc_amd import gen
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--k", type=int, default=33)
+ap.add_argument("--b", type=int, default=37)
+ap.add_argument("--G", type=int, default=3_100_000_000)
+ap.add_argument("--cov", type=float, default=30.0)
+ap.add_argument("--seed", type=int, default=4)
+ap.add_argument("--batch-reads", type=int, default=4194304)
+ap.add_argument("--filter-mode", type=int, default=0)
+ap.add_argument("--popcount", type=int, default=0, help="1: bring the filter(s) to the host and count their bits")
+args = ap.parse_args()
+K = args.k
+t0 = time.time()
+rs = gen.ReadSet(seed=args.seed, G=args.G, cov=args.cov)
+stride, n_reads, br = rs.L + 1, rs.n_reads, args.batch_reads
+print("[c4] %d reads of %d bp, genome %d bp (%.1fs)" % (n_reads, rs.L, args.G, time.time() - t0), flush=True)
+g = bfc_amd.GpuCounter(K, args.b, filter_mode=args.filter_mode, max_batch_pos=br * stride)
+print("[c4] context ready (%.1fs)" % (time.time() - t0), flush=True)
+bad_tab = np.ones(256, dtype=bool); bad_tab[np.frombuffer(b"ACGTacgt", dtype=np.uint8)] = False
+
+
+def make(r0):
+    r1 = min(n_reads, r0 + br)
+    seq, qual, off = rs.reads(r0, r1)
+    s = seq.reshape(r1 - r0, rs.L)
+    nk = (r1 - r0) * (rs.L - K + 1)
+    bad = bad_tab[s]
+    for r in np.nonzero(bad.any(axis=1))[0]:  # ~1 % of the reads carry an N
+        run = 0; c = 0
+        for v in bad[r]:
+            run = 0 if v else run + 1
+            c += run >= K
+        nk += c - (rs.L - K + 1)
+    return bfc_amd.to_stream(seq, off), bfc_amd.to_stream(qual, off), nk
+
+
+nxt = {}
+def prefetch(r0):
+    nxt["v"] = make(r0)
+
+n_kmers = 0; gpu_ms = dict(hist1=0.0, scatter1=0.0, level2=0.0, bloom=0.0, commit=0.0, total=0.0)
+cur = make(0)
+t1 = time.perf_counter()
+nb = 0
+for r0 in range(0, n_reads, br):
+    th = None
+    if r0 + br < n_reads:
+        th = threading.Thread(target=prefetch, args=(r0 + br,)); th.start()
+    s, q, nk = cur
+    g.count_host(s, q)
+    n_kmers += nk; nb += 1
+    if th:
+        th.join(); cur = nxt["v"]
+    if nb % 16 == 0:
+        st = g.stats()
+        print("[c4] %d batches, %.1f G k-mers, %.0f s wall; seen %d keys %d table 2^%d slots" % (nb, n_kmers / 1e9, time.perf_counter() - t1, st["n_seen"], st["n_keys"], 20 + st["tab_cshift"] if K <= 36 else 24 + st["tab_cshift"]), flush=True)
+g.sync()
+wall = time.perf_counter() - t1
+st = g.stats()
+ms, nbt = g.stage_ms()
+assert st["n_kmers"] == n_kmers, (st["n_kmers"], n_kmers)
+res = dict(config="c5 (bfc -1 count pass)" if args.filter_mode else "c4", k=K, b=args.b, reads=n_reads, batch_reads=br, batches=nbt, n_kmers=n_kmers, n_seen=st["n_seen"], n_keys=st["n_keys"],
+           slow_buckets=st["slow_buckets"], tab_cshift=st["tab_cshift"], wall_s_generator_bound=round(wall, 1), gpu_stage_ms={k_: round(v, 1) for k_, v in ms.items()},
+           gpu_s=round(ms["total"] / 1e3, 2), G_kmers_per_gpu_s=round(n_kmers / ms["total"] / 1e6, 2), bloom_frac=round(128 * n_kmers / (ms["bloom"] * 1e-3) / 1e9 / 8000, 4))
+if args.popcount:
+    import oracle
+    for which in ([0, 1] if args.filter_mode else [0]):
+        bits = g.bloom_bytes(which)
+        res["bloom%d_popcount" % which] = int(oracle.lib().orc_popcount_bytes(bits.ctypes.data, len(bits)))
+        del bits
+print(json.dumps(res), flush=True)
+g.close()
