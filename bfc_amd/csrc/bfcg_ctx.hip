@@ -86,6 +86,9 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	KParams &P = c->P;
 	P.k = prm->k; P.q = prm->q; P.bf_shift = prm->bf_shift; P.n_hashes = prm->n_hashes; P.filter_mode = prm->filter_mode;
 	P.l_pre = clamp_lpre(prm->k, prm->l_pre);
+	if (!prm->filter_mode && 2 * prm->k < P.l_pre) { // htab.c:49-50 shifts by 2k - l_pre: negative, undefined in the reference itself
+		set_err("k=%d is too small for l_pre=%d: the count table needs 2k >= l_pre (htab.c:45-58)", prm->k, P.l_pre); free(c); return NULL;
+	}
 	// geometry of the bloom kernel; environment overrides are tuning knobs, not semantics
 	{
 		const char *e;
@@ -98,6 +101,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 10) P.F2 = 10; P.F1 = P.F - P.F2; }
 		if (P.F1 > 10) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
+		if (n_ranks > 1 && P.F2 == 0) { // with several ranks level 2 also gathers a bucket's records from the sources' blocks: it must exist
+			if (P.F <= log2n) { set_err("bf_shift=%d gives %d bloom regions: too few for %d ranks", P.bf_shift, 1 << P.F, n_ranks); free(c); return NULL; }
+			P.F1 = (P.F + 1) / 2 > log2n ? (P.F + 1) / 2 : log2n; P.F2 = P.F - P.F1;
+		}
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
 		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 256;
 		// LDS budget: a third of a CU (3 workgroups of 512 threads resident = 24 waves), else half, else all of it -- the first tier that

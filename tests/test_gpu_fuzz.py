@@ -1,0 +1,109 @@
+"""GPU parity under random parameters (-m gpu): k, filter size, number of hashes, l_pre, quality threshold, read lengths, coverage, Ns,
+FASTA/FASTQ, batch cuts, region size and initial table size drawn from a seeded generator; every draw is checked bit for bit against the
+oracle (bloom bitmaps L0, statistics, table L1).  Small inputs, many shapes: one-level and two-level partitions (bf_shift 10..27),
+single-block regions, tables that grow several times, k from 5 to 63."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(seed):
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([5, 9, 13, 17, 21, 25, 27, 29, 31, 32, 33, 35, 39, 47, 48, 55, 63]))
+    b = int(rng.integers(10, 28))
+    nh = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 7, 12]))
+    l_pre = int(rng.choice([v for v in (4, 8, 12, 16, 20) if v <= 2 * k - 2]))  # htab.c:49-50 shifts by 2k - l_pre: the reference needs it positive
+    q = int(rng.choice([0, 10, 20, 30, 41]))
+    fm = int(rng.random() < 0.25)
+    n = int(rng.integers(1, 1500))
+    cov = float(rng.choice([0.5, 2, 8, 40]))
+    lmax = int(rng.choice([3, 40, 151, 600]))
+    lens = rng.integers(0, lmax + 1, n)
+    G = max(64, int(lens.sum() / cov))
+    genome = rng.integers(0, 4, G + lmax + 1)
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
+    seq = np.empty(int(off[-1]), dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for r in range(n):
+        p = int(rng.integers(0, G))
+        seq[int(off[r]):int(off[r + 1])] = acgt[genome[p:p + lens[r]]]
+    if len(seq):
+        err = rng.random(len(seq)) < 0.01
+        seq[err] = acgt[rng.integers(0, 4, int(err.sum()))]
+        seq[rng.random(len(seq)) < 0.002] = ord("N")
+        low = rng.random(len(seq)) < 0.05
+        seq[low] |= 0x20
+    qual = None if rng.random() < 0.2 else rng.integers(33, 75, len(seq)).astype(np.uint8)
+    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 5)))]))
+    kw = {}
+    if rng.random() < 0.3:
+        kw["region_shift"] = int(rng.integers(4, 11))
+    if rng.random() < 0.3:
+        kw["tab_cshift"] = int(rng.integers(1, 4))
+    return dict(k=k, b=b, nh=nh, l_pre=l_pre, q=q, fm=fm), seq, qual, off, cuts, kw
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_configuration(gpu_lib, seed):
+    prm, seq, qual, off, cuts, kw = _draw(1000 + seed)
+    n = len(off) - 1
+    oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
+    oc.count(seq, qual, off)
+    cap = len(seq) + n + 64
+    g = gpu_lib.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"], max_batch_pos=cap, **kw)
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        o = off[a:e + 1] - off[a]
+        s = gpu_lib.to_stream(seq[int(off[a]):int(off[e])], o)
+        qq = gpu_lib.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None
+        g.count_host(s, qq)
+    ost, st = oc.stats(), g.stats()
+    tag = "%r cuts=%r %r" % (prm, cuts, kw)
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"]), tag
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes()), tag
+    if prm["fm"]:
+        assert np.array_equal(g.bloom_bytes(1), oc.bloom_bytes(True)), tag
+    else:
+        sizes, slots = g.export_table().export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl), tag
+    g.close(); oc.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_on_emulated_ranks(gpu_lib, seed):
+    """the same draws through the multi-GPU stages: 2 / 4 / 8 ranks emulated on one device (LocalCluster), ragged rank shares, ranks
+    with nothing to contribute; global batches in rank-major order must equal the sequential oracle"""
+    from bfc_amd import dist as bdist
+    prm, seq, qual, off, cuts, kw = _draw(5000 + seed)
+    rng = np.random.default_rng(seed)
+    world = int(rng.choice([2, 4, 8]))
+    if prm["b"] < 21:
+        prm["b"] = int(rng.integers(21, 27))  # more bloom regions (2^(b-17)) than ranks
+    if qual is None:
+        qual = np.full(len(seq), ord("I"), dtype=np.uint8)
+    n = len(off) - 1
+    oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
+    oc.count(seq, qual, off)
+    cl = bdist.LocalCluster(gpu_lib, world, prm["k"], prm["b"], max_batch_pos=len(seq) + n + 64, q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
+    for a, e in zip(cuts[:-1], cuts[1:]):  # one global batch per cut; its reads are dealt to the ranks in contiguous, uneven shares
+        marks = sorted([a, e] + [int(v) for v in rng.integers(a, e + 1, world - 1)])
+        shares = []
+        for r in range(world):
+            lo, hi = marks[r], marks[r + 1]
+            o = off[lo:hi + 1] - off[lo]
+            shares.append((gpu_lib.to_stream(seq[int(off[lo]):int(off[hi])], o), gpu_lib.to_stream(qual[int(off[lo]):int(off[hi])], o)))
+        cl.batch(shares)
+    st, ost = cl.stats(), oc.stats()
+    tag = "%r world=%d cuts=%r" % (prm, world, cuts)
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"]), tag
+    assert np.array_equal(cl.bloom_bytes(), oc.bloom_bytes()), tag
+    if prm["fm"]:
+        assert np.array_equal(cl.bloom_bytes(1), oc.bloom_bytes(True)), tag
+    else:
+        sizes, slots = cl.export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl), tag
+    cl.close(); oc.close()
