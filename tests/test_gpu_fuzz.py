@@ -107,3 +107,90 @@ def test_random_configuration_on_emulated_ranks(gpu_lib, seed):
         osz, osl = oc.export()
         assert np.array_equal(sizes, osz) and np.array_equal(slots, osl), tag
     cl.close(); oc.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_exact_dump(gpu_lib, seed, tmp_path):
+    """Parity level L2 under random parameters: with order stamps (track_order) the dump file is byte for byte the oracle's, whose khash
+    emulation is pinned to `bfc -E -t1 -d` by the md5 goldens (tests/test_oracle.py) -- any k, l_pre, batching, initial table size."""
+    prm, seq, qual, off, cuts, kw = _draw(9000 + seed)
+    if prm["fm"]:
+        prm["fm"] = 0
+    n = len(off) - 1
+    oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"])
+    oc.count(seq, qual, off)
+    g = gpu_lib.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], max_batch_pos=len(seq) + n + 64, track_order=True, **kw)
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        o = off[a:e + 1] - off[a]
+        g.count_host(gpu_lib.to_stream(seq[int(off[a]):int(off[e])], o), gpu_lib.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None)
+    f_gpu, f_orc = str(tmp_path / "gpu.hash"), str(tmp_path / "orc.hash")
+    t = g.export_table()
+    assert t.dump(f_gpu) == 0
+    oc.dump(f_orc)
+    assert open(f_gpu, "rb").read() == open(f_orc, "rb").read(), "%r cuts=%r %r" % (prm, cuts, kw)
+    t.close(); g.close(); oc.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_trim_pass(gpu_lib, seed):
+    """`bfc -1` under random parameters: count in filter mode on the GPU, then the GPU trim pass; start / end of every read equal the
+    oracle's max_streak + keep rule (correct.c:478-497, 557-569) on the oracle's second filter"""
+    import ctypes as C
+    prm, seq, qual, off, cuts, kw = _draw(13000 + seed)
+    rng = np.random.default_rng(seed)
+    n = len(off) - 1
+    min_frac = float(rng.choice([0.5, 0.9, 0.99]))
+    oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], filter_mode=1)
+    oc.count(seq, qual, off)
+    g = gpu_lib.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], filter_mode=1, max_batch_pos=len(seq) + n + 64)
+    s_seq = gpu_lib.to_stream(seq, off)
+    g.count_host(s_seq, gpu_lib.to_stream(qual, off) if qual is not None else None)
+    bf = g.export_bloom(1)
+    g.close()
+    L = oracle.lib()
+    obf = L.orc_state_bf_high(oc.st)
+    soff = off + np.arange(n + 1, dtype=np.uint64)
+    tr = gpu_lib.GpuTrimmer(prm["k"], bf, max_pos=len(s_seq) + 64, max_reads=n)
+    start, end = tr.trim(s_seq, soff, min_frac)
+    kept = 0
+    for r in range(n):
+        s = seq[int(off[r]):int(off[r + 1])]
+        if len(s) == 0:
+            assert start[r] == -1
+            continue
+        mx = L.orc_max_streak(prm["k"], obf, s.ctypes.data, len(s))
+        a, e = C.c_int(), C.c_int()
+        if L.orc_trim_decide(mx, prm["k"], len(s), min_frac, C.byref(a), C.byref(e)):
+            assert (int(start[r]), int(end[r])) == (a.value, e.value), (r, prm)
+            kept += 1
+        else:
+            assert start[r] == -1, (r, prm)
+    tr.close(); bf.close(); oc.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_kcov(gpu_lib, seed):
+    """bfc_ec_kcov for whole batches under random parameters: table counted on the GPU and kept in HBM, coverage of every base vs orc_kcov
+    (pinned to the reference's own function in tests/test_kcov.py)"""
+    prm, seq, qual, off, cuts, kw = _draw(17000 + seed)
+    rng = np.random.default_rng(seed)
+    min_occ = int(rng.choice([1, 2, 3, 5]))
+    n = len(off) - 1
+    oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"])
+    oc.count(seq, qual, off)
+    L = oracle.lib()
+    want = np.zeros(len(seq), dtype=np.uint16)
+    for r in range(n):
+        a, e = int(off[r]), int(off[r + 1])
+        if e > a:
+            L.orc_kcov(L.orc_state_ch(oc.st), min_occ, seq[a:e].ctypes.data, e - a, want[a:e].ctypes.data)
+    s = gpu_lib.to_stream(seq, off)
+    g = gpu_lib.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], max_batch_pos=len(s) + 64, **kw)
+    g.count_host(s, gpu_lib.to_stream(qual, off) if qual is not None else None)
+    kc = gpu_lib.GpuKcov(g, max_pos=len(s) + 64)
+    got = kc.kcov(s, min_occ) if len(s) else np.zeros(0, dtype=np.uint16)
+    sep = np.asarray(off[1:], dtype=np.int64) + np.arange(n)
+    assert not got[sep].any()
+    keep = np.ones(len(got), dtype=bool); keep[sep] = False
+    assert np.array_equal(got[keep], want), prm
+    kc.close(); g.close(); oc.close()
