@@ -16,8 +16,9 @@ typedef struct {
 	gzFile fp;
 	uint8_t *buf; int begin, end, eof;
 	uint8_t *line; size_t l_line, m_line;
-	int pending;     /* a header line already read into `line` */
-	int failed;
+	int line_nl;     /* the line just read ended with '\n' (0: the input ended first) */
+	int pending;     /* a header line already read into `line`; hdr_at = index of its '>' / '@' */
+	size_t hdr_at;
 } reader_t;
 
 #define RD_BUF (1 << 20)
@@ -35,7 +36,7 @@ static inline int rd_fill(reader_t *r)
 static inline int rd_line(reader_t *r)
 {
 	int got = 0;
-	r->l_line = 0;
+	r->l_line = 0; r->line_nl = 0;
 	for (;;) {
 		uint8_t *p, *q;
 		size_t n;
@@ -48,7 +49,7 @@ static inline int rd_line(reader_t *r)
 		memcpy(r->line + r->l_line, p, n);
 		r->l_line += n;
 		r->begin += (int)n + (q ? 1 : 0);
-		if (q) return 1;
+		if (q) { r->line_nl = 1; return 1; }
 	}
 }
 
@@ -87,39 +88,45 @@ static inline void app(uint8_t **s, size_t *l, size_t *m, const uint8_t *p, size
 	memcpy(*s + *l, p, n); *l += n;
 }
 
-/* parse the next record into ps->seq/qual; 1 = record, 0 = end of input */
+/* kseq_read (kseq.h:185-224) line by line.  Returns 1 = a record in ps->seq/qual (possibly of length 0), 0 = end of input (kseq: -1),
+ * -2 = a FASTQ record whose quality string is missing or of another length (kseq: -2; the caller ends its batch there, the next call
+ * goes on scanning after it, exactly as repeated bseq_read calls do). */
 static inline int next_record(parser_t *ps)
 {
 	reader_t *r = &ps->rd;
-	if (r->failed) return 0;
-	if (!r->pending) { /* jump to the next header line */
+	if (!r->pending) { /* kseq.h:190-194: jump to the next '>' or '@' -- anywhere, not only at the start of a line */
 		for (;;) {
+			uint8_t *a, *b;
 			if (!rd_line(r)) return 0;
-			if (r->l_line && (r->line[0] == '>' || r->line[0] == '@')) break;
+			a = (uint8_t*)memchr(r->line, '>', r->l_line); b = (uint8_t*)memchr(r->line, '@', r->l_line);
+			if (a == 0 || (b != 0 && b < a)) a = b;
+			if (a) { r->hdr_at = (size_t)(a - r->line); break; }
 		}
 	}
 	r->pending = 0;
 	ps->l_seq = ps->l_qual = 0; ps->rec_has_qual = 0;
 	if (ps->keep_hdr) {
-		ps->l_hdr = 0; app(&ps->hdr, &ps->l_hdr, &ps->m_hdr, r->line + 1, r->l_line - 1);
+		ps->l_hdr = 0; app(&ps->hdr, &ps->l_hdr, &ps->m_hdr, r->line + r->hdr_at + 1, r->l_line - r->hdr_at - 1);
 		if (ps->l_hdr > 1 && ps->hdr[ps->l_hdr - 1] == '\r') --ps->l_hdr;
 		ps->hdr[ps->l_hdr] = 0;
 	}
-	for (;;) { /* sequence lines */
-		if (!rd_line(r)) return 1; /* FASTA record ended by EOF */
+	if (r->hdr_at + 1 >= r->l_line && !r->line_nl) return 0; /* kseq.h:195: the input ends right behind the header character */
+	for (;;) { /* sequence lines (kseq.h:201-205): decided by the first character of each line */
+		if (!rd_line(r)) return 1; /* FASTA record ended by the end of the input */
 		if (r->l_line == 0) continue;
-		if (r->line[0] == '>' || r->line[0] == '@') { r->pending = 1; return 1; }
+		if (r->line[0] == '>' || r->line[0] == '@') { r->pending = 1; r->hdr_at = 0; return 1; }
 		if (r->line[0] == '+') break;
 		app(&ps->seq, &ps->l_seq, &ps->m_seq, r->line, r->l_line);
 		if (ps->l_seq > 1 && ps->seq[ps->l_seq - 1] == '\r') --ps->l_seq; /* kseq.h:138 ("\r\n" line ends), on the accumulated string */
 	}
 	ps->rec_has_qual = 1;
-	while (ps->l_qual < ps->l_seq) { /* quality lines (the '+' line itself is already consumed) */
+	if (!r->line_nl) return -2; /* kseq.h:218-219: the input ends inside the '+' line */
+	do { /* quality lines (kseq.h:220): at least one, then until as long as the sequence */
 		if (!rd_line(r)) break;
 		app(&ps->qual, &ps->l_qual, &ps->m_qual, r->line, r->l_line);
 		if (ps->l_qual > 1 && ps->qual[ps->l_qual - 1] == '\r') --ps->l_qual;
-	}
-	if (ps->l_qual != ps->l_seq) { r->failed = 1; return 0; } /* kseq: -2, bseq_read stops */
+	} while (ps->l_qual < ps->l_seq);
+	if (ps->l_qual != ps->l_seq) return -2;
 	return 1;
 }
 
@@ -322,14 +329,17 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 	}
 }
 
-/* fill one batch: reads until at least chunk_size bases (bseq.c:52-76) or the buffer is full */
+/* fill one batch as bseq_read does (bseq.c:52-76): records until at least chunk_size bases, the end of the input or a malformed record
+ * (kseq_read < 0).  A batch without records is the last one (count.c:97-101 ends the pipeline on it), whatever follows in the file. */
 static inline void fill_batch(parser_t *ps, batch_t *b)
 {
 	uint64_t bases = 0;
 	b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0;
 	for (;;) {
 		if (!ps->have_rec) {
-			if (!next_record(ps)) { b->last = 1; return; }
+			int rc = next_record(ps);
+			if (rc == 0) { b->last = 1; return; }
+			if (rc < 0) { if (b->n_seqs == 0) b->last = 1; return; }
 			ps->have_rec = 1;
 		}
 		if (ps->l_seq + 1 > b->cap) {
@@ -342,7 +352,6 @@ static inline void fill_batch(parser_t *ps, batch_t *b)
 		if (bases >= ps->chunk_size) return;
 	}
 }
-
 
 /* ------------------------------------------------------------------ one input: fast path when possible, serial parser otherwise */
 #include <fcntl.h>

@@ -84,7 +84,11 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 		b.n_pos = 0; b.n_seqs = 0; l_hdrs = 0;
 		off[0] = 0;
 		for (;;) {
-			if (!ps.have_rec) { if (!next_record(&ps)) { last = 1; break; } ps.have_rec = 1; }
+			if (!ps.have_rec) { /* bseq_read (bseq.c:52-76): the batch ends at the end of the input or at a malformed record; an empty batch is the last */
+				int rc = next_record(&ps);
+				if (rc <= 0) { if (rc == 0 || n == 0) last = 1; break; }
+				ps.have_rec = 1;
+			}
 			if (ps.l_seq + 1 > b.cap) { fprintf(stderr, "[E::%s] a read of %zu bases does not fit a GPU batch\n", __func__, ps.l_seq); abort(); }
 			if (n == max_reads || !batch_put(&b, ps.seq, ps.rec_has_qual ? ps.qual : 0, ps.l_seq)) break;
 			ps.have_rec = 0;

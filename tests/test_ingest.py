@@ -118,3 +118,64 @@ def test_gzip_and_small_batches(gpu_lib, tmp_path):
     # a batch buffer smaller than a chunk: the capacity cuts the batches, identically for both parsers
     c0, c4 = _digest(gpu_lib, fn, 1 << 30, 0, cap=50000), _digest(gpu_lib, fn, 1 << 30, 4, cap=50000)
     assert c0[:6] == c4[:6] and c0[0] > 5
+
+
+def _mutate(rng, data):
+    """random damage to a FASTA/FASTQ text: lines dropped, doubled, split, emptied, junk with '@' '>' '+' inside, CRLF, truncation"""
+    lines = data.split(b"\n")
+    for _ in range(int(rng.integers(1, 12))):
+        if len(lines) < 3:
+            break
+        i = int(rng.integers(0, len(lines)))
+        op = int(rng.integers(0, 10))
+        if op == 0:
+            del lines[i]
+        elif op == 1:
+            lines.insert(i, lines[i])
+        elif op == 2:
+            lines.insert(i, b"")
+        elif op == 3:
+            lines.insert(i, bytes(rng.choice(np.frombuffer(b"ACGT@>+ xyz\t", dtype=np.uint8), int(rng.integers(1, 30)))))
+        elif op == 4 and len(lines[i]) > 2:
+            c = int(rng.integers(1, len(lines[i])))
+            lines[i:i + 1] = [lines[i][:c], lines[i][c:]]
+        elif op == 5:
+            lines[i] = lines[i] + b"\r"
+        elif op == 6 and len(lines[i]) > 1:
+            lines[i] = lines[i][:int(rng.integers(0, len(lines[i])))]
+        elif op == 7:
+            lines[i] = lines[i] + bytes(rng.choice(np.frombuffer(b"ACGTI#@", dtype=np.uint8), int(rng.integers(1, 9))))
+        elif op == 8:
+            lines[i] = (b">" if rng.random() < 0.5 else b"@") + lines[i]
+        else:
+            lines[i] = b"+" + lines[i]
+    out = b"\n".join(lines)
+    if rng.random() < 0.3:
+        out = out[:int(rng.integers(0, len(out) + 1))]
+    return out
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(240))
+def test_damaged_inputs_parse_like_the_reference(gpu_lib, tmp_path, seed):
+    """Whatever the text, both parsers cut the batches bseq_read cuts (kseq's grammar incl. its error returns: a record with a bad
+    quality string ends the batch, the next call goes on behind it; an empty batch ends the input)."""
+    rng = np.random.default_rng(seed)
+    kind = seed % 3
+    if kind == 0:
+        data = _fastq(rng, int(rng.integers(1, 400)), 1, 120, crlf=rng.random() < 0.2)
+    elif kind == 1:
+        data = b"".join(b">f%d x\n" % r + rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(0, 200))).tobytes() + b"\n" for r in range(int(rng.integers(1, 300))))
+    else:
+        data = _fastq(rng, 150, 10, 80) + b">fa\nACGTTGCA\nAC\n" + _fastq(rng, 150, 10, 80)
+    fn = str(tmp_path / "d.fq")
+    for rep in range(6):
+        text = _mutate(rng, data)
+        open(fn, "wb").write(text)
+        for chunk in (300, 5000, 1 << 30):
+            want = _ref_digest(fn, chunk)[:6]
+            for threads in (0, 3):
+                got = _digest(gpu_lib, fn, chunk, threads)[:6]
+                if got != want:
+                    open("/tmp/ingest_fail.fq", "wb").write(text)
+                assert got == want, (seed, rep, chunk, threads)
