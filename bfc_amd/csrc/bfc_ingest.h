@@ -15,6 +15,7 @@
 typedef struct {
 	gzFile fp;
 	uint8_t *buf; int begin, end, eof;
+	uint64_t total;  /* bytes delivered by gzread so far */
 	uint8_t *line; size_t l_line, m_line;
 	int line_nl;     /* the line just read ended with '\n' (0: the input ended first) */
 	int pending;     /* a header line already read into `line`; hdr_at = index of its '>' / '@' */
@@ -30,6 +31,7 @@ static inline int rd_fill(reader_t *r)
 	r->end = gzread(r->fp, r->buf, RD_BUF);
 	if (r->end < RD_BUF) r->eof = 1;
 	if (r->end < 0) r->end = 0;
+	r->total += (uint64_t)r->end;
 	return r->end;
 }
 /* next line without its '\n' into r->line; returns 0 at end of input */
@@ -117,7 +119,10 @@ static inline int next_record(parser_t *ps)
 		if (r->line[0] == '>' || r->line[0] == '@') { r->pending = 1; r->hdr_at = 0; return 1; }
 		if (r->line[0] == '+') break;
 		app(&ps->seq, &ps->l_seq, &ps->m_seq, r->line, r->l_line);
-		if (ps->l_seq > 1 && ps->seq[ps->l_seq - 1] == '\r') --ps->l_seq; /* kseq.h:138 ("\r\n" line ends), on the accumulated string */
+		/* kseq.h:138 ("\r\n" line ends), on the accumulated string -- except where kseq returns before it gets there: the line's first
+		 * character was the last byte of the input and its 16 KiB stream buffer already knew (kseq.h:97; it knows unless the input's
+		 * length is a multiple of the buffer size) */
+		if (ps->l_seq > 1 && ps->seq[ps->l_seq - 1] == '\r' && !(r->l_line == 1 && !r->line_nl && r->total % 16384 != 0)) --ps->l_seq;
 	}
 	ps->rec_has_qual = 1;
 	if (!r->line_nl) return -2; /* kseq.h:218-219: the input ends inside the '+' line */
