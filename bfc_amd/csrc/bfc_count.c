@@ -98,10 +98,10 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	 * batches grow with the filter (x4 for -b35, x16 for -b37 as `-s 3g` sets it); batch boundaries never change results */
 	if (opt->bf_shift > 33) cap <<= opt->bf_shift - 33;
 	if ((env = getenv("BFC_GPU_BATCH")) != 0) cap = strtoull(env, 0, 10);
-	if (cap < (1u << 16)) cap = 1u << 16;
 	if (cap > (1ULL << 32) - (1ULL << 27)) cap = (1ULL << 32) - (1ULL << 27);
-	bases = cap;
-	cap += cap / 64 + (1u << 20);
+	bases = cap;                 /* the batch boundary is bseq_read's: the read that brings a batch to `bases` is its last */
+	if (cap < (1u << 16)) cap = 1u << 16;
+	cap += cap / 64 + (1u << 20); /* separators, and the read that crosses the boundary */
 	if (cap >= (1ULL << 32)) cap = (1ULL << 32) - 1;
 	prm.max_batch_pos = cap;
 	timing = getenv("BFC_GPU_TIMING") != 0; /* phase times on stderr */
@@ -112,7 +112,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 
 	/* parser threads: -t (the count itself needs no host threads), BFC_GPU_IO_THREADS overrides; 0 = serial parser only */
 	io_threads = (env = getenv("BFC_GPU_IO_THREADS")) ? atoi(env) : opt->n_threads > 1 ? opt->n_threads : 0;
-	if (ingest_open(&ps, fn, bases, io_threads) != 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
+	if (ingest_open(&ps, fn, bases, io_threads, opt->no_mt_io ? 1 : 2) != 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
 
 	memset(&pp, 0, sizeof(pp));
 	pp.ps = &ps;
@@ -135,9 +135,9 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 			pthread_mutex_unlock(&pp.mtx);
 		}
 		t_wait += now_real() - tt; tt = now_real();
+		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs); /* count.c:99, once per bseq_read call */
 		if (b->n_seqs) {
 			double rt, eff;
-			fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs);
 			if (bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos) != 0) {
 				fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort();
 			}
@@ -149,7 +149,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 				fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, b->n_seqs);
 		}
 		t_submit += now_real() - tt;
-		if (b->last) break;
+		if (b->last) break; /* the last of the pipeline workers has got an empty batch */
 		if (!opt->no_mt_io) {
 			pthread_mutex_lock(&pp.mtx);
 			pp.ready[cur] = 0;
@@ -181,7 +181,7 @@ int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_t
 	uint64_t hs = 0xcbf29ce484222325ULL, hq = hs, hb = hs, i;
 	const int no_hash = getenv("BFC_INGEST_NOHASH") != 0; /* timing the parsers alone (scripts/ingest_rate.py) */
 	memset(out, 0, 7 * sizeof(uint64_t));
-	if (ingest_open(&in, fn, chunk_size, n_threads) != 0) return -1;
+	if (ingest_open(&in, fn, chunk_size, n_threads, 1) != 0) return -1; /* one worker: the first empty batch ends the input, as a plain bseq_read loop does */
 	memset(&b, 0, sizeof(b));
 	b.cap = cap; b.seq = (uint8_t*)malloc(cap); b.qual = (uint8_t*)malloc(cap);
 	for (;;) {

@@ -269,7 +269,7 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 			j->first = i == 0; j->at_eof = at_eof;
 			if (j->lo >= wend) { T = i; break; }
 		}
-		if (T == 0) { b->last = 1; return 1; } /* nothing left */
+		if (T == 0) return 1; /* nothing left: an empty batch */
 		fq_run(f, fq_scan, T);
 		/* chain the walks */
 		for (i = 0; i < T && !cut; ++i) { /* records before the first thing that is not strict are still one chained walk */
@@ -328,14 +328,13 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 				else { fq_strict(f->map + last_hdr, f->map + wend, at_eof, 0, f->map, &nx); f->pos = (uint64_t)(nx - f->map); }
 			} else f->pos = cur;
 		}
-		if (f->pos >= f->size) b->last = 1;
 		if (bases > 0) f->bytes_per_base = (double)(f->pos - pos0) / (double)bases;
 		return 1;
 	}
 }
 
 /* fill one batch as bseq_read does (bseq.c:52-76): records until at least chunk_size bases, the end of the input or a malformed record
- * (kseq_read < 0).  A batch without records is the last one (count.c:97-101 ends the pipeline on it), whatever follows in the file. */
+ * (kseq_read < 0) */
 static inline void fill_batch(parser_t *ps, batch_t *b)
 {
 	uint64_t bases = 0;
@@ -343,8 +342,7 @@ static inline void fill_batch(parser_t *ps, batch_t *b)
 	for (;;) {
 		if (!ps->have_rec) {
 			int rc = next_record(ps);
-			if (rc == 0) { b->last = 1; return; }
-			if (rc < 0) { if (b->n_seqs == 0) b->last = 1; return; }
+			if (rc <= 0) return; /* the caller counts empty batches (ingest_fill) */
 			ps->have_rec = 1;
 		}
 		if (ps->l_seq + 1 > b->cap) {
@@ -368,13 +366,16 @@ typedef struct {
 	parser_t ps;
 	fq_fast_t fast;
 	int fast_batches, serial_batches;
+	int workers, empties; /* the reference's pipeline has 2 workers (1 with -J), each goes on until ITS bseq_read returns nothing
+	                       * (kthread.c:88-106, count.c:97-101,143): the input ends with the workers-th empty batch, not the first */
 } ingest_t;
 
 /* 0 on success; the gz stream is always opened (it is the fallback and the only way for gzip / stdin / FASTA input) */
-static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size, int n_threads)
+static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size, int n_threads, int workers)
 {
 	memset(in, 0, sizeof(*in));
 	in->ps.chunk_size = chunk_size;
+	in->workers = workers < 1 ? 1 : workers;
 	in->ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
 	if (in->ps.rd.fp == 0) return -1;
 	gzbuffer(in->ps.rd.fp, 1 << 18);
@@ -401,13 +402,17 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 
 static inline void ingest_fill(ingest_t *in, batch_t *b)
 {
+	int done = 0;
 	if (in->fast.active) {
-		if (fq_fill_batch(&in->fast, b, in->ps.chunk_size)) { ++in->fast_batches; return; }
-		in->fast.active = 0; /* not strict 4-line FASTQ from here on: the serial parser takes over at the last record boundary */
-		gzseek(in->ps.rd.fp, (z_off_t)in->fast.pos, SEEK_SET);
+		if (fq_fill_batch(&in->fast, b, in->ps.chunk_size)) { if (b->n_seqs) ++in->fast_batches; done = 1; }
+		else {
+			in->fast.active = 0; /* not strict 4-line FASTQ from here on: the serial parser takes over at the last record boundary */
+			gzseek(in->ps.rd.fp, (z_off_t)in->fast.pos, SEEK_SET);
+		}
 	}
-	fill_batch(&in->ps, b);
-	++in->serial_batches;
+	if (!done) { fill_batch(&in->ps, b); if (b->n_seqs) ++in->serial_batches; }
+	b->last = 0;
+	if (b->n_seqs == 0 && ++in->empties >= in->workers) b->last = 1;
 }
 
 static inline void ingest_close(ingest_t *in)

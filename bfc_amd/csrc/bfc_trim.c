@@ -78,6 +78,7 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	ri = (rinfo_t*)malloc(max_reads * sizeof(rinfo_t));
 	if (!b.seq || !b.qual || !off || !st || !en || !ri) { fprintf(stderr, "[E::%s] out of memory\n", __func__); abort(); }
 
+	int empties = 0;
 	for (;;) { /* one batch: parse (keeping headers), trim on the GPU, print */
 		uint64_t bases = 0, r, n = 0;
 		int last = 0;
@@ -86,7 +87,7 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 		for (;;) {
 			if (!ps.have_rec) { /* bseq_read (bseq.c:52-76): the batch ends at the end of the input or at a malformed record; an empty batch is the last */
 				int rc = next_record(&ps);
-				if (rc <= 0) { if (rc == 0 || n == 0) last = 1; break; }
+				if (rc <= 0) break;
 				ps.have_rec = 1;
 			}
 			if (ps.l_seq + 1 > b.cap) { fprintf(stderr, "[E::%s] a read of %zu bases does not fit a GPU batch\n", __func__, ps.l_seq); abort(); }
@@ -104,8 +105,9 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 			bases += ps.l_seq;
 			if (bases >= ps.chunk_size) break;
 		}
+		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_ec_cb", (int)n); /* correct.c:582, once per bseq_read call */
+		if (n == 0 && ++empties >= (opt->no_mt_io ? 1 : 2)) last = 1; /* each of the pipeline's workers ends on its own empty batch (kthread.c:88-106, correct.c:644) */
 		if (n) {
-			fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_ec_cb", (int)n);
 			if (bfcg_trim_batch(tr, b.seq, 0, b.n_pos, off, n, opt->min_frac, st, en) != 0) {
 				fprintf(stderr, "[E::%s] GPU trim pass failed: %s\n", __func__, bfcg_last_error()); abort();
 			}

@@ -187,3 +187,34 @@ def test_dropin_exact_dump_md5(g1_fq, tmp_path):
                        env=dict(os.environ, BFC_GPU_EXACT_DUMP="1"))
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert oracle.md5_file(dump) == "d686549d10dd4c71243269013119784a"
+
+
+REFBIN = os.path.join(oracle.REF_DIR, "bfc-ref")
+
+
+@needs_dropin
+@pytest.mark.skipif(not os.path.exists(REFBIN), reason="oracle/_ref/bfc-ref not built")
+@pytest.mark.parametrize("seed", range(8))
+def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
+    """End to end through the reference's own main(): damaged FASTQ / FASTA text (dropped, doubled, split, junk lines, CRLF, truncation)
+    -> `bfc -E -d` with the GPU count path (serial parser with -t1, multi-threaded one with -t4) writes the very bytes the reference
+    binary writes with -t1 (BFC_GPU_EXACT_DUMP=1), for two chunk sizes."""
+    from test_ingest import _fastq, _mutate
+    rng = np.random.default_rng(100 + seed)
+    data = _fastq(rng, 3000, 20, 160, crlf=seed == 3) if seed % 2 == 0 else _fastq(rng, 1500, 20, 160) + b">fa x\nACGTTGCAACGTTTGACCA\nACGGGT\n" + _fastq(rng, 1500, 20, 160)
+    fn = str(tmp_path / "d.fq")
+    open(fn, "wb").write(_mutate(rng, data))
+    env = dict(os.environ, BFC_GPU_EXACT_DUMP="1")
+    for chunk in ("100000000", "50000"):
+        ref_dump = str(tmp_path / "ref.hash")
+        r = subprocess.run([REFBIN, "-E", "-k", "21", "-b", "24", "-t", "1", "-L", chunk, "-d", ref_dump, fn], capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        for t in ("1", "4"):
+            gpu_dump = str(tmp_path / ("gpu%s.hash" % t))
+            g = subprocess.run([DROPIN, "-E", "-k", "21", "-b", "24", "-t", t, "-L", chunk, "-d", gpu_dump, fn], capture_output=True, timeout=600, env=env)
+            assert g.returncode == 0, g.stderr.decode()[-800:]
+            assert open(gpu_dump, "rb").read() == open(ref_dump, "rb").read(), (seed, chunk, t)
+            # the progress lines (reads per batch) are the reference's too
+            want = [l for l in r.stderr.decode().splitlines() if l.startswith("[M::bfc_count_cb] read")]
+            got = [l for l in g.stderr.decode().splitlines() if l.startswith("[M::bfc_count_cb] read")]
+            assert got == want, (seed, chunk, t)
