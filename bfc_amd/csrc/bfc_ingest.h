@@ -78,7 +78,10 @@ static inline int batch_put(batch_t *b, const uint8_t *s, const uint8_t *q, size
 typedef struct {
 	reader_t rd;
 	uint8_t *seq, *qual; size_t l_seq, m_seq, l_qual, m_qual; /* record being assembled */
-	uint8_t *hdr; size_t l_hdr, m_hdr;  /* header line of the record without its '>' / '@' (name [whitespace comment]) */
+	uint8_t *hdr; size_t l_hdr, m_hdr;  /* name of the record (kseq_t.name): the header up to the first white space */
+	uint8_t *cmt; size_t l_cmt, m_cmt;  /* kseq_t.comment: the rest of the LAST header line that had one -- kseq leaves it untouched when a
+	                                     * header has no comment, and bseq_read copies whatever is there (bseq.c:64) */
+	int have_cmt;                       /* comment.s != NULL */
 	int keep_hdr;
 	int have_rec, rec_has_qual;
 	uint64_t chunk_size;
@@ -107,10 +110,17 @@ static inline int next_record(parser_t *ps)
 	}
 	r->pending = 0;
 	ps->l_seq = ps->l_qual = 0; ps->rec_has_qual = 0;
-	if (ps->keep_hdr) {
-		ps->l_hdr = 0; app(&ps->hdr, &ps->l_hdr, &ps->m_hdr, r->line + r->hdr_at + 1, r->l_line - r->hdr_at - 1);
-		if (ps->l_hdr > 1 && ps->hdr[ps->l_hdr - 1] == '\r') --ps->l_hdr;
-		ps->hdr[ps->l_hdr] = 0;
+	if (ps->keep_hdr) { /* kseq.h:195-196: name = up to the first isspace() character; unless that was the line end, comment = the rest */
+		const uint8_t *h = r->line + r->hdr_at + 1;
+		const size_t lh = r->l_line - r->hdr_at - 1;
+		size_t j = 0;
+		while (j < lh && !(h[j] == ' ' || (h[j] >= '\t' && h[j] <= '\r'))) ++j;
+		ps->l_hdr = 0; app(&ps->hdr, &ps->l_hdr, &ps->m_hdr, h, j); ps->hdr[ps->l_hdr] = 0;
+		if (j < lh) { /* a delimiter other than '\n' (a '\r' of a "\r\n" line end counts: the comment is then the empty string) */
+			ps->l_cmt = 0; app(&ps->cmt, &ps->l_cmt, &ps->m_cmt, h + j + 1, lh - j - 1);
+			if (ps->l_cmt > 1 && ps->cmt[ps->l_cmt - 1] == '\r') --ps->l_cmt;
+			ps->cmt[ps->l_cmt] = 0; ps->have_cmt = 1;
+		}
 	}
 	if (r->hdr_at + 1 >= r->l_line && !r->line_nl) return 0; /* kseq.h:195: the input ends right behind the header character */
 	for (;;) { /* sequence lines (kseq.h:201-205): decided by the first character of each line */
@@ -421,7 +431,7 @@ static inline void ingest_close(ingest_t *in)
 	if (in->fast.map) munmap((void*)in->fast.map, (size_t)in->fast.size);
 	if (in->fast.job) { for (i = 0; i < in->fast.n_threads; ++i) free(in->fast.job[i].rec); free(in->fast.job); }
 	gzclose(in->ps.rd.fp);
-	free(in->ps.rd.buf); free(in->ps.rd.line); free(in->ps.seq); free(in->ps.qual); free(in->ps.hdr);
+	free(in->ps.rd.buf); free(in->ps.rd.line); free(in->ps.seq); free(in->ps.qual); free(in->ps.hdr); free(in->ps.cmt);
 }
 
 #endif

@@ -33,7 +33,7 @@ static double t_cpu(void)
 
 #include "bfc_ingest.h"
 
-typedef struct { uint64_t off_hdr; int l_name; int has_comment, has_qual; } rinfo_t;
+typedef struct { uint64_t off_hdr, off_cmt; int has_comment, has_qual; } rinfo_t; /* name and comment (as bseq_read copied them) in hdrs[] */
 
 void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 {
@@ -44,7 +44,7 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	uint64_t cap, max_reads, *off;
 	int32_t *st, *en;
 	rinfo_t *ri;
-	char *hdrs = 0, *last_comment = 0; size_t l_hdrs, m_hdrs = 0;
+	char *hdrs = 0; size_t l_hdrs, m_hdrs = 0;
 	const char *env;
 	double t0 = (&bfc_real_time && bfc_real_time > 0.) ? bfc_real_time : t_real();
 
@@ -93,14 +93,11 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 			if (ps.l_seq + 1 > b.cap) { fprintf(stderr, "[E::%s] a read of %zu bases does not fit a GPU batch\n", __func__, ps.l_seq); abort(); }
 			if (n == max_reads || !batch_put(&b, ps.seq, ps.rec_has_qual ? ps.qual : 0, ps.l_seq)) break;
 			ps.have_rec = 0;
-			if (l_hdrs + ps.l_hdr + 1 > m_hdrs) { m_hdrs = (l_hdrs + ps.l_hdr + 1) * 2; hdrs = (char*)realloc(hdrs, m_hdrs); }
+			if (l_hdrs + ps.l_hdr + ps.l_cmt + 2 > m_hdrs) { m_hdrs = (l_hdrs + ps.l_hdr + ps.l_cmt + 2) * 2; hdrs = (char*)realloc(hdrs, m_hdrs); }
 			memcpy(hdrs + l_hdrs, ps.hdr, ps.l_hdr + 1);
-			{ /* name = up to the first white space, comment = the rest of the line (kseq.h:196-197) */
-				size_t j = 0;
-				while (j < ps.l_hdr && !isspace(ps.hdr[j])) ++j;
-				ri[n].off_hdr = l_hdrs; ri[n].l_name = (int)j; ri[n].has_comment = j < ps.l_hdr; ri[n].has_qual = ps.rec_has_qual;
-			}
-			l_hdrs += ps.l_hdr + 1;
+			ri[n].off_hdr = l_hdrs; l_hdrs += ps.l_hdr + 1;
+			ri[n].has_comment = ps.have_cmt; ri[n].has_qual = ps.rec_has_qual; ri[n].off_cmt = l_hdrs;
+			if (ps.have_cmt) { memcpy(hdrs + l_hdrs, ps.cmt, ps.l_cmt + 1); l_hdrs += ps.l_cmt + 1; } /* bseq.c:64: whatever kseq's comment buffer holds now */
 			off[++n] = b.n_pos;
 			bases += ps.l_seq;
 			if (bases >= ps.chunk_size) break;
@@ -115,13 +112,10 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 			for (r = 0; r < n; ++r) { /* correct.c:595-611 */
 				char *h = hdrs + ri[r].off_hdr;
 				int is_fq = ri[r].has_qual && !opt->no_qual;
-				/* a record without a comment inherits the last comment read (kseq leaves comment.s untouched and bseq_read
-				 * strdup()s it, bseq.c:64): reproduced, because the output must be byte-identical */
-				if (ri[r].has_comment) { free(last_comment); last_comment = strdup(h + ri[r].l_name + 1); }
 				if (st[r] < 0) continue;
 				putchar(is_fq ? '@' : '>');
-				fwrite(h, 1, (size_t)ri[r].l_name, stdout);
-				if (last_comment) { putchar('\t'); fputs(last_comment, stdout); }
+				fputs(h, stdout);
+				if (ri[r].has_comment) { putchar('\t'); fputs(hdrs + ri[r].off_cmt, stdout); }
 				putchar('\n');
 				fwrite(b.seq + off[r] + st[r], 1, (size_t)(en[r] - st[r]), stdout); putchar('\n');
 				if (is_fq) { puts("+"); fwrite(b.qual + off[r] + st[r], 1, (size_t)(en[r] - st[r]), stdout); putchar('\n'); }
@@ -131,6 +125,6 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	}
 	bfcg_trim_destroy(tr);
 	gzclose(ps.rd.fp);
-	free(ps.rd.buf); free(ps.rd.line); free(ps.seq); free(ps.qual); free(ps.hdr);
-	bfcg_host_free(b.seq); free(b.qual); free(off); free(st); free(en); free(ri); free(hdrs); free(last_comment);
+	free(ps.rd.buf); free(ps.rd.line); free(ps.seq); free(ps.qual); free(ps.hdr); free(ps.cmt);
+	bfcg_host_free(b.seq); free(b.qual); free(off); free(st); free(en); free(ri); free(hdrs);
 }

@@ -218,3 +218,39 @@ def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
             want = [l for l in r.stderr.decode().splitlines() if l.startswith("[M::bfc_count_cb] read")]
             got = [l for l in g.stderr.decode().splitlines() if l.startswith("[M::bfc_count_cb] read")]
             assert got == want, (seed, chunk, t)
+
+
+@pytest.mark.skipif(not (os.path.exists(GPUTRIM) and os.path.exists(REFBIN)), reason="oracle/_ref/bfc-dropin-gputrim / bfc-ref not built")
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_trim_equals_reference_binary_on_damaged_files(tmp_path, seed):
+    """`bfc -1` with both phases on the GPU vs the reference binary on damaged FASTQ / FASTA text: stdout (names, inherited comments,
+    FASTA / FASTQ form, trimmed windows) byte for byte, and the `read N sequences` lines of both passes."""
+    from test_ingest import _fastq, _mutate
+    rng = np.random.default_rng(200 + seed)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 20000)
+    eol = b"\r\n" if seed == 5 else b"\n"
+    recs = []
+    for r in range(2500):  # reads of a small genome (8x): most k-mers are seen again, most reads survive the trim
+        l = int(rng.integers(60, 161)); p = int(rng.integers(0, 20000 - l))
+        s_ = genome[p:p + l].copy()
+        if r % 17 == 0:
+            s_[int(rng.integers(0, l))] = ord("N")
+        q = rng.integers(33, 74, l).astype(np.uint8)
+        if r % 3 == 0:
+            q[0] = ord("@")
+        recs.append(b"@r%d%s" % (r, b" cm:%d" % r if r % 4 else b"") + eol + s_.tobytes() + eol + b"+" + eol + q.tobytes() + eol)
+    base = b"".join(recs)
+    # reads drawn twice so that k-mers are seen and some reads survive the trim
+    data = base if seed % 2 == 0 else base[:len(base) // 2] + b">fa only\nACGTTGCAACGTTTGACCAGGTACCATTGACGGTACCAGT\n" + base[len(base) // 2:]
+    fn = str(tmp_path / "d.fq")
+    open(fn, "wb").write(_mutate(rng, data))
+    for extra in ([], ["-L", "40000"], ["-J"]):
+        args = ["-1", "-k", "21", "-b", "24", "-t", "2"] + extra + [fn]
+        r = subprocess.run([REFBIN] + args, capture_output=True, timeout=600)
+        g = subprocess.run([GPUTRIM] + args, capture_output=True, timeout=600)
+        assert r.returncode == 0 and g.returncode == 0, (r.stderr.decode()[-500:], g.stderr.decode()[-500:])
+        assert g.stdout == r.stdout, (seed, extra, len(g.stdout), len(r.stdout))
+        want = [l for l in r.stderr.decode().splitlines() if "] read " in l]
+        got = [l for l in g.stderr.decode().splitlines() if "] read " in l]
+        assert got == want, (seed, extra)
+        assert len(r.stdout) > 100000
