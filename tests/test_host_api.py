@@ -122,3 +122,40 @@ def test_kmer_occ_uses_the_strand_canonical_hash(gpu_lib):
     t.insert(int(y[0]), int(y[1]), 1)
     assert t.kmer_occ(xs[0]) == t.kmer_occ(xs[1]) == (1 << 8 | 1)
     t.close()
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(20))
+def test_host_table_interoperates_with_the_reference(gpu_lib, seed, tmp_path):
+    """Random k / l_pre / key sets: a table built by the REFERENCE's own bfc_ch_insert and dumped by its bfc_ch_dump is restored by
+    this library and answers every bfc_ch_get like the reference; the library's dump of it is restored by the reference and answers
+    alike again (htab.c:60-92, 129-176 in both directions)."""
+    R = oracle.ref()
+    R.bfc_ch_init.restype = C.c_void_p; R.bfc_ch_init.argtypes = [C.c_int, C.c_int]
+    R.bfc_ch_insert.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int]
+    R.bfc_ch_dump.argtypes = [C.c_void_p, C.c_char_p]
+    R.bfc_ch_restore.restype = C.c_void_p; R.bfc_ch_restore.argtypes = [C.c_char_p]
+    R.bfc_ch_destroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(37, 64)) if seed == 0 else int(rng.integers(11, 37))  # k >= 37 clamps l_pre to 24 (htab.c:24-26): 16 M khash tables, once
+    l_pre = int(rng.choice([v for v in (4, 8, 12, 16, 16, 20) if v <= 2 * k - 2]))
+    m = (1 << k) - 1
+    n = int(rng.integers(1, 4000))
+    ys = [(int(a) & m, int(b) & m) for a, b in zip(rng.integers(0, 2 ** 63, n, dtype=np.int64), rng.integers(0, 2 ** 63, n, dtype=np.int64))]
+    rt = R.bfc_ch_init(k, l_pre)
+    for i, (a, b) in enumerate(ys):
+        for _ in range(int(rng.integers(1, 4)) if i % 50 else 300):  # a few keys saturate
+            R.bfc_ch_insert(rt, (C.c_uint64 * 2)(a, b), int(rng.integers(0, 2)), 0)
+    f1, f2 = str(tmp_path / "ref.hash").encode(), str(tmp_path / "mine.hash").encode()
+    assert R.bfc_ch_dump(rt, f1) == 0
+    t = gpu_lib.HostTable.restore(f1.decode())
+    probes = ys + [(int(a) & m, int(b) & m) for a, b in zip(rng.integers(0, 2 ** 63, 500, dtype=np.int64), rng.integers(0, 2 ** 63, 500, dtype=np.int64))]
+    for a, b in probes:
+        assert t.get(a, b) == R.bfc_ch_get(rt, (C.c_uint64 * 2)(a, b)), (k, l_pre, a, b)
+    assert t.count() == R.bfc_ch_count(rt)
+    assert t.dump(f2.decode()) == 0
+    rt2 = R.bfc_ch_restore(f2)
+    for a, b in probes:
+        assert R.bfc_ch_get(rt2, (C.c_uint64 * 2)(a, b)) == R.bfc_ch_get(rt, (C.c_uint64 * 2)(a, b))
+    assert R.bfc_ch_count(rt2) == R.bfc_ch_count(rt)
+    R.bfc_ch_destroy(rt); R.bfc_ch_destroy(rt2); t.close()
