@@ -246,6 +246,7 @@ static void *fq_copy(void *arg)
 typedef struct {
 	const uint8_t *map; uint64_t size, pos; /* pos: next record boundary */
 	int n_threads, active;
+	uint64_t min_slice;    /* bytes a thread's slice has at least (65536; tests lower it to chain walks inside small files) */
 	double bytes_per_base; /* of the batches so far: sizes the next window */
 	fq_job_t *job;
 } fq_fast_t;
@@ -271,7 +272,7 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 		const int at_eof = wend == f->size;
 		int T = f->n_threads, i, n_used = 0, cut = 0, bad = 0;
 		uint64_t slice, cur = f->pos, bases = 0, npos = 0, nseq = 0;
-		if (wend - f->pos < (uint64_t)T * 65536) T = 1;
+		if (wend - f->pos < (uint64_t)T * f->min_slice) T = 1;
 		slice = (wend - f->pos + T - 1) / T;
 		for (i = 0; i < T; ++i) {
 			fq_job_t *j = &f->job[i];
@@ -401,6 +402,8 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 					(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
 					in->fast.map = p; in->fast.size = (uint64_t)st.st_size; in->fast.pos = 0; in->fast.active = 1;
 					in->fast.n_threads = n_threads > FQ_MAX_THREADS ? FQ_MAX_THREADS : n_threads;
+					in->fast.min_slice = getenv("BFC_INGEST_MIN_SLICE") ? strtoull(getenv("BFC_INGEST_MIN_SLICE"), 0, 10) : 65536;
+					if (in->fast.min_slice < 16) in->fast.min_slice = 16;
 					in->fast.job = (fq_job_t*)calloc((size_t)in->fast.n_threads, sizeof(fq_job_t));
 				} else munmap(m, (size_t)st.st_size);
 			}

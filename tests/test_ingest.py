@@ -99,6 +99,12 @@ def test_parsers_agree(gpu_lib, tmp_path, case):
             assert fast[:6] == serial[:6], (case, chunk, threads)
         if case in ("plain", "crlf", "no_final_newline", "trailing_blank_lines", "long_reads", "tiny_reads") and serial[0]:
             assert fast[6] == serial[0], "every batch of a strict FASTQ comes from the fast path"
+            os.environ["BFC_INGEST_MIN_SLICE"] = "64"  # 8 walks inside every batch, however small
+            try:
+                tiny = _digest(gpu_lib, fn, chunk, 8)
+            finally:
+                os.environ.pop("BFC_INGEST_MIN_SLICE", None)
+            assert tiny[:6] == serial[:6] and tiny[6] == serial[0], (case, chunk)
         if case == "strict_then_multiline" and chunk == 20000:
             assert 0 < fast[6] < serial[0], "fast path until the wrapped record, serial parser from there"
         if case in ("multiline", "fasta"):
@@ -174,8 +180,13 @@ def test_damaged_inputs_parse_like_the_reference(gpu_lib, tmp_path, seed):
         open(fn, "wb").write(text)
         for chunk in (300, 5000, 1 << 30):
             want = _ref_digest(fn, chunk)[:6]
-            for threads in (0, 3):
-                got = _digest(gpu_lib, fn, chunk, threads)[:6]
+            for threads, min_slice in ((0, None), (3, None), (5, "64")):  # the last: walks of a few records each, chained across junk
+                if min_slice:
+                    os.environ["BFC_INGEST_MIN_SLICE"] = min_slice
+                try:
+                    got = _digest(gpu_lib, fn, chunk, threads)[:6]
+                finally:
+                    os.environ.pop("BFC_INGEST_MIN_SLICE", None)
                 if got != want:
                     open("/tmp/ingest_fail.fq", "wb").write(text)
-                assert got == want, (seed, rep, chunk, threads)
+                assert got == want, (seed, rep, chunk, threads, min_slice)
