@@ -285,7 +285,15 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 		/* chain the walks */
 		for (i = 0; i < T && !cut; ++i) { /* records before the first thing that is not strict are still one chained walk */
 			fq_job_t *j = &f->job[i];
-			if (!j->found) { if (cur < j->hi) { bad = 1; break; } continue; }  /* a record should have started in this slice */
+			if (!j->found) {
+				if (cur >= j->hi) continue; /* the previous walk's last record covers this slice */
+				if (at_eof) { /* only line ends left before the end of the file? then the walk simply ended */
+					const uint8_t *t = f->map + cur, *e = f->map + wend;
+					while (t < e && (*t == '\n' || *t == '\r')) ++t;
+					if (t == e) { cur = wend; cut = 1; break; }
+				}
+				bad = 1; break; /* a record should have started in this slice */
+			}
 			if (j->start != cur) { bad = 1; break; }
 			cur = j->end; n_used = i + 1;
 			if (j->status == FQ_CUT) cut = 1;

@@ -4,6 +4,7 @@ bseq_read/kseq (through oracle/_ref/libbfcref.so when it is built).  bfc_ingest_
 import ctypes as C
 import gzip
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -88,7 +89,7 @@ def _make(case, path, rng):
 
 @pytest.mark.parametrize("case", CASES)
 def test_parsers_agree(gpu_lib, tmp_path, case):
-    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    rng = np.random.default_rng(zlib.crc32(case.encode()))  # not hash(): that one changes from run to run
     fn = str(tmp_path / (case + ".fq"))
     size = _make(case, fn, rng)
     for chunk in (20000, 1 << 30) if size < (1 << 22) else (500000,):
