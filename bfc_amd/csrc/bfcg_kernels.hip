@@ -54,7 +54,8 @@ __device__ __forceinline__ void bases16(uint32_t w, int sh, uint32_t &m0, uint32
 __device__ __forceinline__ void quals16(uint32_t w, int sh, int q, uint32_t &mq)
 {
 #pragma unroll
-	for (int b = 0; b < 4; ++b) mq |= (uint32_t)((int)((w >> (8 * b)) & 0xffu) - 33 >= q) << (sh + b);
+	// count.c:85 compares a (signed) char: bytes above 0x7f are negative there, never high quality for a sane -q
+	for (int b = 0; b < 4; ++b) mq |= (uint32_t)((int)(int8_t)((w >> (8 * b)) & 0xffu) - 33 >= q) << (sh + b);
 }
 
 template <int TILE, int BT>
@@ -83,7 +84,7 @@ __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, co
 					uint32_t w = in ? seq[pb] : (uint32_t)'\n', t0m = 0, t1m = 0, tnm = 0;
 					bases16(w | 0x0a0a0a00u, 0, t0m, t1m, tnm);
 					m0 |= (t0m & 1u) << b; m1 |= (t1m & 1u) << b; mn |= (tnm & 1u) << b;
-					mq |= (uint32_t)(qual ? (in && ((int)qual[pb] - 33 >= q)) : 1) << b;
+					mq |= (uint32_t)(qual ? (in && ((int)(int8_t)qual[pb] - 33 >= q)) : 1) << b;
 				}
 			}
 			p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
@@ -98,7 +99,7 @@ __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, co
 			uint32_t ch = in ? seq[pos] : (uint32_t)'\n';
 			uint32_t u = ch & 0xDFu; // fold case
 			uint32_t code = (u == 'A') ? 0u : (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 4u;
-			bool hq = qual ? (in && ((int)qual[pos] - 33 >= q)) : true; // count.c:85
+			bool hq = qual ? (in && ((int)(int8_t)qual[pos] - 33 >= q)) : true; // count.c:85 (signed char)
 			uint64_t b0 = __ballot(code & 1u), b1 = __ballot((code >> 1) & 1u), bn = __ballot(code >> 2), bq = __ballot(hq);
 			if (lane == 0) {
 				planes[0 * PW + 2 * c] = (uint32_t)b0; planes[0 * PW + 2 * c + 1] = (uint32_t)(b0 >> 32);

@@ -374,7 +374,7 @@ int orc_count_read(orc_state_t *st, const uint8_t *seq, const uint8_t *qual, int
 		int c = orc_base_code(seq[i]);
 		if (c < 4) {
 			orc_kmer_push(k, p, c);
-			qmer = ((qmer << 1) | (uint64_t)(qual == 0 || (int)qual[i] - 33 >= st->q)) & m;
+			qmer = ((qmer << 1) | (uint64_t)(qual == 0 || (int)(signed char)qual[i] - 33 >= st->q)) & m; /* count.c:85: s->qual is a char*, signed here */
 			if (++l >= k) {
 				uint64_t y[2], hash = orc_kmer_hash(k, p, y);
 				int is_high = (qmer == m);

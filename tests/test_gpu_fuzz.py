@@ -16,7 +16,7 @@ def _draw(seed):
     b = int(rng.integers(10, 28))
     nh = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 7, 12]))
     l_pre = int(rng.choice([v for v in (4, 8, 12, 16, 20) if v <= 2 * k - 2]))  # htab.c:49-50 shifts by 2k - l_pre: the reference needs it positive
-    q = int(rng.choice([0, 10, 20, 30, 41]))
+    q = int(rng.choice([-50, 0, 10, 20, 30, 41, 94, 100]))
     fm = int(rng.random() < 0.25)
     n = int(rng.integers(1, 1500))
     cov = float(rng.choice([0.5, 2, 8, 40]))
@@ -36,7 +36,7 @@ def _draw(seed):
         seq[rng.random(len(seq)) < 0.002] = ord("N")
         low = rng.random(len(seq)) < 0.05
         seq[low] |= 0x20
-    qual = None if rng.random() < 0.2 else rng.integers(33, 75, len(seq)).astype(np.uint8)
+    qual = None if rng.random() < 0.2 else (rng.integers(0, 256, len(seq)) if rng.random() < 0.25 else rng.integers(33, 75, len(seq))).astype(np.uint8)  # sometimes every byte value
     cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 5)))]))
     kw = {}
     if rng.random() < 0.3:

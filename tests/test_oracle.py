@@ -179,3 +179,26 @@ def test_oracle_vs_live_reference(k, b, nh, fm):
         for row in to[:50]:
             assert o.table_get(int(row[1]), int(row[2])) == r.table_get(int(row[1]), int(row[2]))
     o.close(); r.close()
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("q", [-200, -40, 0, 20, 93, 94, 95, 127])
+def test_quality_threshold_on_every_byte_value(q):
+    """count.c:85 compares `s->qual[i] - 33 >= q` on a (signed) char: quality bytes from 0 to 255 and thresholds from far below to far
+    above the Phred range give the same high-quality flags in the oracle and in the reference."""
+    rng = np.random.default_rng(q + 1000)
+    n, L = 300, 80
+    genome = rng.integers(0, 4, 4000)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    seq = np.concatenate([np.frombuffer(b"ACGT", dtype=np.uint8)[genome[p:p + L]] for p in rng.integers(0, 4000 - L, n)])
+    qual = rng.integers(33, 75, n * L).astype(np.uint8)
+    odd = rng.random(n * L) < 0.03
+    qual[odd] = rng.integers(0, 256, int(odd.sum())).astype(np.uint8)  # a few arbitrary bytes among plausible qualities
+    o = oracle.Counter(21, 20, q=q)
+    r = oracle.Counter(21, 20, q=q, impl="ref")
+    to, tr = o.count(seq, qual, off, trace=True), r.count(seq, qual, off, trace=True)
+    assert np.array_equal(to, tr)
+    assert o.stats() == r.stats()
+    if -40 <= q <= 0:
+        assert 0 < o.stats()["n_high"] < o.stats()["n_kmers"]
+    o.close(); r.close()
