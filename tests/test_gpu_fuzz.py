@@ -36,6 +36,8 @@ def _draw(seed):
         seq[rng.random(len(seq)) < 0.002] = ord("N")
         low = rng.random(len(seq)) < 0.05
         seq[low] |= 0x20
+        odd = rng.random(len(seq)) < 0.003
+        seq[odd] = rng.integers(0, 256, int(odd.sum())).astype(np.uint8)  # any byte at all: everything but ACGTacgt ends a k-mer (bseq.c:9-26)
     qual = None if rng.random() < 0.2 else (rng.integers(0, 256, len(seq)) if rng.random() < 0.25 else rng.integers(33, 75, len(seq))).astype(np.uint8)  # sometimes every byte value
     cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 5)))]))
     kw = {}
