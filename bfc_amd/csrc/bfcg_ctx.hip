@@ -223,12 +223,15 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 {
 	HIPCK(hipSetDevice(c->prm.device));
 	if (c->pend && drain(c) != 0) return -1;
+	// the statistics first: stage A of the next batch (stream stA) adds to them and only has to wait for that small memset; the
+	// filters and the table are touched by stage B alone, on this same stream, so zeroing them needs no host synchronisation
+	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
+	HIPCK(hipEventRecord(c->evCopy, c->st));
+	HIPCK(hipStreamWaitEvent(c->stA, c->evCopy, 0));
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
 	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
 	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
 	if (c->B.tab_first) { HIPCK(hipMemsetAsync(c->B.tab_first, 0xff, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st)); HIPCK(hipMemsetAsync(c->B.sub_last, 0, 8ULL << c->P.l_pre, c->st)); }
-	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
-	HIPCK(hipStreamSynchronize(c->st)); // stage A of the next batch runs on another stream: the zeroing must have landed
 	c->n_batches = 0;
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
 	return 0;
