@@ -132,6 +132,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
+	if (prm->tab_cshift <= 0) // a first batch can create up to half as many keys as it has k-mers: start with a quarter of the batch's positions in slots
+		while ((1ULL << (P.l_pre + P.tab_cshift)) < prm->max_batch_pos / 4 && P.l_pre + P.tab_cshift < 34) ++P.tab_cshift;
 	P.track = (prm->track_order && !prm->filter_mode) ? 1 : 0;
 	// one workgroup per CU (regions of 32 KiB and more: -b36, -b37) runs 1024 threads so that the CU still has 16 waves; no such variant with order stamps
 	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
