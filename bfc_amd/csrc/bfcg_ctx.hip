@@ -470,12 +470,49 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	return finalise_previous(c, b);
 }
 
+// A batch much larger than the filter's regions can take at full speed (list_cap k-mers with clear bits per region) is cut into
+// sub-batches here.  Any byte that is not ACGTacgt is a cut point -- no k-mer spans it (count.c:83,88) -- and batch boundaries never
+// change results, so this is invisible except in speed (every region of an oversized batch takes the exact but slow HBM path).
+static uint64_t split_limit(const bfcg_ctx_t *c)
+{
+	const uint64_t nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
+	return (uint64_t)((double)nfine * (double)c->P.list_cap * 1.15); // positions; ~0.8 k-mers per position
+}
+static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
+// last cut point in (lo, hi]: index just behind a non-ACGT byte, searched backwards from hi over at most 1 MiB; 0 = none
+static uint64_t find_cut(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *d_seq, uint64_t lo, uint64_t hi)
+{
+	const uint64_t win = hi - lo < (1u << 20) ? hi - lo : (1u << 20);
+	const uint8_t *p = h_seq ? h_seq + hi - win : 0;
+	uint8_t *tmp = 0;
+	if (!h_seq) {
+		tmp = (uint8_t *)malloc(win);
+		if (hipMemcpy(tmp, d_seq + hi - win, win, hipMemcpyDeviceToHost) != hipSuccess) { free(tmp); return 0; }
+		p = tmp;
+	}
+	uint64_t cut = 0;
+	for (uint64_t i = win; i > 0; --i) if (!is_acgt(p[i - 1])) { cut = hi - win + i; break; }
+	free(tmp);
+	return cut > lo ? cut : 0;
+}
+
 extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
 {
 	if (c->n_ranks > 1) return set_err("this context is one of %d ranks: use bfcg_mg_scatter / bfcg_mg_process", c->n_ranks);
 	if (n_pos == 0) return 0;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
+	const uint64_t lim = split_limit(c);
+	if (!c->B.seen_out && n_pos > lim + lim / 4) { // oversized for this filter: sub-batches of about `lim` positions
+		uint64_t o = 0;
+		while (n_pos - o > lim + lim / 4) {
+			const uint64_t cut = find_cut(c, 0, d_seq, o, o + lim);
+			if (cut == 0) break; // a megabase without a cut point: take the rest as it is
+			if (bfcg_count_batch_dev(c, d_seq + o, d_qual ? d_qual + o : 0, cut - o) != 0) return -1;
+			o = cut;
+		}
+		if (o) return o < n_pos ? bfcg_count_batch_dev(c, d_seq + o, d_qual ? d_qual + o : 0, n_pos - o) : 0;
+	}
 	int rc = enqueue_batch(c, d_seq, d_qual, n_pos);
 	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c); // debug aids want one batch at a time
 	return rc;
@@ -487,6 +524,17 @@ extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const 
 	if (n_pos == 0) return 0;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
+	const uint64_t lim = split_limit(c);
+	if (!c->B.seen_out && n_pos > lim + lim / 4) { // oversized for this filter: sub-batches (see bfcg_count_batch_dev)
+		uint64_t o = 0;
+		while (n_pos - o > lim + lim / 4) {
+			const uint64_t cut = find_cut(c, h_seq, 0, o, o + lim);
+			if (cut == 0) break;
+			if (bfcg_count_batch_host(c, h_seq + o, h_qual ? h_qual + o : 0, cut - o) != 0) return -1;
+			o = cut;
+		}
+		if (o) return o < n_pos ? bfcg_count_batch_host(c, h_seq + o, h_qual ? h_qual + o : 0, n_pos - o) : 0;
+	}
 	const int b = c->cur;
 	HIPCK(hipMemcpyAsync(c->d_seq2[b], h_seq, n_pos, hipMemcpyHostToDevice, c->stA)); // ordered behind stage A of two batches ago (same stream)
 	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual2[b], h_qual, n_pos, hipMemcpyHostToDevice, c->stA));

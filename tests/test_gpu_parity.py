@@ -143,7 +143,7 @@ def test_tiny_bloom_forces_slow_path(gpu_lib, g1):
     for b in (14, 18):
         oc = oracle.Counter(31, b)
         oc.count(seq, qual, off)
-        g = _gpu_count(gpu_lib, 31, b, seq, qual, off, 1)
+        g = _gpu_count(gpu_lib, 31, b, seq, qual, off, 1, debug_seen=True)  # debug_seen keeps the batch whole (otherwise an oversized batch is cut into sub-batches)
         assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
         assert g.stats()["n_seen"] == oc.stats()["n_seen"]
         sizes, slots = g.export_table().export_sorted()
@@ -308,3 +308,32 @@ def test_largest_filter_b37(gpu_lib, g1, fm):
         osz, osl = oc.export()
         assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
     g.close(); oc.close()
+
+
+def test_oversized_batches_are_cut_into_sub_batches(gpu_lib, g1):
+    """A batch far too large for the filter (here 1 M positions for 2^19 bits) is cut at non-ACGT bytes into sub-batches that the regions
+    take at full speed: same results as the oracle, no region on the slow path -- through the host and the device entry point
+    (device pointers of the parts are not 16-byte aligned)."""
+    rs, (seq, qual, off) = g1
+    oc = oracle.Counter(31, 19)
+    oc.count(seq, qual, off)
+    s, q = gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off)
+    for dev in (False, True):
+        g = gpu_lib.GpuCounter(31, 19, max_batch_pos=len(s) + 64)
+        if dev:
+            d_s = g.dev_alloc(len(s) + 64); d_q = g.dev_alloc(len(q) + 64)
+            g.h2d(d_s, s); g.h2d(d_q, q)
+            g.count_dev(d_s, d_q, len(s))
+        else:
+            g.count_host(s, q)
+        st = g.stats()
+        assert st["n_batches"] > 3 and st["slow_buckets"] == 0
+        assert (st["n_kmers"], st["n_seen"]) == (oc.stats()["n_kmers"], oc.stats()["n_seen"])
+        assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+        sizes, slots = g.export_table().export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+        if dev:
+            g.dev_free(d_s); g.dev_free(d_q)
+        g.close()
+    oc.close()
