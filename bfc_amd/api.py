@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import BfcOpt, BfcgParams, BfcKmer, u64p, u32p, f32p
 
-STAT_NAMES = {0: "n_kmers", 1: "n_high", 2: "n_seen", 3: "n_keys", 4: "tab_ovf", 5: "err_pool", 6: "slow_buckets", 8: "tab_cshift", 9: "n_batches"}
+STAT_NAMES = {0: "n_kmers", 1: "n_high", 2: "n_seen", 3: "n_keys", 4: "tab_ovf", 5: "err_pool", 6: "slow_buckets", 7: "crowded_regions", 8: "tab_cshift", 9: "n_batches"}
 
 
 class BfcGpuError(RuntimeError):
@@ -270,6 +270,7 @@ class GpuCounter:
         out = np.zeros(16, dtype=np.uint64)
         self._ck(self.L.bfcg_stats(self.ctx, out.ctypes.data_as(u64p)))
         d = {STAT_NAMES[i]: int(out[i]) for i in STAT_NAMES}
+        d["stream_batches"] = int(self.L.bfcg_stream_batches(self.ctx))
         d["phase_cycles"] = [int(out[i]) for i in range(10, 16)]  # BFCG_ABLATE&64: k_bloom stage/pass1/pass2/writeback/handover
         return d
 

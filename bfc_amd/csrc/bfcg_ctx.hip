@@ -48,6 +48,9 @@ struct bfcg_ctx {
 	size_t seg_words;
 	uint64_t recv_cap;           // records the level-2 buffers can take
 	uint64_t keys_last, grow[2]; // distinct keys at the last finalised batch; keys added by the last two batches (growth forecast)
+	uint64_t crowded_last;       // ST_CROWDED at the last finalised batch
+	int stream_mode;             // 1: the batches' k-mers hardly repeat -- seen k-mers are streamed to k_commit_stream instead of aggregated
+	uint32_t *stream_out; uint64_t n_stream_batches;
 };
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
@@ -211,6 +214,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
+	(void)hipFree(c->stream_out);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -236,6 +240,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	if (c->B.tab_first) { HIPCK(hipMemsetAsync(c->B.tab_first, 0xff, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st)); HIPCK(hipMemsetAsync(c->B.sub_last, 0, 8ULL << c->P.l_pre, c->st)); }
 	c->n_batches = 0;
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
+	c->crowded_last = 0; c->stream_mode = 0;
 	return 0;
 }
 
@@ -260,6 +265,7 @@ static int table_maintain(bfcg_ctx_t *c);
 static void note_growth(bfcg_ctx_t *c);
 static int finalise_previous(bfcg_ctx_t *c, int b);
 static int table_target_cshift(const bfcg_ctx_t *c);
+static int use_stream(bfcg_ctx_t *c);
 
 static int batch_times(bfcg_ctx_t *c, int b)
 {
@@ -298,6 +304,10 @@ static void note_growth(bfcg_ctx_t *c)
 {
 	const uint64_t keys = c->h_stats[ST_KEYS];
 	c->grow[1] = c->grow[0]; c->grow[0] = keys > c->keys_last ? keys - c->keys_last : 0; c->keys_last = keys;
+	// more than half of the regions filled their aggregation table in the batch(es) just finalised: aggregation does not pay here
+	const uint64_t crowded = c->h_stats[ST_CROWDED], nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
+	if (!c->stream_mode && c->B.table && !c->P.track && c->P.n_hashes == 4 && c->P.bloom_bt == 512 && !getenv("BFCG_NO_STREAM") && (crowded - c->crowded_last) * 2 > nfine) c->stream_mode = 1;
+	c->crowded_last = crowded;
 }
 // sub-table size the table should have now: load <= 1/2 counting parked k-mers and the forecast
 static int table_target_cshift(const bfcg_ctx_t *c)
@@ -421,12 +431,24 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 	HIPCK(hipMemcpyAsync(d, seg_beg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
 	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
+	if (use_stream(c) != 0) return -1;
+	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
 	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
 	HIPCK(hipEventRecord(c->evB[b], c->st));
 	HIPCK(hipGetLastError());
 	c->used[b] = 1;
 	++c->n_batches;
 	return finalise_previous(c, b);
+}
+
+// the hand-over buffer of the STREAM mode is allocated when the mode is first used
+static int use_stream(bfcg_ctx_t *c)
+{
+	if (c->stream_mode) {
+		if (!c->stream_out) HIPCK(hipMalloc(&c->stream_out, c->recv_cap * (uint64_t)c->rw));
+		++c->n_stream_batches;
+	}
+	return 0;
 }
 
 // batch b has just been enqueued: finalise the one before it while b runs
@@ -457,6 +479,8 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	Bt.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1; Bt.recs1 = c->recs1[b];
 	if (c->used[b]) HIPCK(hipStreamWaitEvent(c->stA, c->evB[b], 0)); // stage B two batches ago has released this buffer set
+	if (use_stream(c) != 0) return -1;
+	Bt.stream = c->stream_mode; Bt.stream_out = c->stream_out;
 	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, c->stA, c->evt[b]);
 	HIPCK(hipEventRecord(c->evA[b], c->stA));
 	HIPCK(hipStreamWaitEvent(c->st, c->evA[b], 0));
@@ -577,6 +601,7 @@ extern "C" int bfcg_stage_ms(bfcg_ctx_t *c, double out[6], uint64_t *n_batches, 
 	return 0;
 }
 
+extern "C" uint64_t bfcg_stream_batches(bfcg_ctx_t *c) { return c->n_stream_batches; }
 extern "C" int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[6]) { for (int i = 0; i < 6; ++i) out[i] = c->last_ms[i]; return 0; }
 
 extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)

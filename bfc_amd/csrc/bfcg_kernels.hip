@@ -649,6 +649,7 @@ struct BloomArgs {
 	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
 	uint64_t *agg_out;             // aggregated seen k-mers: three planes [y0 | y1 | count|high<<16] of [n_fine][ag_cap], or NULL = commit inline
 	uint32_t *agg_cnt;             // entries per fine bucket
+	uint32_t *stream_out;          // STREAM mode: seen k-mers as records, region f's at [start[f], start[f] + agg_cnt[f])
 	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
 	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
 	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
@@ -799,7 +800,10 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 // FM (filter mode, `bfc -1`): the second bloom filter takes the k-mers seen before (count.c:67-68).  It is addressed by the same hash,
 // so its blocks for this region's k-mers are the same 2^R blocks: that slice sits in LDS next to the first filter's (instead of the
 // aggregation table) and a seen k-mer costs n_hashes LDS ORs -- no global atomics, no hand-over to k_commit.
-template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false>
+// STREAM: no aggregation; every seen k-mer is appended, as the record it came in, to the region's slice of A.stream_out and k_commit_stream
+// applies them.  For batches in which k-mers hardly repeat (a large genome at ~1x per batch) the aggregation table only costs: it fills
+// with singletons and the rest updates the count table from inside this kernel, a returning atomic in a workgroup that lives microseconds.
+template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false, bool STREAM = false>
 __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
@@ -817,6 +821,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	AggView G;
 	unsigned int *region_hi = nullptr;
 	if (FM) { region_hi = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4; G.id0 = G.id1 = nullptr; G.cnt = G.imin = G.imax = nullptr; G.mask = 0; }
+	else if (STREAM) { G.id0 = G.id1 = nullptr; G.cnt = G.imin = G.imax = nullptr; G.mask = 0; }
 	else {
 		G.id0 = reinterpret_cast<unsigned long long *>(sp); sp += (size_t)P.ag_cap * 8;
 		G.id1 = G.id0;
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			const uint4 *src2 = reinterpret_cast<const uint4 *>(g_region_hi);
 			uint4 *dst2 = reinterpret_cast<uint4 *>(region_hi);
 			for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst2[i] = src2[i];
-		} else {
+		} else if (!STREAM) {
 			for (uint32_t i = threadIdx.x; i < P.ag_cap; i += BT) {
 				G.id0[i] = FS_EMPTY; if (two) G.id1[i] = FS_EMPTY; G.cnt[2 * i] = 0; G.cnt[2 * i + 1] = 0;
 				if (TRACK) { G.imin[i] = 0xffffffffu; G.imax[i] = 0; }
@@ -894,6 +899,15 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 				uint32_t b = bloom_next(z, r.h2);
 				__hip_atomic_fetch_or(&region_hi[r.bl * 16 + (b >> 5)], 1u << (b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
+		} else if constexpr (STREAM) { // the lanes that emit right now take consecutive slots: one LDS atomic per wave, coalesced stores
+			const unsigned long long vote = __ballot(1);
+			const int leader = __ffsll((long long)vote) - 1;
+			uint32_t o0 = 0;
+			if (lane == leader) o0 = atomicAdd(&s_agg_n, (uint32_t)__popcll(vote));
+			o0 = __shfl(o0, leader);
+			RecW<RW> w;
+			Rec<RW>::pack(w, r.y0, r.y1, r.idx, r.hi);
+			rec_store<RW>(A.stream_out + ((uint64_t)rs + o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1))) * RW, w);
 		} else emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx);
 	};
 	// append a k-mer with clear bits to the LDS list: one LDS atomic per wave
@@ -1092,7 +1106,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
 	}
 	// ---- hand the aggregated k-mers over: compacted into this bucket's slice of agg_out (k_commit applies them)
-	for (uint32_t p0 = 0; p0 < (FM ? 0u : P.ag_cap); p0 += BT) {
+	for (uint32_t p0 = 0; p0 < ((FM || STREAM) ? 0u : P.ag_cap); p0 += BT) {
 		const uint32_t p = p0 + threadIdx.x;
 		unsigned long long a = p < P.ag_cap ? G.id0[p] : FS_EMPTY;
 		const bool used = a != FS_EMPTY;
@@ -1144,7 +1158,10 @@ __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 	if (!WALK) {
 		const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
 		const uint32_t f = (uint32_t)(gid / P.ag_cap), j = (uint32_t)(gid % P.ag_cap);
-		if (f >= A.n_fine || j >= A.agg_cnt[f]) return;
+		if (f >= A.n_fine) return;
+		const uint32_t nf = A.agg_cnt[f];
+		if (j == 0 && nf * 10 >= P.ag_cap * 9) atomicAdd(&A.stats[ST_CROWDED], 1ULL); // a full aggregation table: this batch's k-mers hardly repeat
+		if (j >= nf) return;
 		const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
 		const uint64_t fl = TRACK ? A.agg_out[3 * plane + gid] : 0;
 		commit_seen<W, TRACK>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
@@ -1152,12 +1169,30 @@ __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 		const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 		for (uint32_t f = wave * COMMIT_RPW; f < wave * COMMIT_RPW + COMMIT_RPW && f < A.n_fine; ++f) {
 			const uint32_t n = A.agg_cnt[f];
+			if (lane == 0 && n * 10 >= P.ag_cap * 9) atomicAdd(&A.stats[ST_CROWDED], 1ULL);
 			for (uint32_t j = lane; j < n; j += 64) {
 				const uint64_t gid = (uint64_t)f * P.ag_cap + j;
 				const uint32_t c = (uint32_t)A.agg_out[2 * plane + gid];
 				const uint64_t fl = TRACK ? A.agg_out[3 * plane + gid] : 0;
 				commit_seen<W, TRACK>(P, A, A.agg_out[gid], A.agg_out[plane + gid], c & 0xffffu, c >> 16, (uint32_t)fl, (uint32_t)(fl >> 32));
 			}
+		}
+	}
+}
+
+// STREAM mode: the seen k-mers of region f are the records stream_out[start[f] .. start[f] + agg_cnt[f]); one table update each
+template <typename W, int RW>
+__global__ __launch_bounds__(256) void k_commit_stream(KParams P, BloomArgs A)
+{
+	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+	const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	for (uint32_t f = wave * COMMIT_RPW; f < wave * COMMIT_RPW + COMMIT_RPW && f < A.n_fine; ++f) {
+		const uint32_t n = A.agg_cnt[f];
+		const uint64_t base = A.start[f];
+		for (uint32_t j = lane; j < n; j += 64) {
+			uint64_t y0, y1; uint32_t idx; bool hi;
+			Rec<RW>::unpack(rec_load<RW>(A.stream_out + (base + j) * RW), y0, y1, idx, hi);
+			commit_seen<W, false>(P, A, y0, y1, 1u, (uint32_t)hi, 0u, 0u);
 		}
 	}
 }
@@ -1373,13 +1408,20 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	BloomArgs A;
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_slices = B.pool_slices; A.seen_out = B.seen_out;
-	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine;
+	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine; A.stream_out = nullptr;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
 		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
 		else if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+	} else if (B.stream && B.stream_out && !P.track && P.n_hashes == 4) { // low-multiplicity batches: no aggregation (ctx decides, see bfcg_ctx.hip)
+		A.stream_out = B.stream_out;
+		hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		if (ev) hipEventRecord(ev[4], st);
+		hipLaunchKernelGGL((k_commit_stream<W, RW>), dim3((unsigned)((nfine + 4 * COMMIT_RPW - 1) / (4 * COMMIT_RPW))), dim3(256), 0, st, P, A);
+		if (ev) hipEventRecord(ev[5], st);
+		return;
 	} else if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
 		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, true>), dim3(nfine), dim3(512), lds, st, P, A);
@@ -1434,6 +1476,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

@@ -133,9 +133,11 @@ int   bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes);
 void *bfcg_host_alloc(uint64_t bytes);   /* pinned host memory */
 void  bfcg_host_free(void *p);
 
-enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS,
+enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS, BFCG_ST_CROWDED,
        BFCG_ST_TAB_CSHIFT = 8, BFCG_ST_BATCHES, BFCG_ST_N = 16 };
 int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
+/* batches handled without aggregation (k-mers that hardly repeat inside a batch: seen k-mers are streamed to the table kernel) */
+uint64_t bfcg_stream_batches(bfcg_ctx_t *c);
 
 /* per-stage GPU time of the last batch, HIP events on the context's stream (ms):
  * [0] hist1+scans [1] scatter1 [2] hist2+scan2+scatter2 [3] bloom regions [4] table commit [5] total */

@@ -337,3 +337,24 @@ def test_oversized_batches_are_cut_into_sub_batches(gpu_lib, g1):
             g.dev_free(d_s); g.dev_free(d_q)
         g.close()
     oc.close()
+
+
+@pytest.mark.parametrize("k", [31, 33])
+def test_batches_whose_kmers_hardly_repeat_switch_to_stream_mode(gpu_lib, k):
+    """A large genome at ~1.5x per batch: every region's aggregation table fills with singletons, the context notices (crowded regions)
+    and hands the seen k-mers of later batches over as a plain stream (k_bloom STREAM + k_commit_stream).  Same results as the oracle."""
+    rs = gen.ReadSet(seed=11, G=2_000_000, cov=9)
+    seq, qual, off = rs.reads()
+    oc = oracle.Counter(k, 28)
+    oc.count(seq, qual, off)
+    g = _gpu_count(gpu_lib, k, 28, seq, qual, off, 6)
+    st, ost = g.stats(), oc.stats()
+    assert st["crowded_regions"] > 2048 and st["stream_batches"] >= 3
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.reset()  # back to aggregation
+    assert g.stats()["crowded_regions"] == 0
+    g.close(); oc.close()
