@@ -91,3 +91,25 @@ def test_local_cluster_matches_reference_goldens(gpu_lib, g1, n_ranks, k, b):
     if k == 33:
         assert oracle.l1_digest(sizes, slots) == "896ce4092ccc51498b446e7d7775f10c"  # SURVEY C.5 golden, g1/k33/b30
     cl.close()
+
+
+@pytest.mark.gpu
+def test_local_cluster_stream_mode(gpu_lib):
+    """Emulated ranks on batches whose k-mers hardly repeat: every rank's context switches to the STREAM hand-over; still the oracle's result."""
+    from bfc_amd import dist as bdist
+    rs = gen.ReadSet(seed=11, G=2_000_000, cov=9)
+    seq, qual, off = rs.reads()
+    n, k, b, world = rs.n_reads, 33, 28, 4
+    cl = bdist.LocalCluster(gpu_lib, world, k, b, max_batch_pos=(n // 6 + 64) * (rs.L + 1))
+    for row in _shares(seq, qual, off, n, 6, world):
+        cl.batch([(gpu_lib.to_stream(s, o), gpu_lib.to_stream(q, o)) for s, q, o in row])
+    oc = oracle.Counter(k, b)
+    oc.count(seq, qual, off)
+    assert all(c.stats()["stream_batches"] >= 2 for c in cl.ctx)
+    assert np.array_equal(cl.bloom_bytes(), oc.bloom_bytes())
+    st, ost = cl.stats(), oc.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    sizes, slots = cl.export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    cl.close(); oc.close()
