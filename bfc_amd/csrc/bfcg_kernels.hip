@@ -306,11 +306,14 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
-	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4); // bucket of each staged record
+	// bucket of each staged record -- kept for 12-byte records only: with 16- and 24-byte records the 8 KiB would cost the second resident
+	// workgroup, and the bucket is recomputed from the staged record instead
+	constexpr bool KEEP_BK = RW < 4;
+	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4);
 	__shared__ uint32_t planes[4 * PW];
 	__shared__ uint32_t s_total;
 	const int nb1 = 1 << P.F1;
-	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + 2)), *loff = cnt + nb1, *gdelta = loff + nb1; // 3 x nb1 counters behind the stage
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *loff = cnt + nb1, *gdelta = loff + nb1; // 3 x nb1 counters behind the stage
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
 	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
@@ -359,16 +362,19 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 			const uint32_t b = br[j] >> 16, pos = cnt[b] + (br[j] & 0xffffu);
 #pragma unroll
 			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
-			sbk[pos] = (unsigned short)b;
+			if (KEEP_BK) sbk[pos] = (unsigned short)b;
 		}
 	}
 	__syncthreads();
 	const uint32_t n_in = s_total;
 	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
-		const uint64_t dst = (uint32_t)(pos + gdelta[sbk[pos]]);
 		RecW<RW> rec;
 #pragma unroll
 		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
+		uint32_t b;
+		if (KEEP_BK) b = sbk[pos];
+		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) >> P.F2; }
+		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
 		rec_store<RW>(out + dst * RW, rec);
 	}
 }
@@ -455,9 +461,10 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem2);                              // TILE * RW dwords
+	constexpr bool KEEP_BK = RW < 4; // as in k_scatter1: the bucket array only for 12-byte records
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 4); // bucket of each staged record
 	const int nb2 = 1 << P.F2;
-	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + 2)), *loff = cnt + nb2, *gdelta = loff + nb2; // 3 x nb2 counters behind the stage
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *loff = cnt + nb2, *gdelta = loff + nb2; // 3 x nb2 counters behind the stage
 	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
 	if (row >= n_rows) return;
@@ -507,16 +514,19 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 			const uint32_t b = br[j] >> 16, pos = cnt[b] + (br[j] & 0xffffu);
 #pragma unroll
 			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
-			sbk[pos] = (unsigned short)b;
+			if (KEEP_BK) sbk[pos] = (unsigned short)b;
 		}
 	}
 	__syncthreads();
 	const uint32_t n_in = min((uint32_t)TILE, e - s - tile * TILE);
 	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
-		const uint64_t dst = (uint32_t)(pos + gdelta[sbk[pos]]);
 		RecW<RW> rec;
 #pragma unroll
 		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
+		uint32_t b;
+		if (KEEP_BK) b = sbk[pos];
+		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) & (uint32_t)(nb2 - 1); }
+		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
 		rec_store<RW>(out + dst * RW, rec);
 	}
 }
@@ -1384,7 +1394,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4 + 2) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4 + (RW < 4 ? 2 : 0)) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1401,7 +1411,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		const unsigned g2 = (unsigned)(((n_rec_bound / TILE2 + n_seg + 1 + 7) / 8) * 8);
 		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
 		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4 + 2) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4 + (RW < 4 ? 2 : 0)) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
