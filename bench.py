@@ -251,6 +251,16 @@ def main():
     st = g.stats()
     tot, n_launch = g.stage_ms()
     stage.update(tot)
+    # one more, untimed step with one kernel at a time: the same kernels' durations without the other stream's kernels beside them
+    iso_bloom_ms = None
+    if eng is None:
+        os.environ["BFCG_SYNC_BATCHES"] = "1"
+        g.stage_ms(reset=True)
+        step(False)
+        g.sync()
+        iso, n_iso = g.stage_ms()
+        iso_bloom_ms = iso["bloom"] / max(n_iso, 1)
+        os.environ.pop("BFCG_SYNC_BATCHES", None)
     if dist:
         import torch
         t = torch.tensor([dt], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
@@ -281,6 +291,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(), "traffic_note": "HBM bytes per k_bloom launch from profiles/round1_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command)", "kmers_per_launch": int(kmers_per_launch), "avg_launch_ms": round(bloom_ms, 4),
                          "algorithmic_bytes_per_kmer": BLOOM_BYTES_PER_KMER,
+                         "isolated": None if not iso_bloom_ms else {"avg_launch_ms": round(iso_bloom_ms, 4), "achieved": round(BLOOM_BYTES_PER_KMER * kmers_per_launch / (iso_bloom_ms * 1e-3) / 1e9, 1),
+                                                                    "frac": round(BLOOM_BYTES_PER_KMER * kmers_per_launch / (iso_bloom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                                    "note": "same kernel in one extra untimed step with one kernel at a time (in the timed region stage A / level 2 of the next batch run beside it on a second stream)"},
                          "whole_job_frac": round(BLOOM_BYTES_PER_KMER * total_kmers * args.steps / dt / 1e9 / HBM_PEAK_GBS / world, 4)},
         }
         if not args.no_cpu_baseline:

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
 	// bucket of each staged record -- kept for 12-byte records only: with 16- and 24-byte records the 8 KiB would cost the second resident
 	// workgroup, and the bucket is recomputed from the staged record instead
-	constexpr bool KEEP_BK = RW < 4;
+	constexpr bool KEEP_BK = false;
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4);
 	__shared__ uint32_t planes[4 * PW];
 	__shared__ uint32_t s_total;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem2);                              // TILE * RW dwords
-	constexpr bool KEEP_BK = RW < 4; // as in k_scatter1: the bucket array only for 12-byte records
+	constexpr bool KEEP_BK = false;
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 4); // bucket of each staged record
 	const int nb2 = 1 << P.F2;
 	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *loff = cnt + nb2, *gdelta = loff + nb2; // 3 x nb2 counters behind the stage
@@ -1394,7 +1394,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4 + (RW < 4 ? 2 : 0)) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1411,7 +1411,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		const unsigned g2 = (unsigned)(((n_rec_bound / TILE2 + n_seg + 1 + 7) / 8) * 8);
 		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
 		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4 + (RW < 4 ? 2 : 0)) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
