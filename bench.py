@@ -296,7 +296,7 @@ def main():
                                                                     "note": "same kernel in one extra untimed step with one kernel at a time (in the timed region stage A / level 2 of the next batch run beside it on a second stream)"},
                          "whole_job_frac": round(BLOOM_BYTES_PER_KMER * total_kmers * args.steps / dt / 1e9 / HBM_PEAK_GBS / world, 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the reference on the host cores: at N=1 only
             try:
                 cb = cpu_baseline(rs, os.cpu_count() or 1)
             except Exception as e:  # the baseline must never take the GPU number down with it
