@@ -131,6 +131,7 @@ def main():
     use_dist = world > 1 or bool(os.environ.get("BFC_BENCH_FORCE_DIST"))
     dist = None
     if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
         import torch  # first: libbfc_gpu.so then binds to the HIP runtime torch already loaded (one runtime per process)
         import torch.distributed as dist
         torch.cuda.set_device(local)
