@@ -184,7 +184,7 @@ def main():
             ok = 0
         flag = torch.tensor([ok], device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            mode = "dp%d: read shards per GPU, bloom regions + table keys owned by one GPU each, 1 all-to-all of 16-byte k-mer records per batch (RCCL)" % world
+            mode = "dp%d: read shards per GPU, bloom regions + table keys owned by one GPU each, 1 all-to-all of %d-byte k-mer records per batch (RCCL)" % (world, g.mg_info()["rec_bytes"])
         else:
             eng = None
             g = make_counter(1)
