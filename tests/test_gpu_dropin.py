@@ -254,3 +254,35 @@ def test_gpu_trim_equals_reference_binary_on_damaged_files(tmp_path, seed):
         got = [l for l in g.stderr.decode().splitlines() if "] read " in l]
         assert got == want, (seed, extra)
         assert len(r.stdout) > 100000
+
+
+def test_gpu_trim_pass_on_a_large_filter(gpu_lib, g1):
+    """Filters of 4 GiB and more take the query kernel in which four lanes fetch a block together: same windows as the oracle (-b35)."""
+    import ctypes as C
+    rs, (seq, qual, off) = g1
+    n = 3000
+    seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
+    k, b = 33, 35
+    g = gpu_lib.GpuCounter(k, b, filter_mode=1, max_batch_pos=len(seq) + n + 64)
+    s_seq, s_qual = gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off)
+    g.count_host(s_seq, s_qual)
+    bf = g.export_bloom(1)
+    g.close()
+    tr = gpu_lib.GpuTrimmer(k, bf, max_pos=len(s_seq) + 64, max_reads=n)
+    start, end = tr.trim(s_seq, off + np.arange(n + 1, dtype=np.uint64), 0.9)
+    L = oracle.lib()
+    oc = oracle.Counter(k, b, filter_mode=1)
+    oc.count(seq, qual, off)
+    obf = L.orc_state_bf_high(oc.st)
+    kept = 0
+    for r in range(n):
+        s = seq[int(off[r]):int(off[r + 1])]
+        mx = L.orc_max_streak(k, obf, s.ctypes.data, len(s))
+        a, e = C.c_int(), C.c_int()
+        if L.orc_trim_decide(mx, k, len(s), 0.9, C.byref(a), C.byref(e)):
+            assert (int(start[r]), int(end[r])) == (a.value, e.value), r
+            kept += 1
+        else:
+            assert start[r] == -1, r
+    assert kept > 500
+    tr.close(); bf.close(); oc.close()
