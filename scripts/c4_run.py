@@ -19,6 +19,7 @@ ap.add_argument("--cov", type=float, default=30.0)
 ap.add_argument("--seed", type=int, default=4)
 ap.add_argument("--batch-reads", type=int, default=4194304)
 ap.add_argument("--filter-mode", type=int, default=0)
+ap.add_argument("--trim", type=int, default=0, help="1 (with --filter-mode 1): then the trim pass of bfc -1 over the same reads (bloom query kernel + longest streak)")
 ap.add_argument("--popcount", type=int, default=0, help="1: bring the filter(s) to the host and count their bits")
 args = ap.parse_args()
 K = args.k
@@ -80,5 +81,31 @@ if args.popcount:
         bits = g.bloom_bytes(which)
         res["bloom%d_popcount" % which] = int(oracle.lib().orc_popcount_bytes(bits.ctypes.data, len(bits)))
         del bits
+if args.trim and args.filter_mode:
+    t2 = time.time()
+    bf = g.export_bloom(1)
+    g.close(); g = None
+    tr = bfc_amd.GpuTrimmer(K, bf, max_pos=br * stride, max_reads=br)
+    print("[c4] second filter moved to the trimmer (%.1fs)" % (time.time() - t2), flush=True)
+    kept = bases = 0; q_ms = 0.0; nq = 0
+    cur = make(0)
+    t3 = time.perf_counter()
+    for r0 in range(0, n_reads, br):
+        th = None
+        if r0 + br < n_reads:
+            th = threading.Thread(target=prefetch, args=(r0 + br,)); th.start()
+        s, q, nk = cur
+        n = len(s) // stride
+        so = np.arange(n + 1, dtype=np.uint64) * np.uint64(stride)
+        st_, en_ = tr.trim(s, so, 0.9)
+        q_ms += tr.last_ms(); nq += nk
+        k_ = st_ >= 0
+        kept += int(k_.sum()); bases += int((en_[k_] - st_[k_]).sum())
+        if th:
+            th.join(); cur = nxt["v"]
+    res.update(trim_reads_kept=kept, trim_bases_kept=bases, trim_queries=nq, trim_gpu_s=round(q_ms / 1e3, 2), trim_G_queries_per_gpu_s=round(nq / q_ms / 1e6, 2),
+               trim_wall_s_generator_bound=round(time.perf_counter() - t3, 1))
+    tr.close(); bf.close()
 print(json.dumps(res), flush=True)
-g.close()
+if g is not None:
+    g.close()
