@@ -74,6 +74,7 @@ SYMBOLS = {
     "bfcg_trim_last_ms": (C.c_float, [C.c_void_p]),
     "bfcg_trim_dev_seq": (C.c_void_p, [C.c_void_p]),
     "bfcg_stream_batches": (C.c_uint64, [C.c_void_p]),
+    "bfc_ch_union": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
     "bfc_ingest_digest": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, u64p]),
     "bfcg_kcov_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_uint64]),
     "bfcg_kcov_attach": (C.c_void_p, [C.c_void_p, C.c_uint64]),

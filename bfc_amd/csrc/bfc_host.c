@@ -129,6 +129,58 @@ void bfc_ch_raw_recount(bfc_ch_t *ch)
 	for (i = 0; i < n; ++i) c += ch->slots[i] != 0;
 	ch->n_keys = c;
 }
+/* Union of tables whose key sets are disjoint -- the per-GPU tables of an owner-computes run: every key lives on
+ * exactly one rank, so the union IS the reference's table.  Order stamps travel along (first[] per key; sub_last[] = the latest of the
+ * ranks'), which keeps bfc_ch_dump byte-identical to `bfc -t1 -d` across GPUs: the stamps are (batch << 32 | rank-major file index),
+ * one global order.  A key present in several inputs is merged with saturating counts (cannot happen between ranks). */
+bfc_ch_t *bfc_ch_union(const bfc_ch_t *const *tabs, int n)
+{
+	bfc_ch_t *u;
+	uint64_t keys = 0, i;
+	int t, cshift = 2, ordered = 1;
+	if (n <= 0 || !tabs || !tabs[0]) return 0;
+	for (t = 0; t < n; ++t) {
+		if (!tabs[t] || tabs[t]->k != tabs[0]->k || tabs[t]->l_pre != tabs[0]->l_pre) return 0;
+		keys += tabs[t]->n_keys;
+		if (!tabs[t]->first) ordered = 0;
+	}
+	while (((uint64_t)1 << (tabs[0]->l_pre + cshift)) < keys * 2) ++cshift;
+	for (;;) { /* a sub-table that overflows its region sends us round again with twice the room */
+		const uint64_t cmask = ((uint64_t)1 << cshift) - 1;
+		int full = 0;
+		u = bfc_ch_alloc_raw(tabs[0]->k, tabs[0]->l_pre, cshift);
+		if (!u) return 0;
+		if (ordered) {
+			uint64_t *f, *sl;
+			if (bfc_ch_raw_order(u, &f, &sl) != 0) { bfc_ch_destroy(u); return 0; }
+			memset(f, 0xff, (size_t)8 << (u->l_pre + cshift)); memset(sl, 0, (size_t)8 << u->l_pre);
+		}
+		for (t = 0; t < n && !full; ++t) {
+			const bfc_ch_t *a = tabs[t];
+			const uint64_t na = (uint64_t)1 << (a->l_pre + a->cshift);
+			for (i = 0; i < na && !full; ++i) {
+				const uint64_t v = a->slots[i];
+				uint64_t sub, pos, probe, *reg;
+				if (!v) continue;
+				sub = i >> a->cshift; reg = u->slots + (sub << cshift); pos = (v >> 14) & cmask;
+				for (probe = 0; probe <= cmask; ++probe, pos = (pos + 1) & cmask) {
+					if (reg[pos] == 0) { reg[pos] = v; ++u->n_keys; if (ordered) u->first[(sub << cshift) + pos] = a->first[i]; break; }
+					if ((reg[pos] >> 14) == (v >> 14)) { /* the same key twice: counts add up, saturating (htab.c:74-79) */
+						uint64_t c = (reg[pos] & 0xff) + (v & 0xff), h = (reg[pos] >> 8 & 0x3f) + (v >> 8 & 0x3f);
+						reg[pos] = (reg[pos] & ~0x3fffULL) | (c < 255 ? c : 255) | ((h < 63 ? h : 63) << 8);
+						if (ordered && a->first[i] < u->first[(sub << cshift) + pos]) u->first[(sub << cshift) + pos] = a->first[i];
+						break;
+					}
+				}
+				if (probe > cmask) full = 1;
+			}
+			if (ordered && !full) for (i = 0; i < (uint64_t)1 << a->l_pre; ++i) if (a->sub_last[i] > u->sub_last[i]) u->sub_last[i] = a->sub_last[i];
+		}
+		if (!full) return u;
+		bfc_ch_destroy(u); ++cshift;
+	}
+}
+
 bfc_ch_t *bfc_ch_init(int k, int l_pre)
 {
 	assert(k <= 63);

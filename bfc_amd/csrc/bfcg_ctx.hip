@@ -630,7 +630,7 @@ extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
 	if (hipMemcpyAsync(bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
 	    hipStreamSynchronize(c->st) != hipSuccess) { set_err("D2H copy of the count table failed"); bfc_ch_destroy(ch); return NULL; }
-	if (c->B.tab_first && c->n_ranks == 1) { // order stamps travel with the table: bfc_ch_dump can then reproduce khash's layout byte for byte
+	if (c->B.tab_first) { // order stamps travel with the table (with several ranks: into bfc_ch_union): bfc_ch_dump can then reproduce khash's layout byte for byte
 		uint64_t *hf = 0, *hl = 0;
 		if (bfc_ch_raw_order(ch, &hf, &hl) != 0 ||
 		    hipMemcpyAsync(hf, c->B.tab_first, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||

@@ -179,6 +179,17 @@ class LocalCluster:
         assert pos == len(out) and n_sub == len(parts[0][0])
         return sizes.astype(np.uint32), out
 
+    def export_table(self):
+        """The ranks' tables as ONE host table (bfc_ch_union); with track_order its dump is byte-identical to `bfc -t1 -d`."""
+        import ctypes as C
+        from . import api
+        parts = [c.export_table() for c in self.ctx]
+        arr = (C.c_void_p * len(parts))(*[p.ptr for p in parts])
+        u = api._lib.load().bfc_ch_union(arr, len(parts))
+        for p in parts:
+            p.close()
+        return api.HostTable(u)
+
     def close(self):
         for c, a, b in zip(self.ctx, self.d_send, self.d_recv):
             c.sync(); c.dev_free(a); c.dev_free(b[0]); c.dev_free(b[1]); c.close()

@@ -156,6 +156,10 @@ bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (calle
  * fast path (uncompressed strict 4-line FASTQ; n_threads = 0 forces the serial parser).  Used to test that both parsers agree. */
 int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, uint64_t out[7]);
 
+/* Union of the per-GPU tables of an owner-computes run (disjoint key sets: the union is the reference's table); order stamps travel
+ * along, so that bfc_ch_dump of the union is byte-identical to `bfc -t1 -d` across GPUs too.  NULL if k / l_pre differ. */
+bfc_ch_t *bfc_ch_union(const bfc_ch_t *const *tabs, int n);
+
 /* L1 form of a host table: sizes[2^l_pre]; slots (may be NULL) = per sub-table sorted */
 int      bfc_ch_get_lpre(const bfc_ch_t *ch);
 uint64_t bfc_ch_export_sorted(const bfc_ch_t *ch, uint32_t *sizes, uint64_t *slots);

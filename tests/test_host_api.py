@@ -159,3 +159,39 @@ def test_host_table_interoperates_with_the_reference(gpu_lib, seed, tmp_path):
         assert R.bfc_ch_get(rt2, (C.c_uint64 * 2)(a, b)) == R.bfc_ch_get(rt, (C.c_uint64 * 2)(a, b))
     assert R.bfc_ch_count(rt2) == R.bfc_ch_count(rt)
     R.bfc_ch_destroy(rt); R.bfc_ch_destroy(rt2); t.close()
+
+
+def test_union_of_disjoint_tables(gpu_lib):
+    """bfc_ch_union: the per-GPU tables of an owner-computes run hold disjoint key sets; their union answers bfc_ch_get / count / hist like
+    one table that received all inserts; a key in two inputs gets saturating sums."""
+    from bfc_amd import _lib
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    k, l_pre = 33, 20
+    m = (1 << k) - 1
+    keys = [(int(a) & m, int(b) & m) for a, b in zip(rng.integers(0, 2 ** 63, 6000, dtype=np.int64), rng.integers(0, 2 ** 63, 6000, dtype=np.int64))]
+    parts = [gpu_lib.HostTable.init(k, l_pre) for _ in range(4)]
+    oc = L.orc_ch_new(k, l_pre)
+    for i, (a, b) in enumerate(keys):
+        for rep in range(1 + i % 3):
+            parts[i % 4].insert(a, b, (i + rep) & 1)
+            L.orc_ch_insert(oc, (C.c_uint64 * 2)(a, b), (i + rep) & 1)
+    for _ in range(200):  # one key on two "ranks", close to saturation on both
+        parts[0].insert(*keys[0], 1); parts[1].insert(*keys[0], 1)
+    for _ in range(400):
+        L.orc_ch_insert(oc, (C.c_uint64 * 2)(*keys[0]), 1)
+    arr = (C.c_void_p * 4)(*[p.ptr for p in parts])
+    u = gpu_lib.HostTable(_lib.load().bfc_ch_union(arr, 4))
+    assert u.count() == L.orc_ch_count(oc)
+    for a, b in keys[:1500] + [(5, 6)]:
+        assert u.get(a, b) == L.orc_ch_get(oc, (C.c_uint64 * 2)(a, b))
+    cnt = np.zeros(256, dtype=np.uint64); high = np.zeros(64, dtype=np.uint64)
+    omode = L.orc_ch_hist(oc, cnt.ctypes.data_as(C.POINTER(C.c_uint64)), high.ctypes.data_as(C.POINTER(C.c_uint64)))
+    mode, c2, h2 = u.hist()
+    assert mode == omode and np.array_equal(cnt, c2) and np.array_equal(high, h2)
+    other = gpu_lib.HostTable.init(31, 20)
+    arr2 = (C.c_void_p * 2)(parts[0].ptr, other.ptr)
+    assert not _lib.load().bfc_ch_union(arr2, 2)  # different k
+    for p in parts + [u, other]:
+        p.close()
+    L.orc_ch_free(oc)

@@ -113,3 +113,21 @@ def test_local_cluster_stream_mode(gpu_lib):
     osz, osl = oc.export()
     assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
     cl.close(); oc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_local_cluster_exact_dump(gpu_lib, g1, n_ranks, tmp_path):
+    """Parity level L2 across GPUs: with order stamps the union of the ranks' tables (bfc_ch_union) dumps to the very bytes of
+    `bfc -E -t1 -d` (md5 golden from the reference binary, g1 / k=31 / -b26)."""
+    from bfc_amd import dist as bdist
+    rs, (seq, qual, off) = g1
+    n = rs.n_reads
+    cl = bdist.LocalCluster(gpu_lib, n_ranks, 31, 26, max_batch_pos=(n // 3 + 64) * (rs.L + 1), track_order=True)
+    for row in _shares(seq, qual, off, n, 3, n_ranks):
+        cl.batch([(gpu_lib.to_stream(s, o), gpu_lib.to_stream(q, o)) for s, q, o in row])
+    t = cl.export_table()
+    fn = str(tmp_path / "u.hash")
+    assert t.dump(fn) == 0
+    assert oracle.md5_file(fn) == "d686549d10dd4c71243269013119784a"
+    t.close(); cl.close()
