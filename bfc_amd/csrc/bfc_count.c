@@ -99,7 +99,16 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	if (opt->bf_shift > 33) cap <<= opt->bf_shift - 33;
 	if ((env = getenv("BFC_GPU_BATCH")) != 0) cap = strtoull(env, 0, 10);
 	if (cap > (1ULL << 32) - (1ULL << 27)) cap = (1ULL << 32) - (1ULL << 27);
-	bases = cap;                 /* the batch boundary is bseq_read's: the read that brings a batch to `bases` is its last */
+	bases = cap;
+	{ /* an uncompressed regular file cannot hold more positions than bytes: no 100 GB of buffers for a small input behind a big filter */
+		struct stat sb;
+		FILE *fp;
+		if (fn && strcmp(fn, "-") && stat(fn, &sb) == 0 && S_ISREG(sb.st_mode) && (fp = fopen(fn, "rb")) != 0) {
+			int c0 = fgetc(fp), c1 = fgetc(fp);
+			fclose(fp);
+			if (!(c0 == 0x1f && c1 == 0x8b) && (uint64_t)sb.st_size + 4096 < cap) cap = (uint64_t)sb.st_size + 4096;
+		}
+	}                 /* the batch boundary is bseq_read's: the read that brings a batch to `bases` is its last */
 	if (cap < (1u << 16)) cap = 1u << 16;
 	cap += cap / 64 + (1u << 20); /* separators, and the read that crosses the boundary */
 	if (cap >= (1ULL << 32)) cap = (1ULL << 32) - 1;

@@ -286,3 +286,20 @@ def test_gpu_trim_pass_on_a_large_filter(gpu_lib, g1):
             assert start[r] == -1, r
     assert kept > 500
     tr.close(); bf.close(); oc.close()
+
+
+@needs_dropin
+@pytest.mark.skipif(not os.path.exists(REFBIN), reason="oracle/_ref/bfc-ref not built")
+def test_dropin_with_the_largest_filter(g1_fq, tmp_path):
+    """`bfc -s 3g` (k=33, -b37: a 16 GiB filter, batches of 16 reference chunks) on a small file: the dump equals the reference binary's,
+    and the library sizes its buffers by the file, not by the 1.6 G-position batch the filter would allow."""
+    env = dict(os.environ, BFC_GPU_EXACT_DUMP="1", BFC_GPU_TIMING="1")
+    ref_dump, gpu_dump = str(tmp_path / "ref.hash"), str(tmp_path / "gpu.hash")
+    r = subprocess.run([REFBIN, "-E", "-s", "3g", "-t", "1", "-d", ref_dump, g1_fq], capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    g = subprocess.run([DROPIN, "-E", "-s", "3g", "-t", "4", "-d", gpu_dump, g1_fq], capture_output=True, timeout=900, env=env)
+    assert g.returncode == 0, g.stderr.decode()[-800:]
+    assert open(gpu_dump, "rb").read() == open(ref_dump, "rb").read()
+    import re
+    m = re.search(rb"buffers for (\d+) positions per batch", g.stderr)
+    assert m and int(m.group(1)) < 4 * os.path.getsize(g1_fq)
