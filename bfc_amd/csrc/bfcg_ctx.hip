@@ -41,7 +41,7 @@ struct bfcg_ctx {
 	uint64_t n_batches;
 	float last_ms[6];
 	double sum_ms[6]; uint64_t n_timed; // cumulative per-stage GPU time of finalised batches (bfcg_stage_ms)
-	int rw;                      // bytes per record: 12 (k <= 31), 16 (k <= 47), 24
+	int rw;                      // bytes per record: 12 (k <= 31), 16 (k <= 47), 20
 	uint64_t bloom_bytes;        // bytes of the bloom slice this rank owns
 	int n_ranks, rank, log2n;
 	uint32_t *d_seg, *h_seg;     // multi-GPU: seg_beg | seg_end | row_base | bucket_start (device / pinned host), one set per in-flight batch
@@ -140,7 +140,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	P.track = (prm->track_order && !prm->filter_mode) ? 1 : 0;
 	// one workgroup per CU (regions of 32 KiB and more: -b36, -b37) runs 1024 threads so that the CU still has 16 waves; no such variant with order stamps
 	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
-	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 24;
+	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 20;
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
 	P.idx_rank = n_ranks > 1 ? (uint32_t)prm->rank << (32 - log2n) : 0u;
@@ -158,8 +158,9 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	HIPCKN(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
 	{
-		const uint64_t tiles1 = (prm->max_batch_pos + BFCG_TILE1 - 1) / BFCG_TILE1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
-		const uint64_t rows2 = c->recv_cap / BFCG_TILE2 + nb1 + 1;
+		const uint64_t tile = (uint64_t)bfcg_tile_of(P.k);
+		const uint64_t tiles1 = (prm->max_batch_pos + tile - 1) / tile, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
+		const uint64_t rows2 = c->recv_cap / tile + nb1 + 1;
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->rows1[b], sizeof(uint32_t) * tiles1 * nb1));
 			HIPCKN(hipMalloc(&c->chunk1[b], sizeof(uint32_t) * chunks1 * nb1));
@@ -419,7 +420,8 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 			seg_beg[seg] = (uint32_t)off; off += seg_cnt[s * nb_loc + k]; seg_end[seg] = (uint32_t)off;
 		}
 	if (off > c->recv_cap) return set_err("received %llu records for this rank's buckets, capacity %llu", (unsigned long long)off, (unsigned long long)c->recv_cap);
-	for (int seg = 0; seg < n_seg; ++seg) { row_base[seg] = (uint32_t)rows; rows += (seg_end[seg] - seg_beg[seg] + BFCG_TILE2 - 1) / BFCG_TILE2; }
+	const uint32_t tile2 = (uint32_t)bfcg_tile_of(c->P.k);
+	for (int seg = 0; seg < n_seg; ++seg) { row_base[seg] = (uint32_t)rows; rows += (seg_end[seg] - seg_beg[seg] + tile2 - 1) / tile2; }
 	row_base[n_seg] = (uint32_t)rows;
 	for (int k = 0; k < nb_loc; ++k) {
 		bucket_start[k] = (uint32_t)tot;

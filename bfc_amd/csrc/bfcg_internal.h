@@ -4,6 +4,8 @@
 #define BFCG_TILE1 4096
 #define BFCG_TILE2 4096
 #define BFCG_SCAN_CH 64
+/* records per scatter tile: 20-byte records (k > 47) take 3072 so that two workgroups' stages fit a CU's LDS */
+static inline int bfcg_tile_of(int k) { return k > 47 ? 3072 : 4096; }
 #define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */
 #include <stdint.h>
 

@@ -2,7 +2,7 @@
 // (count.c + bbf.c + htab.c).  See DESIGN.md for the pipeline; in short, per batch of reads:
 //
 //   k_hist1    bases -> k-mers (K1, kmer_dev.h) -> histogram of level-1 bucket ids
-//   k_scatter  K1 again -> 16/24-byte k-mer records scattered into level-1 buckets
+//   k_scatter  K1 again -> 12/16/20-byte k-mer records scattered into level-1 buckets
 //   k_hist2    level-1 buckets -> histogram of fine bucket ids          (two-level only)
 //   k_scatter2 level-1 buckets -> fine buckets                          (two-level only)
 //   k_bloom    one workgroup per fine bucket = one contiguous REGION of 2^R bloom blocks,
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool kmer_at(const uint32_t *planes, int r, int k, W 
 
 // A record is RD dwords:  RD=3 (k <= 31): y0 | is_high<<31, y1, file index   -- 12 bytes
 //                         RD=4 (k <= 47): two u64 = y0 | is_high<<47 | index[15:0]<<48, y1 | index[31:16]<<48
-//                         RD=6 (k <= 63): y0 | is_high<<63, y1, index (u64 each)
+//                         RD=5 (k <= 63): u64 y0 | is_high<<63, u64 y1, u32 index             -- 20 bytes (4-byte aligned)
 template <int RD> struct RecW { uint32_t d[RD]; };
 
 template <int RD> __device__ __forceinline__ RecW<RD> rec_load(const uint32_t *p);
@@ -138,22 +138,15 @@ template <> __device__ __forceinline__ RecW<3> rec_load<3>(const uint32_t *p)
 { const uint3 v = *reinterpret_cast<const uint3 *>(p); RecW<3> r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; return r; }
 template <> __device__ __forceinline__ RecW<4> rec_load<4>(const uint32_t *p)
 { const uint4 v = *reinterpret_cast<const uint4 *>(p); RecW<4> r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; return r; }
-template <> __device__ __forceinline__ RecW<6> rec_load<6>(const uint32_t *p)
-{
-	const uint2 *q = reinterpret_cast<const uint2 *>(p);
-	const uint2 a = q[0], b = q[1], c = q[2];
-	RecW<6> r; r.d[0] = a.x; r.d[1] = a.y; r.d[2] = b.x; r.d[3] = b.y; r.d[4] = c.x; r.d[5] = c.y; return r;
-}
+template <> __device__ __forceinline__ RecW<5> rec_load<5>(const uint32_t *p) // records are only dword-aligned
+{ RecW<5> r; r.d[0] = p[0]; r.d[1] = p[1]; r.d[2] = p[2]; r.d[3] = p[3]; r.d[4] = p[4]; return r; }
 template <int RD> __device__ __forceinline__ void rec_store(uint32_t *p, const RecW<RD> &r);
 template <> __device__ __forceinline__ void rec_store<3>(uint32_t *p, const RecW<3> &r)
 { *reinterpret_cast<uint3 *>(p) = make_uint3(r.d[0], r.d[1], r.d[2]); }
 template <> __device__ __forceinline__ void rec_store<4>(uint32_t *p, const RecW<4> &r)
 { *reinterpret_cast<uint4 *>(p) = make_uint4(r.d[0], r.d[1], r.d[2], r.d[3]); }
-template <> __device__ __forceinline__ void rec_store<6>(uint32_t *p, const RecW<6> &r)
-{
-	uint2 *q = reinterpret_cast<uint2 *>(p);
-	q[0] = make_uint2(r.d[0], r.d[1]); q[1] = make_uint2(r.d[2], r.d[3]); q[2] = make_uint2(r.d[4], r.d[5]);
-}
+template <> __device__ __forceinline__ void rec_store<5>(uint32_t *p, const RecW<5> &r)
+{ p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; p[3] = r.d[3]; p[4] = r.d[4]; }
 
 template <int RD> struct Rec;
 template <> struct Rec<3> {
@@ -176,13 +169,13 @@ template <> struct Rec<4> {
 		idx = (uint32_t)(a >> 48) | ((uint32_t)(b >> 48) << 16);
 	}
 };
-template <> struct Rec<6> {
-	static __device__ __forceinline__ void pack(RecW<6> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+template <> struct Rec<5> {
+	static __device__ __forceinline__ void pack(RecW<5> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
 	{
 		const uint64_t a = y0 | ((uint64_t)hi << 63);
-		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)y1; r.d[3] = (uint32_t)(y1 >> 32); r.d[4] = idx; r.d[5] = 0;
+		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)y1; r.d[3] = (uint32_t)(y1 >> 32); r.d[4] = idx;
 	}
-	static __device__ __forceinline__ void unpack(const RecW<6> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	static __device__ __forceinline__ void unpack(const RecW<5> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
 	{
 		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32);
 		y0 = a & ~(1ULL << 63); hi = a >> 63; y1 = r.d[2] | ((uint64_t)r.d[3] << 32); idx = r.d[4];
@@ -306,7 +299,7 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
-	// bucket of each staged record -- kept for 12-byte records only: with 16- and 24-byte records the 8 KiB would cost the second resident
+	// bucket of each staged record -- kept for 12-byte records only: with 16- and 20-byte records the 8 KiB would cost the second resident
 	// workgroup, and the bucket is recomputed from the staged record instead
 	constexpr bool KEEP_BK = false;
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4);
@@ -1429,17 +1422,18 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 template <typename W, int RW>
 static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
 {
+	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
 	const int nb1 = 1 << P.F1;
-	const int64_t tiles1 = (n_pos + TILE1 - 1) / TILE1;
+	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
 	const int n_chunks = (int)((tiles1 + SCAN_CH - 1) / SCAN_CH);
 	if (ev) hipEventRecord(ev[0], st);
 	const unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8); // one block per tile, dealt XCD-contiguously
-	hipLaunchKernelGGL((k_hist1<W, TILE1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.stats);
+	hipLaunchKernelGGL((k_hist1<W, T1, BT1>), dim3(g1), dim3(BT1), 0, st, P, seq, qual, n_pos, B.rows1, B.stats);
 	hipLaunchKernelGGL(k_colsum, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, TILE2);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, T2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, TILE1, BTS1>), dim3(g1), dim3(BTS1), (size_t)TILE1 * (RW * 4) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1452,11 +1446,12 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	const int nb_loc = n_seg / segs_per_bucket, nfine = nb_loc << P.F2;
 	const uint32_t *fine_recs = in1; const uint32_t *fine_start = bucket_start;
 	if (P.F2 > 0) {
-		// rows of level 2 <= records/TILE2 + one ragged row per segment; surplus blocks exit at once
-		const unsigned g2 = (unsigned)(((n_rec_bound / TILE2 + n_seg + 1 + 7) / 8) * 8);
-		hipLaunchKernelGGL((k_hist2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
+		constexpr int T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
+		// rows of level 2 <= records/T2 + one ragged row per segment; surplus blocks exit at once
+		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
+		hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
 		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, TILE2, BT2>), dim3(g2), dim3(BT2), (size_t)TILE2 * (RW * 4) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
@@ -1499,7 +1494,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	if (ev) hipEventRecord(ev[5], st);
 }
 
-#define DISPATCH_W(fn, ...) do { if (P.k <= 31) fn<uint32_t, 3>(__VA_ARGS__); else if (P.k == 32) fn<uint32_t, 4>(__VA_ARGS__); else if (P.k <= 47) fn<uint64_t, 4>(__VA_ARGS__); else fn<uint64_t, 6>(__VA_ARGS__); } while (0)
+#define DISPATCH_W(fn, ...) do { if (P.k <= 31) fn<uint32_t, 3>(__VA_ARGS__); else if (P.k == 32) fn<uint32_t, 4>(__VA_ARGS__); else if (P.k <= 47) fn<uint64_t, 4>(__VA_ARGS__); else fn<uint64_t, 5>(__VA_ARGS__); } while (0)
 
 void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
 { DISPATCH_W(run_stage_a_t, P, B, seq, qual, n_pos, (uint32_t *)out1, st, ev); }
@@ -1524,8 +1519,9 @@ int bloom_lds_bytes(const KParams &P)
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, TILE1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE1 * (RW * 4 + 2) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2 * (RW * 4 + 2) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
+	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2;
+	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
@@ -1543,7 +1539,7 @@ hipError_t set_bloom_lds_attr(const KParams &P)
 	if (P.k <= 31) return set_attr_t<uint32_t, 3>(lds);
 	if (P.k == 32) return set_attr_t<uint32_t, 4>(lds);
 	if (P.k <= 47) return set_attr_t<uint64_t, 4>(lds);
-	return set_attr_t<uint64_t, 6>(lds);
+	return set_attr_t<uint64_t, 5>(lds);
 }
 
 void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *bloom, uint8_t *flags, hipStream_t st)
