@@ -14,6 +14,7 @@
 #include <string.h>
 #include <assert.h>
 #include <pthread.h>
+#include <sys/stat.h>
 #include "bfc_gpu.h"
 #include "bfc_host.h"
 
@@ -220,6 +221,7 @@ static void grow(bfc_ch_t *ch) /* caller holds the write lock */
 	uint64_t n = (uint64_t)1 << (ch->l_pre + ch->cshift), i;
 	uint64_t *ns = (uint64_t*)calloc((size_t)1 << (ch->l_pre + nc), 8);
 	uint32_t cmask = (1u << nc) - 1;
+	if (!ns) { fprintf(stderr, "[E::%s] out of memory growing the count table to %llu slots\n", __func__, 1ULL << (ch->l_pre + nc)); abort(); } /* no error codes on this path */
 	for (i = 0; i < n; ++i) {
 		uint64_t v = ch->slots[i], *reg;
 		uint32_t pos;
@@ -411,16 +413,22 @@ bfc_ch_t *bfc_ch_restore(const char *fn)
 {
 	FILE *fp;
 	uint32_t t[2];
-	uint64_t s, n_sub;
+	uint64_t s, n_sub, left = UINT64_MAX;
+	struct stat st;
 	bfc_ch_t *ch;
 	if ((fp = fopen(fn, "rb")) == 0) return 0;
 	if (fread(t, 4, 2, fp) != 2) { fclose(fp); return 0; }
+	if (fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode)) left = (uint64_t)st.st_size - 8;
 	ch = bfc_ch_init((int)t[0], (int)t[1]);
 	assert((int)t[1] == ch->l_pre);
 	n_sub = (uint64_t)1 << ch->l_pre;
 	for (s = 0; s < n_sub; ++s) {
 		uint32_t j;
 		if (fread(t, 4, 2, fp) != 2) { fclose(fp); bfc_ch_destroy(ch); return 0; }
+		if (left != UINT64_MAX) { /* a truncated or damaged file: stop before a bogus size makes the table grow */
+			if (left < 8 || (uint64_t)t[1] * 8 > left - 8) { fclose(fp); bfc_ch_destroy(ch); return 0; }
+			left -= 8 + (uint64_t)t[1] * 8;
+		}
 		for (j = 0; j < t[1]; ++j) {
 			uint64_t v;
 			if (fread(&v, 8, 1, fp) != 1) { fclose(fp); bfc_ch_destroy(ch); return 0; }

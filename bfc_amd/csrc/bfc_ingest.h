@@ -67,8 +67,8 @@ typedef struct {
 static inline int batch_put(batch_t *b, const uint8_t *s, const uint8_t *q, size_t l)
 {
 	if (b->n_pos + l + 1 > b->cap) return 0;
-	memcpy(b->seq + b->n_pos, s, l);
-	if (q) { memcpy(b->qual + b->n_pos, q, l); b->has_qual = 1; }
+	if (l) memcpy(b->seq + b->n_pos, s, l); /* an empty record may come with s == NULL (no sequence line was ever buffered) */
+	if (q) { if (l) memcpy(b->qual + b->n_pos, q, l); b->has_qual = 1; }
 	else memset(b->qual + b->n_pos, '~', l);
 	b->seq[b->n_pos + l] = '\n'; b->qual[b->n_pos + l] = '!';
 	b->n_pos += l + 1; ++b->n_seqs;
