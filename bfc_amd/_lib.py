@@ -72,6 +72,7 @@ SYMBOLS = {
     "bfcg_trim_destroy": (None, [C.c_void_p]),
     "bfcg_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_uint64, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bfcg_trim_last_ms": (C.c_float, [C.c_void_p]),
+    "bfcg_trim_adopted": (C.c_int, [C.c_void_p]),
     "bfcg_trim_dev_seq": (C.c_void_p, [C.c_void_p]),
     "bfcg_stream_batches": (C.c_uint64, [C.c_void_p]),
     "bfc_ch_union": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
@@ -94,6 +95,8 @@ SYMBOLS = {
     "bfcg_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), u64p, C.c_int]),
     "bfcg_bloom_to_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "bfcg_export_bloom": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),
+    "bfcg_export_bloom_resident": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),
+    "bfcg_resident_drop": (None, [C.c_void_p]),
     "bfcg_export_table": (C.c_void_p, [C.c_void_p]),
     "bfc_ch_get_lpre": (C.c_int, [C.c_void_p]),
     "bfc_ch_export_sorted": (C.c_uint64, [C.c_void_p, u32p, u64p]),

@@ -291,8 +291,12 @@ class GpuCounter:
         self._ck(self.L.bfcg_bloom_to_host(self.ctx, which, out.ctypes.data))
         return out
 
-    def export_bloom(self, which=0):
-        return HostBloom(self.L.bfcg_export_bloom(self.ctx, which))
+    def export_bloom(self, which=0, resident=False):
+        """Host bfc_bf_t of filter `which`; resident=True also leaves a copy in HBM for a GpuTrimmer to adopt (what bfc_count does)."""
+        p = (self.L.bfcg_export_bloom_resident if resident else self.L.bfcg_export_bloom)(self.ctx, which)
+        if not p:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return HostBloom(p)
 
     def export_table(self):
         p = self.L.bfcg_export_table(self.ctx)
@@ -348,6 +352,11 @@ class GpuTrimmer:
 
     def last_ms(self):
         return float(self.L.bfcg_trim_last_ms(self.t))
+
+    @property
+    def adopted(self):
+        """True if the filter was found resident in HBM (left there by the count pass) instead of being uploaded."""
+        return bool(self.L.bfcg_trim_adopted(self.t))
 
 
 class GpuKcov:

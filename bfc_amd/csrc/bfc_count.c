@@ -170,7 +170,8 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	if (!opt->no_mt_io) pthread_join(tid, 0);
 
 	tt = now_real();
-	ret = opt->filter_mode ? (void*)bfcg_export_bloom(ctx, 1) : (void*)bfcg_export_table(ctx);
+	ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_export_bloom(ctx, 1) : bfcg_export_bloom_resident(ctx, 1)) /* bf_high also stays in HBM for the trim pass (bfc_trim.c) */
+	                       : (void*)bfcg_export_table(ctx);
 	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
 	for (i = 0; i < 2; ++i) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); }

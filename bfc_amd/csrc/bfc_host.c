@@ -38,18 +38,33 @@ static inline void kmer_y(int k, const uint64_t x[4], uint64_t y[2])
 
 /* ------------------------------------------------------------------ bloom filter (bbf.c) */
 
-bfc_bf_t *bfc_bf_init(int n_shift, int n_hashes)
+/* A filter exported by bfc_count may still have its copy in HBM (bfcg_export_bloom_resident), for the trim pass to adopt.  That copy
+ * dies with the host object and as soon as the host object is written to.  Weak: this file also links without the GPU objects. */
+void bfcg_resident_drop(const void *bf) __attribute__((weak));
+
+bfc_bf_t *bfc_bf_alloc_raw(int n_shift, int n_hashes)
 {
 	bfc_bf_t *b; void *p = 0;
 	if (n_shift + BFC_BLK_SHIFT > 64 || n_shift < BFC_BLK_SHIFT) return 0;
 	b = (bfc_bf_t*)calloc(1, sizeof(bfc_bf_t));
+	if (!b) return 0;
 	b->n_shift = n_shift; b->n_hashes = n_hashes;
 	if (posix_memalign(&p, 64, 1ULL << (n_shift - 3)) != 0) { free(b); return 0; }
 	b->b = (uint8_t*)p;
-	memset(b->b, 0, 1ULL << (n_shift - 3));
 	return b;
 }
-void bfc_bf_destroy(bfc_bf_t *b) { if (b) { free(b->b); free(b); } }
+bfc_bf_t *bfc_bf_init(int n_shift, int n_hashes)
+{
+	bfc_bf_t *b = bfc_bf_alloc_raw(n_shift, n_hashes);
+	if (b) memset(b->b, 0, 1ULL << (n_shift - 3));
+	return b;
+}
+void bfc_bf_destroy(bfc_bf_t *b)
+{
+	if (!b) return;
+	if (bfcg_resident_drop) bfcg_resident_drop(b);
+	free(b->b); free(b);
+}
 
 static inline uint8_t *bf_walk(const bfc_bf_t *b, uint64_t hash, int *h1, int *h2)
 {
@@ -63,6 +78,7 @@ int bfc_bf_insert(bfc_bf_t *b, uint64_t hash) /* single-k-mer host insert; atomi
 {
 	int h1, h2, i, z, cnt = 0;
 	uint8_t *p = bf_walk(b, hash, &h1, &h2);
+	if (bfcg_resident_drop) bfcg_resident_drop(b); /* the copy in HBM, if any, is stale from here on (one relaxed load when there is none) */
 	for (i = 0, z = h1; i < b->n_hashes; z = (z + h2) & BFC_BLK_MASK) {
 		uint8_t u;
 		if (z < 8) continue;

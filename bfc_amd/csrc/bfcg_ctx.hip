@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
 #include "bfc_gpu.h"
 #include "bfcg_internal.h"
 #include "bfc_host.h"
@@ -618,9 +620,53 @@ extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)
 
 extern "C" bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which)
 {
-	bfc_bf_t *b = bfc_bf_init(c->P.bf_shift, c->P.n_hashes);
-	if (!b) return NULL;
+	bfc_bf_t *b = bfc_bf_alloc_raw(c->P.bf_shift, c->P.n_hashes); // every byte is overwritten below: no 2^(b-3)-byte memset on the host
+	if (!b) { set_err("host allocation of the bloom filter failed"); return NULL; }
 	if (bfcg_bloom_to_host(c, which, b->b) != 0) { bfc_bf_destroy(b); return NULL; }
+	return b;
+}
+
+// ---- filters that stay in HBM behind their host object.  `bfc -1` counts into bf_high and then queries it for every k-mer again
+// (correct.c:556): bfc_count hands the host copy the reference's API promises (bfc_bf_t.b is public) AND leaves a device copy here,
+// which bfcg_trim_create adopts instead of uploading 2^(b-3) bytes again.  The copy is dropped when the host object is destroyed or
+// written to through this library (bfc_bf_destroy / bfc_bf_insert call bfcg_resident_drop).
+struct resident_t { const void *bf; void *dev; int device, n_shift; };
+static resident_t g_res[8];
+static std::atomic<int> g_res_n{0};
+static std::mutex g_res_mu;
+
+extern "C" void bfcg_resident_drop(const void *bf)
+{
+	if (g_res_n.load(std::memory_order_relaxed) == 0) return;
+	void *dev = 0; int device = 0;
+	{
+		std::lock_guard<std::mutex> lk(g_res_mu);
+		for (int i = 0; i < 8; ++i) if (g_res[i].dev && g_res[i].bf == bf) { dev = g_res[i].dev; device = g_res[i].device; g_res[i].dev = 0; g_res_n.fetch_sub(1); break; }
+	}
+	if (dev) { int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(device); (void)hipFree(dev); (void)hipSetDevice(cur); }
+}
+static void *resident_take(const bfc_bf_t *bf, int device)
+{
+	if (g_res_n.load(std::memory_order_relaxed) == 0) return 0;
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	for (int i = 0; i < 8; ++i)
+		if (g_res[i].dev && g_res[i].bf == (const void *)bf && g_res[i].device == device && g_res[i].n_shift == bf->n_shift) {
+			void *dev = g_res[i].dev; g_res[i].dev = 0; g_res_n.fetch_sub(1); return dev;
+		}
+	return 0;
+}
+
+extern "C" bfc_bf_t *bfcg_export_bloom_resident(bfcg_ctx_t *c, int which)
+{
+	bfc_bf_t *b = bfcg_export_bloom(c, which);
+	if (!b) return NULL;
+	void *dev = 0;
+	if (hipSetDevice(c->prm.device) != hipSuccess || hipMalloc(&dev, c->bloom_bytes) != hipSuccess) { (void)hipGetLastError(); return b; } // no room: the host copy alone is a complete answer
+	if (hipMemcpyAsync(dev, which ? c->B.bloom_hi : c->B.bloom, c->bloom_bytes, hipMemcpyDeviceToDevice, c->st) != hipSuccess ||
+	    hipStreamSynchronize(c->st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return b; }
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	for (int i = 0; i < 8; ++i) if (!g_res[i].dev) { g_res[i] = resident_t{b, dev, c->prm.device, c->P.bf_shift}; g_res_n.fetch_add(1); return b; }
+	(void)hipFree(dev); // registry full
 	return b;
 }
 
@@ -688,6 +734,7 @@ struct bfcg_trim {
 	int device;
 	hipStream_t st;
 	unsigned int *bloom;
+	int adopted;    // the filter was already in HBM (left there by bfc_count), not uploaded
 	uint8_t *d_seq, *d_flags;
 	uint64_t *d_off;
 	int32_t *d_start, *d_end;
@@ -708,8 +755,12 @@ extern "C" bfcg_trim_t *bfcg_trim_create(int k, const bfc_bf_t *bf, int device, 
 	t->device = device; t->max_pos = max_pos; t->max_reads = max_reads;
 	HIPCKN(hipStreamCreate(&t->st));
 	HIPCKN(hipEventCreate(&t->e0)); HIPCKN(hipEventCreate(&t->e1));
-	HIPCKN(hipMalloc(&t->bloom, 1ULL << (bf->n_shift - 3)));
-	HIPCKN(hipMemcpy(t->bloom, bf->b, 1ULL << (bf->n_shift - 3), hipMemcpyHostToDevice));
+	t->bloom = (unsigned int *)resident_take(bf, device); // left in HBM by bfc_count (bfcg_export_bloom_resident)?
+	t->adopted = t->bloom != 0;
+	if (!t->bloom) {
+		HIPCKN(hipMalloc(&t->bloom, 1ULL << (bf->n_shift - 3)));
+		HIPCKN(hipMemcpy(t->bloom, bf->b, 1ULL << (bf->n_shift - 3), hipMemcpyHostToDevice));
+	}
 	HIPCKN(hipMalloc(&t->d_seq, max_pos)); HIPCKN(hipMalloc(&t->d_flags, max_pos));
 	HIPCKN(hipMalloc(&t->d_off, (max_reads + 1) * 8));
 	HIPCKN(hipMalloc(&t->d_start, max_reads * 4)); HIPCKN(hipMalloc(&t->d_end, max_reads * 4));
@@ -749,6 +800,7 @@ extern "C" int bfcg_trim_batch(bfcg_trim_t *t, const uint8_t *h_seq, const uint8
 	return 0;
 }
 extern "C" float bfcg_trim_last_ms(bfcg_trim_t *t) { return t->last_ms; }
+extern "C" int bfcg_trim_adopted(bfcg_trim_t *t) { return t->adopted; }
 extern "C" void *bfcg_trim_dev_seq(bfcg_trim_t *t) { return t->d_seq; }
 
 // ---------------------------------------------------------------------------------------------------------------

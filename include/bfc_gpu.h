@@ -148,6 +148,10 @@ int bfcg_stage_ms(bfcg_ctx_t *c, double out[6], uint64_t *n_batches, int reset);
 /* results */
 int bfcg_bloom_to_host(bfcg_ctx_t *c, int which /*0: bf, 1: bf_high*/, uint8_t *dst);   /* 2^(bf_shift-3) / n_ranks bytes: the owned slice */
 bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which);   /* host bfc_bf_t (caller: bfc_bf_destroy) */
+/* the same, and a copy of the filter stays in HBM behind the returned object until bfc_bf_destroy / a host bfc_bf_insert on it:
+ * bfcg_trim_create on the same device adopts that copy instead of uploading 2^(n_shift-3) bytes (`bfc -1`: count.c:153 -> correct.c:556) */
+bfc_bf_t *bfcg_export_bloom_resident(bfcg_ctx_t *c, int which);
+void bfcg_resident_drop(const void *bf);                   /* drop the HBM copy behind a host filter, if there is one */
 bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (caller: bfc_ch_destroy) */
 
 /* Ingest only, no GPU: parses `fn` (FASTA/FASTQ, plain or gzip) into the batches bfc_count would submit -- kseq's grammar
@@ -175,6 +179,7 @@ void bfcg_trim_destroy(bfcg_trim_t *t);
 int bfcg_trim_batch(bfcg_trim_t *t, const uint8_t *h_seq, const uint8_t *d_seq, uint64_t n_pos, const uint64_t *h_off, uint64_t n_reads,
                     float min_frac, int32_t *start, int32_t *end);
 float bfcg_trim_last_ms(bfcg_trim_t *t);   /* GPU time of the last batch's query + streak kernels (HIP events) */
+int bfcg_trim_adopted(bfcg_trim_t *t);     /* 1 if the filter was found resident in HBM (no upload) */
 void *bfcg_trim_dev_seq(bfcg_trim_t *t);   /* the context's device staging buffer (max_pos bytes) */
 
 /* k-mer coverage of the corrector: replaces, for a whole batch of reads, bfc_ec_kcov (correct.c:96-117) as

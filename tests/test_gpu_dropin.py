@@ -149,6 +149,44 @@ def test_gpu_trim_pass_matches_reference(gpu_lib, g1):
     tr.close(); bf.close(); oc.close()
 
 
+def test_filter_left_in_hbm_for_the_trim_pass(gpu_lib, g1):
+    """bfc_count leaves bf_high in HBM behind the host object it returns (bfcg_export_bloom_resident); the trim context adopts that
+    copy (no upload) and trims exactly as from an uploaded filter.  The copy goes away with the host object, and a host-side
+    bfc_bf_insert makes it stale: the next trim context uploads the modified host bytes."""
+    rs, (seq, qual, off) = g1
+    k, b = 31, 24
+    g = gpu_lib.GpuCounter(k, b, filter_mode=1, max_batch_pos=len(seq) + rs.n_reads + 64)
+    s_seq, s_qual = gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off)
+    g.count_host(s_seq, s_qual)
+    plain, res, res2 = g.export_bloom(1), g.export_bloom(1, resident=True), g.export_bloom(1, resident=True)
+    g.close()
+    assert np.array_equal(plain.bytes(), res.bytes())
+    soff = off + np.arange(rs.n_reads + 1, dtype=np.uint64)
+    kw = dict(max_pos=len(s_seq) + 64, max_reads=rs.n_reads)
+    t0 = gpu_lib.GpuTrimmer(k, plain, **kw); t1 = gpu_lib.GpuTrimmer(k, res, **kw)
+    assert not t0.adopted and t1.adopted
+    a0, a1 = t0.trim(s_seq, soff, 0.9), t1.trim(s_seq, soff, 0.9)
+    assert np.array_equal(a0[0], a1[0]) and np.array_equal(a0[1], a1[1]) and (a0[0] >= 0).sum() > 100
+    t2 = gpu_lib.GpuTrimmer(k, res, **kw)  # the copy was handed over to t1: a second context uploads
+    assert not t2.adopted
+    t0.close(); t1.close(); t2.close()
+    # a host write through the library drops the stale copy: the next context sees the host's bytes
+    from bfc_amd import _lib
+    L = _lib.load()
+    before = res2.bytes().copy()
+    rng = np.random.default_rng(3)
+    for h in rng.integers(0, 1 << 62, 200000, dtype=np.uint64):
+        L.bfc_bf_insert(res2.ptr, int(h))
+    assert not np.array_equal(before, res2.bytes())
+    t3 = gpu_lib.GpuTrimmer(k, res2, **kw)
+    assert not t3.adopted
+    a3 = t3.trim(s_seq, soff, 0.9)
+    assert (a3[0] >= 0).sum() >= (a0[0] >= 0).sum()  # more bits set: never fewer reads kept
+    t3.close()
+    res3_probe = gpu_lib.GpuTrimmer(k, plain, **kw); assert not res3_probe.adopted; res3_probe.close()
+    plain.close(); res.close(); res2.close()
+
+
 GPUTRIM = os.path.join(oracle.REF_DIR, "bfc-dropin-gputrim")
 
 
