@@ -7,8 +7,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <sys/mman.h>
 #include <atomic>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include "bfc_gpu.h"
 #include "bfcg_internal.h"
 #include "bfc_host.h"
@@ -608,14 +611,50 @@ extern "C" int bfcg_stage_ms(bfcg_ctx_t *c, double out[6], uint64_t *n_batches, 
 extern "C" uint64_t bfcg_stream_batches(bfcg_ctx_t *c) { return c->n_stream_batches; }
 extern "C" int bfcg_last_batch_ms(bfcg_ctx_t *c, float out[6]) { for (int i = 0; i < 6; ++i) out[i] = c->last_ms[i]; return 0; }
 
+// Large device -> pageable host copies (a 16 GiB filter, a 64 GiB table).  hipMemcpy into pageable memory stages through one
+// pinned buffer and one host thread, whose memcpy into never-touched pages (page faults) sets the pace at about a third of the PCIe
+// rate.  Here T threads each own every T-th 32 MiB chunk: D2H into their own pinned buffer on their own stream, then memcpy to the
+// destination -- the copies of some threads run under the page faults of the others.  The device must be idle on `src`.
+static int d2h_parallel(int device, void *dst, const void *src, uint64_t bytes)
+{
+	const uint64_t CH = 32ull << 20;
+	const char *env = getenv("BFC_GPU_D2H_THREADS");
+	int T = env ? atoi(env) : 8;
+	if (T > 32) T = 32;
+	if (T < 2 || bytes < 8 * CH) {
+		HIPCK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+		return 0;
+	}
+	if (!getenv("BFC_GPU_NO_THP")) { // fresh destination pages: ask for 2 MiB ones (512x fewer page faults); advisory, ignored where unsupported
+		const uintptr_t a = ((uintptr_t)dst + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), e = ((uintptr_t)dst + bytes) & ~(uintptr_t)((2u << 20) - 1);
+		if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+	}
+	std::vector<hipError_t> err((size_t)T, hipSuccess);
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; ++t)
+		th.emplace_back([&, t]() {
+			void *stage = 0; hipStream_t st = 0; hipError_t e;
+			if ((e = hipSetDevice(device)) != hipSuccess || (e = hipHostMalloc(&stage, CH, hipHostMallocDefault)) != hipSuccess) { err[t] = e; return; }
+			if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { err[t] = e; (void)hipHostFree(stage); return; }
+			for (uint64_t o = (uint64_t)t * CH; o < bytes; o += (uint64_t)T * CH) {
+				const uint64_t n = bytes - o < CH ? bytes - o : CH;
+				if ((e = hipMemcpyAsync(stage, (const char *)src + o, n, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) { err[t] = e; break; }
+				memcpy((char *)dst + o, stage, n);
+			}
+			(void)hipStreamDestroy(st); (void)hipHostFree(stage);
+		});
+	for (auto &x : th) x.join();
+	for (int t = 0; t < T; ++t) if (err[t] != hipSuccess) return set_err("device-to-host copy failed: %s", hipGetErrorString(err[t]));
+	return 0;
+}
+
 extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)
 {
 	unsigned long long *src = which ? c->B.bloom_hi : c->B.bloom;
 	if (!src) return set_err("bloom filter %d does not exist in this mode", which);
 	if (drain(c) != 0) return -1;
-	HIPCK(hipMemcpyAsync(dst, src, c->bloom_bytes, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	return 0;
+	return d2h_parallel(c->prm.device, dst, src, c->bloom_bytes);
 }
 
 extern "C" bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which)
@@ -676,12 +715,13 @@ extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 	if (drain(c) != 0) return NULL;
 	bfc_ch_t *ch = bfc_ch_alloc_raw(c->P.k, c->P.l_pre, c->P.tab_cshift);
 	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
-	if (hipMemcpyAsync(bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
-	    hipStreamSynchronize(c->st) != hipSuccess) { set_err("D2H copy of the count table failed"); bfc_ch_destroy(ch); return NULL; }
+	if (hipStreamSynchronize(c->st) != hipSuccess || d2h_parallel(c->prm.device, bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift)) != 0) {
+		set_err("D2H copy of the count table failed"); bfc_ch_destroy(ch); return NULL;
+	}
 	if (c->B.tab_first) { // order stamps travel with the table (with several ranks: into bfc_ch_union): bfc_ch_dump can then reproduce khash's layout byte for byte
 		uint64_t *hf = 0, *hl = 0;
 		if (bfc_ch_raw_order(ch, &hf, &hl) != 0 ||
-		    hipMemcpyAsync(hf, c->B.tab_first, 8ULL << (c->P.l_pre + c->P.tab_cshift), hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+		    d2h_parallel(c->prm.device, hf, c->B.tab_first, 8ULL << (c->P.l_pre + c->P.tab_cshift)) != 0 ||
 		    hipMemcpyAsync(hl, c->B.sub_last, 8ULL << c->P.l_pre, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
 		    hipStreamSynchronize(c->st) != hipSuccess) { set_err("D2H copy of the order stamps failed"); bfc_ch_destroy(ch); return NULL; }
 	}
