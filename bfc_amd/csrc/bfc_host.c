@@ -15,6 +15,7 @@
 #include <assert.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include "bfc_gpu.h"
 #include "bfc_host.h"
 
@@ -140,12 +141,43 @@ int bfc_ch_raw_order(bfc_ch_t *ch, uint64_t **first, uint64_t **sub_last)
 	return 0;
 }
 static void drop_order(bfc_ch_t *ch) { free(ch->first); free(ch->sub_last); ch->first = ch->sub_last = 0; }
-void bfc_ch_raw_recount(bfc_ch_t *ch)
+/* one pass over all slots: keys, count histogram, high-count histogram.  A human-sized table is 2^33 slots (64 GiB): the pass is split
+ * over up to 16 threads from 2^24 slots on (read-only, so callers' concurrent reads stay safe). */
+typedef struct { const uint64_t *slots; uint64_t beg, end, keys, cnt[256], high[64]; } scan_t;
+static void *scan_worker(void *p)
 {
-	uint64_t i, n = (uint64_t)1 << (ch->l_pre + ch->cshift), c = 0;
-	for (i = 0; i < n; ++i) c += ch->slots[i] != 0;
-	ch->n_keys = c;
+	scan_t *w = (scan_t*)p;
+	uint64_t i;
+	for (i = w->beg; i < w->end; ++i) {
+		uint64_t v = w->slots[i];
+		if (v) { ++w->keys; ++w->cnt[v & 0xff]; ++w->high[v >> 8 & 0x3f]; }
+	}
+	return 0;
 }
+static uint64_t scan_slots(const bfc_ch_t *ch, uint64_t cnt[256], uint64_t high[64])
+{
+	uint64_t n = (uint64_t)1 << (ch->l_pre + ch->cshift), keys = 0;
+	int T = 1, t, j;
+	scan_t *w;
+	pthread_t tid[16];
+	if (n >= (1ULL << 24)) { long nc = sysconf(_SC_NPROCESSORS_ONLN); T = nc >= 16 ? 16 : nc > 1 ? (int)nc : 1; }
+	w = (scan_t*)calloc((size_t)T, sizeof(scan_t));
+	for (t = 0; t < T; ++t) { w[t].slots = ch->slots; w[t].beg = n / T * t; w[t].end = t == T - 1 ? n : n / T * (t + 1); }
+	for (t = 1; t < T; ++t) if (pthread_create(&tid[t], 0, scan_worker, &w[t]) != 0) { scan_worker(&w[t]); tid[t] = 0; }
+	scan_worker(&w[0]);
+	for (t = 1; t < T; ++t) if (tid[t]) pthread_join(tid[t], 0);
+	if (cnt) memset(cnt, 0, 256 * 8);
+	if (high) memset(high, 0, 64 * 8);
+	for (t = 0; t < T; ++t) {
+		keys += w[t].keys;
+		if (cnt) for (j = 0; j < 256; ++j) cnt[j] += w[t].cnt[j];
+		if (high) for (j = 0; j < 64; ++j) high[j] += w[t].high[j];
+	}
+	free(w);
+	return keys;
+}
+void bfc_ch_raw_recount(bfc_ch_t *ch) { ch->n_keys = scan_slots(ch, 0, 0); }
+void bfc_ch_raw_set_count(bfc_ch_t *ch, uint64_t n_keys) { ch->n_keys = n_keys; } /* the builder already knows it */
 /* Union of tables whose key sets are disjoint -- the per-GPU tables of an owner-computes run: every key lives on
  * exactly one rank, so the union IS the reference's table.  Order stamps travel along (first[] per key; sub_last[] = the latest of the
  * ranks'), which keeps bfc_ch_dump byte-identical to `bfc -t1 -d` across GPUs: the stamps are (batch << 32 | rank-major file index),
@@ -315,13 +347,9 @@ uint64_t bfc_ch_count(const bfc_ch_t *ch) { return ch->n_keys; }
 
 int bfc_ch_hist(const bfc_ch_t *ch, uint64_t cnt[256], uint64_t high[64])
 {
-	uint64_t i, n = (uint64_t)1 << (ch->l_pre + ch->cshift), max = 0;
+	uint64_t i, max = 0;
 	int max_i = -1;
-	memset(cnt, 0, 256 * 8); memset(high, 0, 64 * 8);
-	for (i = 0; i < n; ++i) {
-		uint64_t v = ch->slots[i];
-		if (v) { ++cnt[v & 0xff]; ++high[v >> 8 & 0x3f]; }
-	}
+	scan_slots(ch, cnt, high);
 	for (i = 3; i < 256; ++i) if (cnt[i] > max) { max = cnt[i]; max_i = (int)i; }
 	return max_i;
 }
@@ -391,6 +419,7 @@ int bfc_ch_dump(const bfc_ch_t *ch, const char *fn)
 	uint32_t t[2], c = 1u << ch->cshift, j;
 	uint64_t s, n_sub = (uint64_t)1 << ch->l_pre;
 	ord_t *ord = ch->first ? (ord_t*)malloc((size_t)c * sizeof(ord_t)) : 0;
+	uint64_t *pack = 0;
 	if ((fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout) == 0) { free(ord); return -1; }
 	t[0] = (uint32_t)ch->k; t[1] = (uint32_t)ch->l_pre;
 	fwrite(t, 4, 2, fp);
@@ -417,9 +446,14 @@ int bfc_ch_dump(const bfc_ch_t *ch, const char *fn)
 		if (size) for (nb = 4; size >= (nb >> 2) + (nb >> 1); nb <<= 1);
 		t[0] = nb; t[1] = size;
 		fwrite(t, 4, 2, fp);
-		for (j = 0; j < c; ++j) if (reg[j]) fwrite(&reg[j], 8, 1, fp);
+		if (size) { /* one write per sub-table, not one per key */
+			uint32_t n = 0;
+			if (!pack) pack = (uint64_t*)malloc((size_t)c * 8);
+			for (j = 0; j < c; ++j) if (reg[j]) pack[n++] = reg[j];
+			fwrite(pack, 8, n, fp);
+		}
 	}
-	free(ord);
+	free(ord); free(pack);
 	fprintf(stderr, "[M::%s] dumpped the hash table to file '%s'.\n", __func__, fn);
 	if (fp != stdout) fclose(fp);
 	return 0;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "bfc_gpu.h"
+#include "bfc_host.h"
 
 static uint64_t rs = 88172645463325252ULL;
 static uint64_t rnd(void) { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; }
@@ -72,6 +73,18 @@ int main(int argc, char **argv)
 		}
 		if (r) bfc_ch_destroy(r);
 		bfc_ch_destroy(a); bfc_ch_destroy(b); free(xs);
+	}
+	{ /* the threaded slot scan (tables of 2^24 slots and more) against the single-threaded one on the same inserts */
+		bfc_ch_t *big = bfc_ch_alloc_raw(31, 20, 5), *small = bfc_ch_init(31, 20);
+		uint64_t c1[256], h1[64], c2[256], h2[64], m = (1ULL << 31) - 1; int i, m1, m2;
+		for (i = 0; i < 300000; ++i) {
+			uint64_t x[2]; int hi = rnd() & 1;
+			x[0] = rnd() & m & ~0xffULL; x[1] = (rnd() & m) >> (rnd() % 24); /* few distinct values: counts of 3 and more appear */
+			bfc_ch_insert(big, x, hi, 1); bfc_ch_insert(small, x, hi, 1);
+		}
+		m1 = bfc_ch_hist(big, c1, h1); m2 = bfc_ch_hist(small, c2, h2);
+		if (m1 != m2 || memcmp(c1, c2, sizeof(c1)) || memcmp(h1, h2, sizeof(h1)) || bfc_ch_count(big) != bfc_ch_count(small)) { fprintf(stderr, "threaded histogram differs\n"); ++bad; }
+		bfc_ch_destroy(big); bfc_ch_destroy(small);
 	}
 	{ /* bloom filter host calls */
 		bfc_bf_t *bf = bfc_bf_init(20, 4); int i, seen = 0;

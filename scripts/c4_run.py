@@ -20,6 +20,7 @@ ap.add_argument("--seed", type=int, default=4)
 ap.add_argument("--batch-reads", type=int, default=4194304)
 ap.add_argument("--filter-mode", type=int, default=0)
 ap.add_argument("--trim", type=int, default=0, help="1 (with --filter-mode 1): then the trim pass of bfc -1 over the same reads (bloom query kernel + longest streak)")
+ap.add_argument("--export", type=int, default=0, help="1 (table mode): bring the count table to the host as bfc_count does and check it there (bfc_ch_count, bfc_ch_hist)")
 ap.add_argument("--popcount", type=int, default=0, help="1: bring the filter(s) to the host and count their bits")
 args = ap.parse_args()
 K = args.k
@@ -81,6 +82,15 @@ if args.popcount:
         bits = g.bloom_bytes(which)
         res["bloom%d_popcount" % which] = int(oracle.lib().orc_popcount_bytes(bits.ctypes.data, len(bits)))
         del bits
+if args.export and not args.filter_mode:
+    t2 = time.time(); tab = g.export_table(); t3 = time.time()
+    mode, cnt, high = tab.hist(); t4 = time.time()
+    assert tab.count() == st["n_keys"] == int(cnt.sum()) == int(high.sum()), (tab.count(), st["n_keys"], int(cnt.sum()))
+    sat = int(cnt[255])
+    lo = int((np.arange(256, dtype=np.uint64) * cnt).sum())  # = n_seen when no counter saturated, a lower bound otherwise
+    assert lo <= st["n_seen"] and (sat > 0 or lo == st["n_seen"]), (lo, st["n_seen"], sat)
+    res.update(export_s=round(t3 - t2, 2), export_GiB=round(8 * 2.0 ** ((20 if K <= 36 else 24) + st["tab_cshift"]) / 2 ** 30, 1), hist_s=round(t4 - t3, 2), hist_mode=int(mode), cnt_saturated=sat, sum_i_cnt=lo)
+    tab.close()
 if args.trim and args.filter_mode:
     t2 = time.time()
     bf = g.export_bloom(1)
