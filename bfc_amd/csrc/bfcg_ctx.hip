@@ -621,7 +621,7 @@ static int d2h_parallel(int device, void *dst, const void *src, uint64_t bytes)
 	const char *env = getenv("BFC_GPU_D2H_THREADS");
 	int T = env ? atoi(env) : 8;
 	if (T > 32) T = 32;
-	if (T < 2 || bytes < 8 * CH) {
+	if (T < 2 || bytes < (2ull << 30)) { // below 2 GiB the threads' set-up (pinned buffers, streams: 0.1 s) costs more than it saves
 		HIPCK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
 		return 0;
 	}
