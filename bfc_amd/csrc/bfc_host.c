@@ -49,6 +49,7 @@ bfc_bf_t *bfc_bf_alloc_raw(int n_shift, int n_hashes)
 	if (n_shift + BFC_BLK_SHIFT > 64 || n_shift < BFC_BLK_SHIFT) return 0;
 	b = (bfc_bf_t*)calloc(1, sizeof(bfc_bf_t));
 	if (!b) return 0;
+	if (bfcg_resident_drop) bfcg_resident_drop(b); /* an address can come back: whatever was registered for it belongs to a dead object */
 	b->n_shift = n_shift; b->n_hashes = n_hashes;
 	if (posix_memalign(&p, 64, 1ULL << (n_shift - 3)) != 0) { free(b); return 0; }
 	b->b = (uint8_t*)p;
