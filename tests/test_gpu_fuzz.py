@@ -2,6 +2,8 @@
 FASTA/FASTQ, batch cuts, region size and initial table size drawn from a seeded generator; every draw is checked bit for bit against the
 oracle (bloom bitmaps L0, statistics, table L1).  Small inputs, many shapes: one-level and two-level partitions (bf_shift 10..27),
 single-block regions, tables that grow several times, k from 5 to 63."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,8 +12,11 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
+SEED_BASE = int(os.environ.get("BFC_FUZZ_SEED_BASE", "0"))  # other values draw other configurations (scripts/more_fuzz.sh)
+
+
 def _draw(seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + 100003 * SEED_BASE)
     k = int(rng.choice([5, 9, 13, 17, 21, 25, 27, 29, 31, 32, 33, 35, 39, 47, 48, 55, 63]))
     b = int(rng.integers(10, 28))
     nh = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 7, 12]))
