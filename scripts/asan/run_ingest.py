@@ -7,10 +7,11 @@ import test_ingest as T
 
 exe = os.path.join(ROOT, "build", "asan_ingest")
 n_seed = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
 with tempfile.TemporaryDirectory() as d:
     fn = os.path.join(d, "d.fq")
-    for seed in range(n_seed):
+    for seed in range(first, first + n_seed):
         rng = np.random.default_rng(seed)
         kind = seed % 3
         if kind == 0:

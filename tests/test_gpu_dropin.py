@@ -238,7 +238,7 @@ def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
     -> `bfc -E -d` with the GPU count path (serial parser with -t1, multi-threaded one with -t4) writes the very bytes the reference
     binary writes with -t1 (BFC_GPU_EXACT_DUMP=1), for two chunk sizes."""
     from test_ingest import _fastq, _mutate
-    rng = np.random.default_rng(100 + seed)
+    rng = np.random.default_rng(100 + seed + 100003 * int(os.environ.get("BFC_FUZZ_SEED_BASE", "0")))
     data = _fastq(rng, 3000, 20, 160, crlf=seed == 3) if seed % 2 == 0 else _fastq(rng, 1500, 20, 160) + b">fa x\nACGTTGCAACGTTTGACCA\nACGGGT\n" + _fastq(rng, 1500, 20, 160)
     fn = str(tmp_path / "d.fq")
     open(fn, "wb").write(_mutate(rng, data))
@@ -264,7 +264,7 @@ def test_gpu_trim_equals_reference_binary_on_damaged_files(tmp_path, seed):
     """`bfc -1` with both phases on the GPU vs the reference binary on damaged FASTQ / FASTA text: stdout (names, inherited comments,
     FASTA / FASTQ form, trimmed windows) byte for byte, and the `read N sequences` lines of both passes."""
     from test_ingest import _fastq, _mutate
-    rng = np.random.default_rng(200 + seed)
+    rng = np.random.default_rng(200 + seed + 100003 * int(os.environ.get("BFC_FUZZ_SEED_BASE", "0")))
     genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 20000)
     eol = b"\r\n" if seed == 5 else b"\n"
     recs = []
@@ -291,7 +291,7 @@ def test_gpu_trim_equals_reference_binary_on_damaged_files(tmp_path, seed):
         want = [l for l in r.stderr.decode().splitlines() if "] read " in l]
         got = [l for l in g.stderr.decode().splitlines() if "] read " in l]
         assert got == want, (seed, extra)
-        assert len(r.stdout) > 100000
+        assert len(r.stdout) > 100000 or os.environ.get("BFC_FUZZ_SEED_BASE", "0") != "0"  # the stock seeds keep most of the text; other bases may truncate early
 
 
 def test_gpu_trim_pass_on_a_large_filter(gpu_lib, g1):
