@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 SEED_BASE = int(os.environ.get("BFC_FUZZ_SEED_BASE", "0"))  # other values draw other configurations (scripts/more_fuzz.sh)
 
 
-def _draw(seed):
+def _draw(seed, scale=1):
     rng = np.random.default_rng(seed + 100003 * SEED_BASE)
     k = int(rng.choice([5, 9, 13, 17, 21, 25, 27, 29, 31, 32, 33, 35, 39, 47, 48, 55, 63]))
     b = int(rng.integers(10, 28))
@@ -23,7 +23,7 @@ def _draw(seed):
     l_pre = int(rng.choice([v for v in (4, 8, 12, 16, 20) if v <= 2 * k - 2]))  # htab.c:49-50 shifts by 2k - l_pre: the reference needs it positive
     q = int(rng.choice([-50, 0, 10, 20, 30, 41, 94, 100]))
     fm = int(rng.random() < 0.25)
-    n = int(rng.integers(1, 1500))
+    n = int(rng.integers(1, 1500 * scale))
     cov = float(rng.choice([0.5, 2, 8, 40]))
     lmax = int(rng.choice([3, 40, 151, 600]))
     lens = rng.integers(0, lmax + 1, n)
@@ -53,9 +53,7 @@ def _draw(seed):
     return dict(k=k, b=b, nh=nh, l_pre=l_pre, q=q, fm=fm), seq, qual, off, cuts, kw
 
 
-@pytest.mark.parametrize("seed", range(120))
-def test_random_configuration(gpu_lib, seed):
-    prm, seq, qual, off, cuts, kw = _draw(1000 + seed)
+def _check(gpu_lib, prm, seq, qual, off, cuts, kw):
     n = len(off) - 1
     oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
     oc.count(seq, qual, off)
@@ -67,7 +65,7 @@ def test_random_configuration(gpu_lib, seed):
         qq = gpu_lib.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None
         g.count_host(s, qq)
     ost, st = oc.stats(), g.stats()
-    tag = "%r cuts=%r %r" % (prm, cuts, kw)
+    tag = "%r cuts=%r %r reads=%d bases=%d" % (prm, cuts, kw, n, len(seq))
     assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"]), tag
     assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes()), tag
     if prm["fm"]:
@@ -77,6 +75,18 @@ def test_random_configuration(gpu_lib, seed):
         osz, osl = oc.export()
         assert np.array_equal(sizes, osz) and np.array_equal(slots, osl), tag
     g.close(); oc.close()
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_configuration(gpu_lib, seed):
+    _check(gpu_lib, *_draw(1000 + seed))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_medium_configuration(gpu_lib, seed):
+    """the same draws at 40x the size (up to 60 000 reads, tens of millions of positions): many tiles per bucket, multi-chunk scans, full
+    aggregation tables, table growth inside a batch, STREAM mode decisions -- still bit for bit the oracle's filter(s), statistics and table"""
+    _check(gpu_lib, *_draw(20000 + seed, scale=int(os.environ.get("BFC_FUZZ_SCALE", "40"))))
 
 
 @pytest.mark.parametrize("seed", range(24))
