@@ -94,7 +94,7 @@ def test_random_configuration_on_emulated_ranks(gpu_lib, seed):
     """the same draws through the multi-GPU stages: 2 / 4 / 8 ranks emulated on one device (LocalCluster), ragged rank shares, ranks
     with nothing to contribute; global batches in rank-major order must equal the sequential oracle"""
     from bfc_amd import dist as bdist
-    prm, seq, qual, off, cuts, kw = _draw(5000 + seed)
+    prm, seq, qual, off, cuts, kw = _draw(5000 + seed, scale=int(os.environ.get("BFC_FUZZ_RANK_SCALE", "1")))  # 40: the medium-size draws through the rank stages
     rng = np.random.default_rng(seed)
     world = int(rng.choice([2, 4, 8]))
     if prm["b"] < 21:
