@@ -507,7 +507,11 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 static uint64_t split_limit(const bfcg_ctx_t *c)
 {
 	const uint64_t nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
-	return (uint64_t)((double)nfine * (double)c->P.list_cap * 1.15); // positions; ~0.8 k-mers per position
+	// positions; ~0.8 k-mers per position.  In the first batch of an empty filter every k-mer has clear bits, and a region's load varies by far
+	// more than sqrt(mean) -- its few dozen distinct genome k-mers come at coverage/4 copies each -- so the cut sits below list_cap on average:
+	// c2 at 1 048 576 reads per batch ran at 12.2 instead of 25 G k-mers/s with the cut at 1.15 (5 % of the regions on the slow path).
+	// Callers split from 7/6 of this on: just above the limit a few hundred slow regions cost less (5 %) than a second pass over the filter (12 %).
+	return (uint64_t)((double)nfine * (double)c->P.list_cap * 0.95);
 }
 static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
 // last cut point in (lo, hi]: index just behind a non-ACGT byte, searched backwards from hi over at most 1 MiB; 0 = none
@@ -534,10 +538,11 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
 	const uint64_t lim = split_limit(c);
-	if (!c->B.seen_out && n_pos > lim + lim / 4) { // oversized for this filter: sub-batches of about `lim` positions
+	if (!c->B.seen_out && n_pos > lim + lim / 6) { // oversized for this filter: equal sub-batches of at most `lim` positions
+		const uint64_t target = n_pos / ((n_pos + lim - 1) / lim) + 1;
 		uint64_t o = 0;
-		while (n_pos - o > lim + lim / 4) {
-			const uint64_t cut = find_cut(c, 0, d_seq, o, o + lim);
+		while (n_pos - o > target + target / 8) {
+			const uint64_t cut = find_cut(c, 0, d_seq, o, o + target);
 			if (cut == 0) break; // a megabase without a cut point: take the rest as it is
 			if (bfcg_count_batch_dev(c, d_seq + o, d_qual ? d_qual + o : 0, cut - o) != 0) return -1;
 			o = cut;
@@ -556,10 +561,11 @@ extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const 
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
 	const uint64_t lim = split_limit(c);
-	if (!c->B.seen_out && n_pos > lim + lim / 4) { // oversized for this filter: sub-batches (see bfcg_count_batch_dev)
+	if (!c->B.seen_out && n_pos > lim + lim / 6) { // oversized for this filter: equal sub-batches of at most `lim` positions (see bfcg_count_batch_dev)
+		const uint64_t target = n_pos / ((n_pos + lim - 1) / lim) + 1;
 		uint64_t o = 0;
-		while (n_pos - o > lim + lim / 4) {
-			const uint64_t cut = find_cut(c, h_seq, 0, o, o + lim);
+		while (n_pos - o > target + target / 8) {
+			const uint64_t cut = find_cut(c, h_seq, 0, o, o + target);
 			if (cut == 0) break;
 			if (bfcg_count_batch_host(c, h_seq + o, h_qual ? h_qual + o : 0, cut - o) != 0) return -1;
 			o = cut;
