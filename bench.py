@@ -156,8 +156,13 @@ def main():
     stride = rs.L + 1
     batch_reads = min(args.batch_reads, n_reads)
 
+    # Weak scaling keeps the work PER GPU fixed: every rank brings its own c2 read set (another genome: seed 2 + rank) and owns 2^33 bits of
+    # the filter, so with N ranks the job is one count of N x c2 into a filter of 2^33 x N bits (-b 33 + log2 N) -- what `bfc -s` does for an
+    # N times larger genome.  With the filter fixed at -b33 every bloom region would receive N times a single-GPU batch's k-mers per global
+    # batch, more than a region's LDS list takes: all of them on the exact but ~25x slower path (scripts/mg_load.py).
     def make_counter(n_ranks):
-        return bfc_amd.GpuCounter(K, BF_SHIFT, q=Q, n_hashes=N_HASHES, l_pre=L_PRE, device=local, max_batch_pos=batch_reads * stride,
+        shift = BF_SHIFT + (n_ranks.bit_length() - 1 if n_ranks > 1 else 0)
+        return bfc_amd.GpuCounter(K, shift, q=Q, n_hashes=N_HASHES, l_pre=L_PRE, device=local, max_batch_pos=batch_reads * stride,
                                   rank=rank if n_ranks > 1 else 0, n_ranks=n_ranks)
 
     # owner-computes exchange over RCCL; a collective preflight decides for ALL ranks whether it is usable here
@@ -184,7 +189,7 @@ def main():
             ok = 0
         flag = torch.tensor([ok], device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            mode = "dp%d: read shards per GPU, bloom regions + table keys owned by one GPU each, 1 all-to-all of %d-byte k-mer records per batch (RCCL)" % (world, g.mg_info()["rec_bytes"])
+            mode = "dp%d: read shards per GPU (one c2 read set each), ONE filter of 2^%d bits (2^33 per GPU) and one table, bloom regions + table keys owned by one GPU each, 1 all-to-all of %d-byte k-mer records per batch (RCCL)" % (world, BF_SHIFT + world.bit_length() - 1, g.mg_info()["rec_bytes"])
         else:
             eng = None
             g = make_counter(1)

@@ -66,6 +66,7 @@ SYMBOLS = {
     "bfcg_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_sync": (C.c_int, [C.c_void_p]),
     "bfcg_mg_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "bfcg_batch_limit": (C.c_uint64, [C.c_void_p]),
     "bfcg_mg_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, u32p]),
     "bfcg_mg_process": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
     "bfcg_trim_create": (C.c_void_p, [C.c_int, C.POINTER(BfcBf), C.c_int, C.c_uint64, C.c_uint64]),

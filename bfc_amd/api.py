@@ -241,6 +241,10 @@ class GpuCounter:
         self.L.bfcg_mg_info(self.ctx, out)
         return dict(nb1=out[0], nb_loc=out[1], rec_bytes=out[2], n_ranks=out[3])
 
+    def batch_limit(self):
+        """positions per batch (per rank: of the global batch / n_ranks) the filter's regions take at full speed"""
+        return int(self.L.bfcg_batch_limit(self.ctx))
+
     def mg_scatter(self, d_seq, d_qual, n_pos, d_send):
         counts = np.zeros(self.mg_info()["nb1"], dtype=np.uint32)
         self._ck(self.L.bfcg_mg_scatter(self.ctx, d_seq, d_qual, n_pos, d_send, counts.ctypes.data_as(u32p)))

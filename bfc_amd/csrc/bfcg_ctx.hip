@@ -531,6 +531,9 @@ static uint64_t find_cut(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *d_s
 	return cut > lo ? cut : 0;
 }
 
+// positions of a batch this context's regions take at full speed (with several ranks: of the global batch, divided by the ranks)
+extern "C" uint64_t bfcg_batch_limit(bfcg_ctx_t *c) { return split_limit(c); }
+
 extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
 {
 	if (c->n_ranks > 1) return set_err("this context is one of %d ranks: use bfcg_mg_scatter / bfcg_mg_process", c->n_ranks);

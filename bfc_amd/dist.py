@@ -79,6 +79,7 @@ class GpuEngine:
         # two receive buffers: stage B of batch t is left running on buffer t % 2 while batch t + 1 is scattered and exchanged
         self._recv = [torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
         self._cur = 0
+        self.kmer_limit = int(counter.batch_limit() / 0.95)  # k-mers of a global batch this rank's regions take without the slow path
 
     @property
     def recv(self):
@@ -99,6 +100,12 @@ def count_batch(engine, d_seq, d_qual, n_pos, group=None):
     stage A and exchange overlap with it; engine.g.sync() / stats() / exports drain the pipeline."""
     counts = engine.scatter(d_seq, d_qual, n_pos)
     seg_cnt = exchange(engine, counts, group)
+    lim = getattr(engine, "kmer_limit", None)
+    if lim and int(seg_cnt.sum()) > lim and not getattr(engine, "_warned", False):
+        import warnings
+        engine._warned = True
+        warnings.warn("this rank received %d k-mers of one global batch, its bloom regions take about %d at full speed: "
+                      "use smaller shares or a larger filter (bfcg_batch_limit)" % (int(seg_cnt.sum()), lim))
     engine.process(seg_cnt)
     return seg_cnt
 

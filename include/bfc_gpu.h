@@ -122,6 +122,11 @@ int bfcg_sync(bfcg_ctx_t *c);
  * (all-to-all over RCCL) so that d_recv holds, source-major, the records of the owned buckets, and calls
  * bfcg_mg_process with seg_cnt[source][owned bucket].  info: {2^F1, owned buckets nb_loc, bytes per record, n_ranks}. */
 int bfcg_mg_info(bfcg_ctx_t *c, int out[4]);
+/* Positions per batch the filter's regions take at full speed (a region holds about list-capacity k-mers with clear bits in LDS; beyond
+ * that it takes an exact but far slower path).  bfcg_count_batch_* cut larger batches themselves.  With several ranks the GLOBAL batch
+ * (all ranks' shares together) should stay below n_ranks times this: size the filter, or the shares, accordingly -- bench.py keeps
+ * 2^33 bits of filter per rank. */
+uint64_t bfcg_batch_limit(bfcg_ctx_t *c);
 int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts);
 int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt);
 
