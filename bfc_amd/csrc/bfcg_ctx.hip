@@ -275,6 +275,10 @@ static int use_stream(bfcg_ctx_t *c);
 
 static int batch_times(bfcg_ctx_t *c, int b)
 {
+	// stage B's stream has been synchronised by the caller; the stage-A events of this slot sit on stream stA and are long complete when stage A
+	// did work, but an EMPTY stage A (a rank without a share, or the extra pairs of a batch processed in source groups) only records them,
+	// possibly behind that stream's wait for an older stage B: wait for them explicitly
+	for (int i = 0; i < 3; ++i) HIPCK(hipEventSynchronize(c->evt[b][i]));
 	for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&c->last_ms[i], c->evt[b][i == 2 ? 6 : i], c->evt[b][i + 1]));
 	c->last_ms[5] = c->last_ms[0] + c->last_ms[1] + c->last_ms[2] + c->last_ms[3] + c->last_ms[4]; // GPU time of the stages (they overlap across batches)
 	for (int i = 0; i < 6; ++i) c->sum_ms[i] += c->last_ms[i];

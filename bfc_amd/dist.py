@@ -65,6 +65,36 @@ def exchange(engine, counts, group=None):
     return theirs_h.numpy().astype(np.uint32)
 
 
+def process_in_groups(ctx, recv_ptr, seg_cnt, rec_bytes, kmer_limit):
+    """Stage B of one global batch on the owner.  When the rank received more k-mers than its bloom regions take at full speed
+    (bfcg_batch_limit) the sources are processed in consecutive groups, each its own stage B: the receive buffer is source-major and the
+    global order is rank-major, so a group's records all precede the next group's -- results are those of one big batch, without every
+    region overflowing its LDS list.  Not with order stamps (track_order): the batch number is part of a stamp and must agree across ranks.
+    Returns the number of stage-B launches."""
+    seg_cnt = np.ascontiguousarray(seg_cnt, dtype=np.uint32)
+    per_src = seg_cnt.astype(np.int64).sum(1)
+    if not kmer_limit or int(per_src.sum()) <= kmer_limit or len(per_src) == 1:
+        ctx.mg_process(recv_ptr, seg_cnt)
+        return 1
+    starts = np.concatenate([[0], np.cumsum(per_src)])
+    groups, g0, acc = [], 0, 0
+    for s_, n in enumerate(per_src):
+        if s_ > g0 and acc + int(n) > kmer_limit:
+            groups.append((g0, s_)); g0, acc = s_, 0
+        acc += int(n)
+    groups.append((g0, len(per_src)))
+    done = 0
+    for g0, g1 in groups:
+        if starts[g1] == starts[g0]:
+            continue
+        seg = np.zeros_like(seg_cnt); seg[g0:g1] = seg_cnt[g0:g1]
+        if done:  # stage A and stage B come in pairs (buffer sets, timing events): an empty stage A opens the next pair
+            ctx.mg_scatter(None, None, 0, None)
+        ctx.mg_process(recv_ptr + int(starts[g0]) * rec_bytes, seg)
+        done += 1
+    return done
+
+
 class GpuEngine:
     """Stage A / stage B on libbfc_gpu.so with torch-owned exchange buffers (torch is plumbing: device memory + RCCL)."""
 
@@ -79,6 +109,7 @@ class GpuEngine:
         # two receive buffers: stage B of batch t is left running on buffer t % 2 while batch t + 1 is scattered and exchanged
         self._recv = [torch.empty((cap + cap // 4 + (1 << 20)) * self.rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
         self._cur = 0
+        self.track = bool(getattr(counter.params, "track_order", 0))
         self.kmer_limit = int(counter.batch_limit() / 0.95)  # k-mers of a global batch this rank's regions take without the slow path
 
     @property
@@ -91,7 +122,8 @@ class GpuEngine:
     def process(self, seg_cnt):
         import torch
         torch.cuda.current_stream(self.send.device).synchronize()  # the exchange ran on torch's stream; stage B of the previous batch keeps running
-        self.g.mg_process(self.recv.data_ptr(), seg_cnt)  # returns once the previous batch is finalised: its receive buffer is free again
+        # returns once the previous stage B is finalised: its receive buffer is free again
+        process_in_groups(self.g, self.recv.data_ptr(), seg_cnt, self.rec_words * 4, None if self.track else self.kmer_limit)
         self._cur ^= 1
 
 
@@ -101,7 +133,7 @@ def count_batch(engine, d_seq, d_qual, n_pos, group=None):
     counts = engine.scatter(d_seq, d_qual, n_pos)
     seg_cnt = exchange(engine, counts, group)
     lim = getattr(engine, "kmer_limit", None)
-    if lim and int(seg_cnt.sum()) > lim and not getattr(engine, "_warned", False):
+    if lim and getattr(engine, "track", False) and int(seg_cnt.sum()) > lim and not getattr(engine, "_warned", False):
         import warnings
         engine._warned = True
         warnings.warn("this rank received %d k-mers of one global batch, its bloom regions take about %d at full speed: "
@@ -114,8 +146,10 @@ class LocalCluster:
     """N ranks emulated on ONE device by N contexts and a host-mediated exchange: exercises stage A / stage B, the
     segment bookkeeping and the rank-major order on real kernels where only one GPU is available (tests)."""
 
-    def __init__(self, gpu_lib, n_ranks, k, bf_shift, max_batch_pos, **kw):
+    def __init__(self, gpu_lib, n_ranks, k, bf_shift, max_batch_pos, kmer_limit=None, **kw):
         self.n = n_ranks
+        self.kmer_limit = kmer_limit  # None: from the contexts (bfcg_batch_limit); tests force small values to exercise the source groups
+        self.track = bool(kw.get("track_order"))
         self.ctx = [gpu_lib.GpuCounter(k, bf_shift, max_batch_pos=max_batch_pos, rank=r, n_ranks=n_ranks, **kw) for r in range(n_ranks)]
         info = self.ctx[0].mg_info()
         self.rw, self.nb1, self.nb_loc = info["rec_bytes"] // 4, info["nb1"], info["nb_loc"]
@@ -155,7 +189,8 @@ class LocalCluster:
             buf = self.d_recv[o][self.t & 1]
             if len(recv):
                 self.ctx[o].h2d(buf, recv)
-            self.ctx[o].mg_process(buf, seg)
+            lim = self.kmer_limit if self.kmer_limit is not None else int(self.ctx[o].batch_limit() / 0.95)
+            self.launches = getattr(self, "launches", 0) + process_in_groups(self.ctx[o], buf, seg, self.rw * 4, None if self.track else lim)
         self.t += 1
 
     def bloom_bytes(self, which=0):

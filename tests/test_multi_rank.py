@@ -94,6 +94,30 @@ def test_local_cluster_matches_reference_goldens(gpu_lib, g1, n_ranks, k, b):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,limit", [(4, 1), (8, 20000), (2, 1)])
+def test_local_cluster_source_groups(gpu_lib, g1, n_ranks, limit):
+    """A rank that receives more k-mers of a global batch than its regions take at full speed runs stage B once per group of sources
+    (dist.process_in_groups; limit 1 = one group per source): rank-major order is file order, so filter, statistics and table are still
+    those of the sequential oracle."""
+    from bfc_amd import dist as bdist
+    rs, (seq, qual, off) = g1
+    n, k, b = rs.n_reads, 31, 28
+    cl = bdist.LocalCluster(gpu_lib, n_ranks, k, b, max_batch_pos=(n // 2 + 64) * (rs.L + 1), kmer_limit=limit)
+    for row in _shares(seq, qual, off, n, 2, n_ranks):
+        cl.batch([(gpu_lib.to_stream(s, o), gpu_lib.to_stream(q, o)) for s, q, o in row])
+    assert cl.launches > 2 * n_ranks, cl.launches  # more stage-B launches than (batches x owners)
+    oc = oracle.Counter(k, b)
+    oc.count(seq, qual, off)
+    assert np.array_equal(cl.bloom_bytes(), oc.bloom_bytes())
+    st, ost = cl.stats(), oc.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    sizes, slots = cl.export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    cl.close(); oc.close()
+
+
+@pytest.mark.gpu
 def test_local_cluster_stream_mode(gpu_lib):
     """Emulated ranks on batches whose k-mers hardly repeat: every rank's context switches to the STREAM hand-over; still the oracle's result."""
     from bfc_amd import dist as bdist
