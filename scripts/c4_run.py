@@ -93,9 +93,10 @@ if args.export and not args.filter_mode:
     tab.close()
 if args.trim and args.filter_mode:
     t2 = time.time()
-    bf = g.export_bloom(1)
+    bf = g.export_bloom(1, resident=True)  # as bfc_count does: host object + copy left in HBM for the trim context to adopt
     g.close(); g = None
     tr = bfc_amd.GpuTrimmer(K, bf, max_pos=br * stride, max_reads=br)
+    res["trim_filter_adopted_from_hbm"] = tr.adopted
     print("[c4] second filter moved to the trimmer (%.1fs)" % (time.time() - t2), flush=True)
     kept = bases = 0; q_ms = 0.0; nq = 0
     cur = make(0)
