@@ -182,6 +182,27 @@ def test_oracle_vs_live_reference(k, b, nh, fm):
 
 
 @pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_vs_live_reference_random(seed):
+    """The oracle pinned on the draws the GPU fuzz uses (tests/test_gpu_fuzz.py::_draw: random k, filter size, hashes, l_pre, quality
+    threshold, filter mode, read lengths, arbitrary bytes in sequence and quality; BFC_FUZZ_SEED_BASE for other draws): statistics, both
+    filters and the table equal the reference's own functions called in file order."""
+    from test_gpu_fuzz import _draw
+    prm, seq, qual, off, cuts, kw = _draw(30000 + seed)
+    o = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
+    r = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"], impl="ref")
+    o.count(seq, qual, off); r.count(seq, qual, off)
+    assert o.stats() == r.stats(), prm
+    assert np.array_equal(o.bloom_bytes(), r.bloom_bytes()), prm
+    if prm["fm"]:
+        assert np.array_equal(o.bloom_bytes(True), r.bloom_bytes(True)), prm
+    else:
+        so, sr = o.export(), r.export()
+        assert np.array_equal(so[0], sr[0]) and np.array_equal(so[1], sr[1]), prm
+    o.close(); r.close()
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built (needs /root/reference)")
 @pytest.mark.parametrize("q", [-200, -40, 0, 20, 93, 94, 95, 127])
 def test_quality_threshold_on_every_byte_value(q):
     """count.c:85 compares `s->qual[i] - 33 >= q` on a (signed) char: quality bytes from 0 to 255 and thresholds from far below to far
