@@ -61,6 +61,7 @@ SYMBOLS = {
     "bfcg_create": (C.c_void_p, [C.POINTER(BfcgParams)]),
     "bfcg_destroy": (None, [C.c_void_p]),
     "bfcg_last_error": (C.c_char_p, []),
+    "bfcg_build_id": (C.c_char_p, []),
     "bfcg_reset": (C.c_int, [C.c_void_p]),
     "bfcg_count_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -121,3 +122,17 @@ def load():
             f.argtypes = args
         _lib = L
     return _lib
+
+
+def build_id():
+    """The library's embedded identity, e.g. 'src:0123456789abcdef git:abcdef012345'."""
+    return load().bfcg_build_id().decode()
+
+
+def check_build_id():
+    """Raise unless the loaded library was built from the sources in this tree."""
+    from . import build
+    have, want = build_id(), "src:" + build.source_hash()
+    if not have.startswith(want):
+        raise OSError("libbfc_gpu.so is stale: built from %s, the tree is %s (run `python -m bfc_amd.build`)" % (have, want))
+    return have

@@ -10,7 +10,8 @@
  * sequence lines until a line starting with '+', '>' or '@'; after '+', quality lines until at
  * least as many characters as bases; a length mismatch ends the input (kseq returns -2 and
  * bseq_read stops).  A FASTA record has no qualities: all its bases count as high quality
- * (count.c:85), expressed here by writing '~' into the quality stream.
+ * (count.c:85): a batch without any qualities is submitted without a quality stream, a mixed batch as its
+ * homogeneous runs (bfc_ingest.h: kind_cut).
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -147,9 +148,17 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs); /* count.c:99, once per bseq_read call */
 		if (b->n_seqs) {
 			double rt, eff;
-			if (bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos) != 0) {
-				fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort();
-			}
+			int rc = 0;
+			if (b->has_qual && b->n_noq) { /* mixed batch: its runs of records with / without qualities, one after the other */
+				uint64_t o = 0;
+				int j, kind = (b->n_cut & 1) ? !b->last_kind : b->last_kind; /* kind of the first run: the kinds alternate at every cut */
+				for (j = 0; j <= b->n_cut && rc == 0; ++j, kind = !kind) {
+					const uint64_t e = j < b->n_cut ? b->kind_cut[j] : b->n_pos;
+					if (e > o) rc = bfcg_count_batch_host(ctx, b->seq + o, kind ? b->qual + o : 0, e - o);
+					o = e;
+				}
+			} else rc = bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos);
+			if (rc != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
 			bfcg_stats(ctx, st);
 			rt = now_real() - t0; eff = 100. * now_cpu() / (rt + 1e-6);
 			if (!opt->filter_mode)
@@ -174,7 +183,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	                       : (void*)bfcg_export_table(ctx);
 	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
-	for (i = 0; i < 2; ++i) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); }
+	for (i = 0; i < 2; ++i) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); free(pp.b[i].kind_cut); }
 	pthread_mutex_destroy(&pp.mtx); pthread_cond_destroy(&pp.cv);
 	ingest_close(&ps);
 	bfcg_destroy(ctx); /* the first bloom filter dies here, as in count.c:155 */
@@ -204,7 +213,7 @@ int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_t
 		if (b.last) break;
 	}
 	out[3] = hs; out[4] = hq; out[5] = hb; out[6] = (uint64_t)in.fast_batches;
-	free(b.seq); free(b.qual);
+	free(b.seq); free(b.qual); free(b.kind_cut);
 	ingest_close(&in);
 	return 0;
 }

@@ -314,13 +314,14 @@ int bfc_ch_insert(bfc_ch_t *ch, const uint64_t x[2], int is_high, int forced)
 	(void)forced; /* lock-free upsert never has to give up (htab.c:67-72 returns -1 only on lock contention) */
 	if (ch->first) { pthread_rwlock_wrlock(&ch->grow_lock); drop_order(ch); pthread_rwlock_unlock(&ch->grow_lock); }
 	for (;;) {
-		int r;
+		int r, seen_cshift;
 		pthread_rwlock_rdlock(&ch->grow_lock);
 		r = upsert(ch, sub, key, is_high);
+		seen_cshift = ch->cshift;
 		pthread_rwlock_unlock(&ch->grow_lock);
 		if (r >= 0) { if (r) __sync_fetch_and_add(&ch->n_keys, 1); return 0; }
 		pthread_rwlock_wrlock(&ch->grow_lock);
-		grow(ch);
+		if (ch->cshift == seen_cshift) grow(ch); /* else another thread that found the same sub-table full has grown it meanwhile: just retry */
 		pthread_rwlock_unlock(&ch->grow_lock);
 	}
 }

@@ -61,12 +61,23 @@ typedef struct {
 	uint8_t *seq, *qual;   /* pinned */
 	uint64_t n_pos, cap;
 	int n_seqs, has_qual, last;
+	/* a batch that mixes records with and without qualities (FASTA records in a FASTQ file): stream offsets at which the kind changes.
+	 * Records without qualities are always high quality (count.c:85: qual == NULL), whatever -q says -- no in-band quality byte can
+	 * say that for every q, so bfc_count submits such a batch as its homogeneous runs (batch boundaries never change results). */
+	uint64_t *kind_cut; int n_cut, m_cut, n_noq, last_kind; /* last_kind: -1 none yet, 0 no qualities, 1 qualities */
 } batch_t;
+
+static inline void batch_clear(batch_t *b) { b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0; b->n_cut = 0; b->n_noq = 0; b->last_kind = -1; }
 
 /* append one record to the batch; returns 0 if it does not fit */
 static inline int batch_put(batch_t *b, const uint8_t *s, const uint8_t *q, size_t l)
 {
 	if (b->n_pos + l + 1 > b->cap) return 0;
+	if (b->last_kind >= 0 && b->last_kind != (q != 0)) {
+		if (b->n_cut == b->m_cut) { b->m_cut = b->m_cut ? b->m_cut * 2 : 16; b->kind_cut = (uint64_t*)realloc(b->kind_cut, sizeof(uint64_t) * (size_t)b->m_cut); }
+		b->kind_cut[b->n_cut++] = b->n_pos;
+	}
+	b->last_kind = q != 0; b->n_noq += q == 0;
 	if (l) memcpy(b->seq + b->n_pos, s, l); /* an empty record may come with s == NULL (no sequence line was ever buffered) */
 	if (q) { if (l) memcpy(b->qual + b->n_pos, q, l); b->has_qual = 1; }
 	else memset(b->qual + b->n_pos, '~', l);
@@ -266,7 +277,7 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 {
 	uint64_t win = (uint64_t)((double)chunk_size * (f->bytes_per_base > 0 ? f->bytes_per_base * 1.02 : 3.0)) + (1u << 18);
 	const uint64_t pos0 = f->pos;
-	b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0;
+	batch_clear(b);
 	for (;;) {
 		const uint64_t wend = f->pos + win < f->size ? f->pos + win : f->size;
 		const int at_eof = wend == f->size;
@@ -338,7 +349,7 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 				if (j->n_copy) { lastj = j; last_hdr = j->rec[j->n_copy - 1].hdr; }
 			}
 			fq_run(f, fq_copy, n_used > 0 ? n_used : 1);
-			b->n_pos = o; b->n_seqs = (int)nseq; b->has_qual = nseq > 0;
+			b->n_pos = o; b->n_seqs = (int)nseq; b->has_qual = nseq > 0; b->last_kind = nseq > 0 ? 1 : -1;
 			if (lastj) { /* the next batch starts after the last record taken */
 				const uint8_t *nx = 0;
 				int all = 1;
@@ -357,7 +368,7 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 static inline void fill_batch(parser_t *ps, batch_t *b)
 {
 	uint64_t bases = 0;
-	b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0;
+	batch_clear(b);
 	for (;;) {
 		if (!ps->have_rec) {
 			int rc = next_record(ps);

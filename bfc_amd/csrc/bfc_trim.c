@@ -82,7 +82,7 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	for (;;) { /* one batch: parse (keeping headers), trim on the GPU, print */
 		uint64_t bases = 0, r, n = 0;
 		int last = 0;
-		b.n_pos = 0; b.n_seqs = 0; l_hdrs = 0;
+		batch_clear(&b); l_hdrs = 0;
 		off[0] = 0;
 		for (;;) {
 			if (!ps.have_rec) { /* bseq_read (bseq.c:52-76): the batch ends at the end of the input or at a malformed record; an empty batch is the last */
@@ -126,5 +126,5 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	bfcg_trim_destroy(tr);
 	gzclose(ps.rd.fp);
 	free(ps.rd.buf); free(ps.rd.line); free(ps.seq); free(ps.qual); free(ps.hdr); free(ps.cmt);
-	bfcg_host_free(b.seq); free(b.qual); free(off); free(st); free(en); free(ri); free(hdrs);
+	bfcg_host_free(b.seq); free(b.qual); free(b.kind_cut); free(off); free(st); free(en); free(ri); free(hdrs);
 }

@@ -672,6 +672,7 @@ extern "C" int bfcg_bloom_to_host(bfcg_ctx_t *c, int which, uint8_t *dst)
 
 extern "C" bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which)
 {
+	if (c->n_ranks > 1) { set_err("this context owns 1/%d of the filter: bfcg_bloom_to_host copies the slice, a whole bfc_bf_t cannot come from one rank", c->n_ranks); return NULL; }
 	bfc_bf_t *b = bfc_bf_alloc_raw(c->P.bf_shift, c->P.n_hashes); // every byte is overwritten below: no 2^(b-3)-byte memset on the host
 	if (!b) { set_err("host allocation of the bloom filter failed"); return NULL; }
 	if (bfcg_bloom_to_host(c, which, b->b) != 0) { bfc_bf_destroy(b); return NULL; }

@@ -82,6 +82,55 @@ int bfcgen_fastq(uint64_t seed, uint64_t G, const uint8_t *g, int L, double err,
 	return 0;
 }
 
+/* ---- helpers of the benchmark / test tooling (no part of the counting path) ---- */
+
+/* number of bfc_kmer_insert calls on n reads of length L (count.c:83-88: one per position with >= k ACGT in a row) */
+uint64_t bfcgen_count_kmers(const uint8_t *seq, uint64_t n, int L, int k)
+{
+	uint64_t total = 0;
+	int64_t r;
+#pragma omp parallel for schedule(static) reduction(+:total)
+	for (r = 0; r < (int64_t)n; ++r) {
+		const uint8_t *s = seq + (uint64_t)r * (uint64_t)L;
+		int j, run = 0;
+		for (j = 0; j < L; ++j) {
+			const uint8_t c = s[j] & 0xDF;
+			run = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? run + 1 : 0;
+			total += run >= k;
+		}
+	}
+	return total;
+}
+
+/* n reads of length L -> the separator-delimited stream form of include/bfc_gpu.h PART 2: read, then one byte `sep` */
+void bfcgen_to_stream(const uint8_t *src, uint64_t n, int L, uint8_t sep, uint8_t *dst)
+{
+	int64_t r;
+#pragma omp parallel for schedule(static)
+	for (r = 0; r < (int64_t)n; ++r) {
+		memcpy(dst + (uint64_t)r * (uint64_t)(L + 1), src + (uint64_t)r * (uint64_t)L, (size_t)L);
+		dst[(uint64_t)r * (uint64_t)(L + 1) + (uint64_t)L] = sep;
+	}
+}
+
+/* checksums of a bitmap as SURVEY App. B.3 defines them: popcount, and FNV-1a/64 over all bytes in order */
+uint64_t bfcgen_popcount(const uint8_t *p, uint64_t n)
+{
+	uint64_t total = 0;
+	int64_t i, nw = (int64_t)(n / 8);
+	const uint64_t *w = (const uint64_t*)p;
+#pragma omp parallel for schedule(static) reduction(+:total)
+	for (i = 0; i < nw; ++i) total += (uint64_t)__builtin_popcountll(w[i]);
+	for (i = nw * 8; i < (int64_t)n; ++i) total += (uint64_t)__builtin_popcount(p[i]);
+	return total;
+}
+uint64_t bfcgen_fnv1a64(const uint8_t *p, uint64_t n)
+{
+	uint64_t h = 0xcbf29ce484222325ULL, i;
+	for (i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ULL;
+	return h;
+}
+
 #ifdef BFCGEN_MAIN
 int main(int argc, char **argv)
 {

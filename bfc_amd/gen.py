@@ -30,6 +30,13 @@ def _L():
         L.bfcgen_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
         L.bfcgen_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.bfcgen_fastq.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_char_p]
+        L.bfcgen_count_kmers.restype = C.c_uint64
+        L.bfcgen_count_kmers.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+        L.bfcgen_to_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint8, C.c_void_p]
+        L.bfcgen_popcount.restype = C.c_uint64
+        L.bfcgen_popcount.argtypes = [C.c_void_p, C.c_uint64]
+        L.bfcgen_fnv1a64.restype = C.c_uint64
+        L.bfcgen_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -73,3 +80,24 @@ FIXTURES = {
 
 def fixture(name):
     return ReadSet(**FIXTURES[name])
+
+
+def count_kmers(seq, L, k):
+    """Number of bfc_kmer_insert calls on fixed-length reads: positions with >= k ACGT in a row (count.c:83-88)."""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    return int(_L().bfcgen_count_kmers(seq.ctypes.data, len(seq) // L, L, k))
+
+
+def to_stream(arr, L, sep=10, out=None):
+    """Fixed-length reads -> the stream form of the device API (every read followed by one separator byte)."""
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    n = len(arr) // L
+    out = out if out is not None else np.empty(n * (L + 1), dtype=np.uint8)
+    _L().bfcgen_to_stream(arr.ctypes.data, n, L, sep, out.ctypes.data)
+    return out
+
+
+def bitmap_checksums(bits):
+    """(popcount, FNV-1a/64) of a bitmap, as SURVEY App. B.3 defines the bloom goldens."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    return int(_L().bfcgen_popcount(bits.ctypes.data, len(bits))), int(_L().bfcgen_fnv1a64(bits.ctypes.data, len(bits)))

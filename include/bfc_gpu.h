@@ -103,6 +103,9 @@ void bfcg_params_default(bfcg_params_t *p);
 bfcg_ctx_t *bfcg_create(const bfcg_params_t *p);
 void bfcg_destroy(bfcg_ctx_t *c);
 const char *bfcg_last_error(void);
+/* "src:<sha256/16 of the library's sources> git:<HEAD when it was built>": ties a travelling libbfc_gpu.so to the sources it claims
+ * (bfc_amd/build.py::source_hash recomputes the first part from the tree; __graft_entry__.smoke() and bench.py compare). */
+const char *bfcg_build_id(void);
 /* clear both bloom filters and the table */
 int bfcg_reset(bfcg_ctx_t *c);
 

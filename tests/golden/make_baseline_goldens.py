@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Known answers of THE REFERENCE ITSELF at BASELINE.json's single-GPU shapes (c2, c3) and at c5's parameters.
+
+    make -C oracle && python tests/golden/make_baseline_goldens.py [c2 c3 c5s ...]
+
+Runs the reference's own functions in file order (`bfc -t1` semantics: oracle/_ref/libbfcref.so = /root/reference
+compiled in place, harness oracle/ref_shim.c, count.c:72-89 / count.c:127-157) over the full synthetic read set of
+each configuration and writes tests/golden/baseline.json: k-mer / high / seen totals, distinct keys, both histograms,
+bloom popcount + FNV-1a, the layout-free L1 digest of the table.  Data only.  Build container only
+(c3 takes ~25 min of one core and ~12 GB; the GPU box never runs this).
+
+bench.py compares its headline run with the c3 entry ("verified": true); tests/test_gpu_baseline_shapes.py compares the
+GPU path with every entry.
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from bfc_amd import gen  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("BASELINE_OUT") or os.path.join(HERE, "baseline.json")
+
+# name: generator arguments, k, bf_shift (as `-s` / the default give), filter_mode
+CASES = {
+    "c2": dict(gen=dict(seed=2, G=4_600_000, cov=100.0), k=31, b=33, fm=0),
+    "c3": dict(gen=dict(seed=3, G=248_000_000, cov=30.0), k=33, b=35, fm=0),     # `-s 250m -k33` => -b35
+    # c5's parameters (`-s 3g -k51 -1`: -b37, two 16 GiB filters, 20-byte records, 10+10 scatter levels) on a read set a CPU finishes
+    "c5s": dict(gen=dict(seed=5, G=20_000_000, cov=30.0), k=51, b=37, fm=1),
+    # c4's parameters (`-s 3g`: k=33, -b37, table mode) on the same small read set
+    "c4s": dict(gen=dict(seed=5, G=20_000_000, cov=30.0), k=33, b=37, fm=0),
+}
+
+
+def run(name):
+    cs = CASES[name]
+    t0 = time.time()
+    rs = gen.ReadSet(**cs["gen"])
+    c = oracle.Counter(cs["k"], cs["b"], filter_mode=cs["fm"], impl="ref")
+    CH = 2_000_000
+    for r0 in range(0, rs.n_reads, CH):
+        seq, qual, off = rs.reads(r0, min(rs.n_reads, r0 + CH))
+        c.count(seq, qual, off)
+        print("[%s] %d / %d reads  %.0fs" % (name, min(rs.n_reads, r0 + CH), rs.n_reads, time.time() - t0), file=sys.stderr, flush=True)
+    st = c.stats()
+    pop, fnv = c.bloom_checksums()
+    e = dict(name=name, gen=cs["gen"], k=cs["k"], b=cs["b"], filter_mode=cs["fm"], n_reads=rs.n_reads,
+             n_kmers=st["n_kmers"], n_high=st["n_high"], n_seen=st["n_seen"], hash_xor="%016x" % st["hash_xor"],
+             bf_popcount=pop, bf_fnv1a64="%016x" % fnv)
+    if cs["fm"]:
+        pop2, fnv2 = c.bloom_checksums(high=True)
+        e.update(bf_high_popcount=pop2, bf_high_fnv1a64="%016x" % fnv2)
+    else:
+        mode, cnt, high = c.table_hist()
+        e.update(distinct=c.table_count(), hist_mode=int(mode), cnt=[int(v) for v in cnt], high=[int(v) for v in high])
+        with tempfile.NamedTemporaryFile(suffix=".hash", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tf:
+            c.dump(tf.name)
+            kk, l_pre, sizes, slots = oracle.parse_dump(tf.name)
+        e.update(l_pre=l_pre, l1_digest=oracle.l1_digest(sizes, slots))
+    c.close()
+    e["ref_seconds"] = round(time.time() - t0, 1)
+    print(e, file=sys.stderr, flush=True)
+    return e
+
+
+if __name__ == "__main__":
+    assert oracle.have_ref(), "build oracle/_ref first (make -C oracle)"
+    names = sys.argv[1:] or list(CASES)
+    cur = {}
+    if os.path.exists(OUT):
+        cur = {e["name"]: e for e in json.load(open(OUT))}
+    for n in names:
+        cur[n] = run(n)
+        json.dump([cur[k] for k in sorted(cur)], open(OUT, "w"), indent=1)
+    print("wrote", OUT, sorted(cur))

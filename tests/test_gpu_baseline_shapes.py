@@ -1,0 +1,116 @@
+"""GPU parity at BASELINE.json's own shapes (-m gpu).
+
+The fixtures of the other GPU tests stop at 100 kb genomes and filters of 2^27 bits; the configurations the metric is quoted
+on run other kernel geometries: c2 (k=31, -b33: 65 536 bloom regions, 8+8 scatter levels, aggregation mode, 12-byte records),
+c3 (k=33, -b35: 262 144 regions, 9+9 levels, 16-byte records, STREAM mode, a table that grows several times), c4 / c5
+(-b37: 2^20 regions, 10+10 levels; k=51 `-1`: two 16 GiB filters, 20-byte records).  Here the GPU path runs those shapes
+and must reproduce what THE REFERENCE ITSELF computed for the same read sets:
+  * tests/golden/fixtures.json  (g42 at k=31/-b30 and k=33/-b33), and
+  * tests/golden/baseline.json  (the full c2 and c3 read sets, and c4's / c5's parameters on a 20 Mbp genome;
+    generator tests/golden/make_baseline_goldens.py: the reference's functions in file order = `bfc -t1`).
+Compared: k-mer / high / seen totals, distinct keys, bloom popcount + FNV-1a (L0 through its digest), both histograms,
+and the layout-free L1 digest of the whole table.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from bfc_amd import gen
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "fixtures.json")))
+BASE = {e["name"]: e for e in json.load(open(os.path.join(HERE, "golden", "baseline.json")))}
+
+
+def _count_fixed(gpu_lib, rs, k, b, batch_reads, filter_mode=0, **kw):
+    """Whole read set of `rs` (fixed-length reads) through the device API in batches of `batch_reads`, generated chunk by chunk."""
+    stride = rs.L + 1
+    g = gpu_lib.GpuCounter(k, b, filter_mode=filter_mode, max_batch_pos=min(batch_reads, rs.n_reads) * stride + 64, **kw)
+    for r0 in range(0, rs.n_reads, batch_reads):
+        r1 = min(rs.n_reads, r0 + batch_reads)
+        seq, qual, _ = rs.reads(r0, r1)
+        g.count_host(gen.to_stream(seq, rs.L, 10), gen.to_stream(qual, rs.L, 33))
+    return g
+
+
+def _check_against(g, e, l1=True):
+    st = g.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (e["n_kmers"], e["n_high"], e["n_seen"]), (st, e["name"] if "name" in e else e["fixture"])
+    pop, fnv = gen.bitmap_checksums(g.bloom_bytes())
+    want_fnv = e["bf_fnv1a64"] if isinstance(e["bf_fnv1a64"], int) else int(e["bf_fnv1a64"], 16)
+    assert (pop, fnv) == (e["bf_popcount"], want_fnv), "first bloom filter differs from the reference's (L0)"
+    if e["filter_mode"]:
+        pop, fnv = gen.bitmap_checksums(g.bloom_bytes(1))
+        want_fnv = e["bf_high_fnv1a64"] if isinstance(e["bf_high_fnv1a64"], int) else int(e["bf_high_fnv1a64"], 16)
+        assert (pop, fnv) == (e["bf_high_popcount"], want_fnv), "second bloom filter (bfc -1) differs from the reference's"
+        return st
+    t = g.export_table()
+    assert t.count() == e["distinct"] == st["n_keys"]
+    mode, cnt, high = t.hist()
+    assert int(mode) == e["hist_mode"]
+    if "cnt" in e:
+        assert np.array_equal(cnt, np.array(e["cnt"], dtype=np.uint64)) and np.array_equal(high, np.array(e["high"], dtype=np.uint64))
+    else:
+        assert [int(v) for v in cnt[1:5]] == e["cnt_1_4"] and [int(v) for v in high[0:3]] == e["high_0_2"]
+    if l1:
+        sizes, slots = t.export_sorted()
+        assert oracle.l1_digest(sizes, slots) == e["l1_digest"], "count table differs from the reference's (L1)"
+    t.close()
+    return st
+
+
+@pytest.mark.parametrize("k,b", [(31, 30), (33, 33)])
+@pytest.mark.parametrize("n_batches", [1, 3])
+def test_g42_reference_goldens(gpu_lib, g42, k, b, n_batches):
+    """g42 (1 Mbp x 30) at k=31/-b30 (L1 10c69c17...) and k=33/-b33 (37e9a864...): the default 1 GiB filter geometry."""
+    rs, _ = g42
+    e = [x for x in FIX["fixtures"] if x["fixture"] == "g42" and (x["k"], x["b"], x["filter_mode"]) == (k, b, 0)][0]
+    assert e["l1_digest"] == {(31, 30): "10c69c17d5625df5b9fc7530c94b2e66", (33, 33): "37e9a864777226c76bff184bf03ef779"}[(k, b)]
+    g = _count_fixed(gpu_lib, rs, k, b, (rs.n_reads + n_batches - 1) // n_batches)
+    _check_against(g, e)
+    g.close()
+
+
+@pytest.mark.parametrize("batch_reads", [786432, 1572864])
+def test_c2_full_read_set(gpu_lib, batch_reads):
+    """Config c2 as bench.py runs it (k=31, -b33, 3.07 M reads at 100x, 4 or 2 batches): equals the reference on the same reads."""
+    e = BASE["c2"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], batch_reads)
+    st = _check_against(g, e)
+    assert st["slow_buckets"] == 0
+    g.close()
+
+
+def test_c3_full_read_set(gpu_lib):
+    """Config c3 as bench.py runs it (k=33, -b35 table mode, 49.6 M reads: 9+9 scatter levels, 16-byte records, the batches'
+    k-mers hardly repeat so the context switches to STREAM mode, the table grows to 300 M keys): equals the reference."""
+    e = BASE["c3"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584)
+    st = _check_against(g, e)
+    assert st["stream_batches"] > 0, "c3 is expected to run (mostly) without in-LDS aggregation"
+    g.close()
+
+
+def test_c4_parameters(gpu_lib):
+    """`-s 3g`: k=33, -b37 in table mode (16 GiB filter, 2^20 regions, 10+10 scatter levels) on a 20 Mbp genome at 30x."""
+    e = BASE["c4s"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_000_000)
+    _check_against(g, e)
+    g.close()
+
+
+def test_c5_parameters(gpu_lib):
+    """`-s 3g -k51 -1`: k=51, -b37, filter mode (two 16 GiB filters with both slices of a region in LDS, 20-byte records)."""
+    e = BASE["c5s"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_000_000, filter_mode=1)
+    _check_against(g, e)
+    g.close()

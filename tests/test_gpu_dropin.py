@@ -15,7 +15,38 @@ from bfc_amd import gen
 pytestmark = pytest.mark.gpu
 
 DROPIN = os.path.join(oracle.REF_DIR, "bfc-dropin")
-needs_dropin = pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/bfc-dropin not built (needs /root/reference at build time)")
+
+
+def _missing(*paths):
+    """These tests only run where a GPU is (-m gpu).  The reference-built binaries under oracle/_ref/ are made in the build container
+    (oracle/Makefile, from /root/reference in place) and must TRAVEL to the GPU box: a missing one is a failure, never a skip."""
+    gone = [p for p in paths if not os.path.exists(p)]
+    return "did not travel to the GPU box (built by `make -C oracle` where /root/reference exists): " + ", ".join(gone) if gone else None
+
+
+@pytest.fixture
+def dropin_bin():
+    m = _missing(DROPIN)
+    if m:
+        pytest.fail(m)
+    return DROPIN
+
+
+needs_dropin = pytest.mark.usefixtures("dropin_bin")
+
+
+@pytest.fixture
+def gputrim_bin():
+    m = _missing(os.path.join(oracle.REF_DIR, "bfc-dropin-gputrim"))
+    if m:
+        pytest.fail(m)
+
+
+@pytest.fixture
+def ref_bin():
+    m = _missing(os.path.join(oracle.REF_DIR, "bfc-ref"))
+    if m:
+        pytest.fail(m)
 
 
 @pytest.fixture(scope="module")
@@ -190,7 +221,7 @@ def test_filter_left_in_hbm_for_the_trim_pass(gpu_lib, g1):
 GPUTRIM = os.path.join(oracle.REF_DIR, "bfc-dropin-gputrim")
 
 
-@pytest.mark.skipif(not os.path.exists(GPUTRIM), reason="oracle/_ref/bfc-dropin-gputrim not built")
+@pytest.mark.usefixtures("gputrim_bin")
 def test_dropin_gpu_trim_binary(g1_fq, tmp_path):
     """`bfc -1` with BOTH phases on the GPU (bfc_count + bfc_correct from libbfc_gpu.so, reference main() unmodified):
     stdout byte-identical to the reference; in table mode the same binary forwards to the reference's corrector."""
@@ -231,7 +262,7 @@ REFBIN = os.path.join(oracle.REF_DIR, "bfc-ref")
 
 
 @needs_dropin
-@pytest.mark.skipif(not os.path.exists(REFBIN), reason="oracle/_ref/bfc-ref not built")
+@pytest.mark.usefixtures("ref_bin")
 @pytest.mark.parametrize("seed", range(8))
 def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
     """End to end through the reference's own main(): damaged FASTQ / FASTA text (dropped, doubled, split, junk lines, CRLF, truncation)
@@ -258,7 +289,7 @@ def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
             assert got == want, (seed, chunk, t)
 
 
-@pytest.mark.skipif(not (os.path.exists(GPUTRIM) and os.path.exists(REFBIN)), reason="oracle/_ref/bfc-dropin-gputrim / bfc-ref not built")
+@pytest.mark.usefixtures("gputrim_bin", "ref_bin")
 @pytest.mark.parametrize("seed", range(8))
 def test_gpu_trim_equals_reference_binary_on_damaged_files(tmp_path, seed):
     """`bfc -1` with both phases on the GPU vs the reference binary on damaged FASTQ / FASTA text: stdout (names, inherited comments,
@@ -327,7 +358,7 @@ def test_gpu_trim_pass_on_a_large_filter(gpu_lib, g1):
 
 
 @needs_dropin
-@pytest.mark.skipif(not os.path.exists(REFBIN), reason="oracle/_ref/bfc-ref not built")
+@pytest.mark.usefixtures("ref_bin")
 def test_dropin_with_the_largest_filter(g1_fq, tmp_path):
     """`bfc -s 3g` (k=33, -b37: a 16 GiB filter, batches of 16 reference chunks) on a small file: the dump equals the reference binary's,
     and the library sizes its buffers by the file, not by the 1.6 G-position batch the filter would allow."""

@@ -1,7 +1,7 @@
 """GPU parity under random parameters (-m gpu): k, filter size, number of hashes, l_pre, quality threshold, read lengths, coverage, Ns,
 FASTA/FASTQ, batch cuts, region size and initial table size drawn from a seeded generator; every draw is checked bit for bit against the
 oracle (bloom bitmaps L0, statistics, table L1).  Small inputs, many shapes: one-level and two-level partitions (bf_shift 10..27),
-single-block regions, tables that grow several times, k from 5 to 63."""
+single-block regions, tables that grow several times, k from 5 to 63; a second family draws bf_shift 28..33."""
 import os
 
 import numpy as np
@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 SEED_BASE = int(os.environ.get("BFC_FUZZ_SEED_BASE", "0"))  # other values draw other configurations (scripts/more_fuzz.sh)
 
 
-def _draw(seed, scale=1):
+def _draw(seed, scale=1, b_range=(10, 28)):
     rng = np.random.default_rng(seed + 100003 * SEED_BASE)
     k = int(rng.choice([5, 9, 13, 17, 21, 25, 27, 29, 31, 32, 33, 35, 39, 47, 48, 55, 63]))
-    b = int(rng.integers(10, 28))
+    b = int(rng.integers(*b_range))
     nh = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 7, 12]))
     l_pre = int(rng.choice([v for v in (4, 8, 12, 16, 20) if v <= 2 * k - 2]))  # htab.c:49-50 shifts by 2k - l_pre: the reference needs it positive
     q = int(rng.choice([-50, 0, 10, 20, 30, 41, 94, 100]))
@@ -80,6 +80,13 @@ def _check(gpu_lib, prm, seq, qual, off, cuts, kw):
 @pytest.mark.parametrize("seed", range(120))
 def test_random_configuration(gpu_lib, seed):
     _check(gpu_lib, *_draw(1000 + seed))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configuration_large_filters(gpu_lib, seed):
+    """the same kind of draws with filters of 2^28 .. 2^33 bits (up to the default 1 GiB): two full scatter levels, tens of thousands of
+    bloom regions most of which see no k-mer at all, and the table geometries that go with them"""
+    _check(gpu_lib, *_draw(30000 + seed, scale=4, b_range=(28, 34)))
 
 
 @pytest.mark.parametrize("seed", range(8))

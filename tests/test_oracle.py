@@ -99,7 +99,7 @@ def test_fixture_g1(e, g1, tmp_path):
     c.close()
 
 
-@pytest.mark.parametrize("e", [e for e in FIX["fixtures"] if e["fixture"] == "g42" and e["k"] != 33], ids=lambda e: "k%d_b%d_f%d" % (e["k"], e["b"], e["filter_mode"]))
+@pytest.mark.parametrize("e", [e for e in FIX["fixtures"] if e["fixture"] == "g42"], ids=lambda e: "k%d_b%d_f%d" % (e["k"], e["b"], e["filter_mode"]))
 def test_fixture_g42(e, g42):
     rs, (seq, qual, off) = g42
     _check_fixture(e, seq, qual, off).close()
