@@ -36,7 +36,7 @@ class BfcKmer(C.Structure):
 class BfcgParams(C.Structure):
     _fields_ = [("k", C.c_int), ("q", C.c_int), ("bf_shift", C.c_int), ("n_hashes", C.c_int), ("l_pre", C.c_int),
                 ("filter_mode", C.c_int), ("device", C.c_int), ("max_batch_pos", C.c_uint64),
-                ("region_shift", C.c_int), ("tab_cshift", C.c_int), ("debug_seen", C.c_int), ("track_order", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int)]
+                ("region_shift", C.c_int), ("tab_cshift", C.c_int), ("debug_seen", C.c_int), ("track_order", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int), ("table_layout", C.c_int)]
 
 
 # every symbol include/bfc_gpu.h declares: name -> (restype, argtypes)
@@ -93,6 +93,7 @@ SYMBOLS = {
     "bfcg_host_alloc": (C.c_void_p, [C.c_uint64]),
     "bfcg_host_free": (None, [C.c_void_p]),
     "bfcg_stats": (C.c_int, [C.c_void_p, u64p]),
+    "bfcg_table_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "bfcg_last_batch_ms": (C.c_int, [C.c_void_p, f32p]),
     "bfcg_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), u64p, C.c_int]),
     "bfcg_bloom_to_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

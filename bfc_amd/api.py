@@ -195,13 +195,13 @@ class GpuCounter:
     """Device-level counting context (bfcg_ctx_t)."""
 
     def __init__(self, k, bf_shift, q=20, n_hashes=4, l_pre=20, filter_mode=0, device=0, max_batch_pos=1 << 24,
-                 region_shift=0, tab_cshift=0, debug_seen=False, rank=0, n_ranks=1, track_order=False):
+                 region_shift=0, tab_cshift=0, debug_seen=False, rank=0, n_ranks=1, track_order=False, table_layout=0):
         self.L = _lib.load()
         p = BfcgParams()
         self.L.bfcg_params_default(C.byref(p))
         p.k, p.q, p.bf_shift, p.n_hashes, p.l_pre, p.filter_mode = k, q, bf_shift, n_hashes, l_pre, filter_mode
         p.device, p.max_batch_pos, p.region_shift, p.tab_cshift, p.debug_seen = device, int(max_batch_pos), region_shift, tab_cshift, int(debug_seen)
-        p.rank, p.n_ranks, p.track_order = rank, n_ranks, int(track_order)
+        p.rank, p.n_ranks, p.track_order, p.table_layout = rank, n_ranks, int(track_order), int(table_layout)
         self.rank, self.n_ranks = rank, n_ranks
         self.params = p
         self.bf_shift, self.k = bf_shift, k
@@ -277,6 +277,12 @@ class GpuCounter:
         d["stream_batches"] = int(self.L.bfcg_stream_batches(self.ctx))
         d["phase_cycles"] = [int(out[i]) for i in range(10, 16)]  # BFCG_ABLATE&64: k_bloom stage/pass1/pass2/writeback/handover
         return d
+
+    def table_info(self):
+        """How the count table is held right now: region-owned segments (updated through LDS) or the host's (sub-table, key) layout."""
+        out = (C.c_int * 4)()
+        self.L.bfcg_table_info(self.ctx, out)
+        return dict(segments=bool(out[0]), seg_shift=out[1], tab_cshift=out[2], seg_growths=out[3])
 
     def last_batch_ms(self):
         out = np.zeros(6, dtype=np.float32)

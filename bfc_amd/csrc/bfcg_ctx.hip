@@ -56,6 +56,11 @@ struct bfcg_ctx {
 	uint64_t crowded_last;       // ST_CROWDED at the last finalised batch
 	int stream_mode;             // 1: the batches' k-mers hardly repeat -- seen k-mers are streamed to k_commit_stream instead of aggregated
 	uint32_t *stream_out; uint64_t n_stream_batches;
+	int pipeline;                // stage A of batch t+1 on its own stream under stage B of batch t
+	int seg_ok;                  // the geometry allows region-owned table segments (KParams.seg): every reset starts in that layout
+	int seg_init_shift;          // log2 slots per segment after a reset
+	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
+	uint64_t n_seg_grow;         // segment growths since creation
 };
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
@@ -119,7 +124,17 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		// leaves 16 KiB for the list and the first-setter table next to the region and the second slice / aggregation table
 		const size_t region = (size_t)64 << P.R;
 		const size_t rwb = 8; // list entry: file-order index + (record index | mask)
-		const size_t second = prm->filter_mode ? region : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (prm->track_order ? 8 : 0)); // second filter's slice, or the aggregation table
+		{ // region-owned table segments (bfcg_kernels.hip: k_commit_seg) where a k-mer's identity inside its region fits the 50 key bits of a slot;
+		  // decided here because the bloom kernel then needs no aggregation table in LDS: the room goes to the list (larger batches at full speed)
+			const char *es = getenv("BFCG_SEG");
+			P.seg_lo = P.R < P.k ? P.R : P.k;
+			P.seg_hi = P.k < P.bf_shift - 9 ? P.k : P.bf_shift - 9;
+			if (P.seg_hi < P.seg_lo) P.seg_hi = P.seg_lo;
+			const int id_bits = 2 * P.k - (P.seg_hi - P.seg_lo);
+			c->seg_ok = !prm->filter_mode && !prm->track_order && P.R <= 8 && !getenv("BFCG_BT") && id_bits <= BFC_CH_KEYBITS && prm->table_layout != 1 && !(es && atoi(es) == 0);
+			P.seg = c->seg_ok;
+		}
+		const size_t second = prm->filter_mode ? region : P.seg ? 0 : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (prm->track_order ? 8 : 0)); // second filter's slice, or the aggregation table
 		size_t budget = (size_t)53000;
 		if (region + second + 16 * 1024 > budget) budget = 80 * 1024 - 1024;
 		if (region + second + 16 * 1024 > budget) budget = 160 * 1024 - 1024;
@@ -147,6 +162,11 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
 	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 20;
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
+	// Stage A of the next batch under stage B of this one (two streams) pays only where both kernels' workgroups fit a CU side by side:
+	// 12-byte records (scatter stage 52 KB of LDS next to the bloom kernel's 53 KB: c2 14.2 vs 15.4 ms per step).  With 16-byte records the
+	// scatter kernels hold 74 KB each, the kernels take turns on every CU and both run several times slower (c3: 389 vs 328 ms per step).
+	{ const char *e = getenv("BFCG_PIPELINE"); c->pipeline = e ? atoi(e) != 0 : c->rw == 12; }
+
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
 	P.idx_rank = n_ranks > 1 ? (uint32_t)prm->rank << (32 - log2n) : 0u;
 	c->bloom_bytes = (1ULL << (P.bf_shift - 3)) >> log2n; // owner computes: this rank keeps 1/n_ranks of the regions
@@ -183,8 +203,19 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	c->seg_words = (size_t)4 * nb1 + 8;
 	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * 2 * c->seg_words)); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * 2 * c->seg_words)); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
+	P.f_base = (uint32_t)c->rank * (uint32_t)nfine;
+	if (c->seg_ok) { // segments start with a quarter of a batch's positions in slots, like the table below
+		int sh = prm->tab_cshift > 0 ? prm->tab_cshift + 3 : 6;
+		if (prm->tab_cshift <= 0) while (((uint64_t)nfine << sh) < prm->max_batch_pos / 4 && sh < BFCG_SEG_MAX_SHIFT) ++sh;
+		if (sh > BFCG_SEG_MAX_SHIFT) sh = BFCG_SEG_MAX_SHIFT;
+		c->seg_init_shift = sh;
+		P.seg = 1; P.seg_shift = sh;
+		HIPCKN(set_seg_lds_attr());
+		HIPCKN(hipMalloc(&B.seg_tab, ((uint64_t)nfine << sh) * 8));
+		HIPCKN(hipMalloc(&c->stream_out, c->recv_cap * (uint64_t)c->rw));
+	}
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
-	else HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
+	else if (!c->seg_ok) HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
 	if (P.track) { HIPCKN(hipMalloc(&B.tab_first, 8ULL << (P.l_pre + P.tab_cshift))); HIPCKN(hipMalloc(&B.sub_last, 8ULL << P.l_pre)); }
 	HIPCKN(hipMalloc(&B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1))); // last row: unslotted words
 	// parked k-mers of a batch that outruns the table (the host grows it and replays them): a batch cannot create more keys than
@@ -220,7 +251,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
-	(void)hipFree(c->stream_out);
+	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -242,11 +273,23 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	HIPCK(hipStreamWaitEvent(c->stA, c->evCopy, 0));
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
 	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
+	if (c->seg_ok) { // back to region-owned segments of the initial size (a run that outgrew them, or an export, left the other layout behind)
+		const uint64_t nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
+		if (c->seg_escaped || c->P.seg_shift != c->seg_init_shift || !c->B.seg_tab) {
+			HIPCK(hipStreamSynchronize(c->st));
+			if (c->B.table) { HIPCK(hipFree(c->B.table)); c->B.table = 0; }
+			if (c->B.seg_tab) { HIPCK(hipFree(c->B.seg_tab)); c->B.seg_tab = 0; }
+			c->P.seg_shift = c->seg_init_shift;
+			HIPCK(hipMalloc(&c->B.seg_tab, (nfine << c->P.seg_shift) * 8));
+		}
+		c->P.seg = 1; c->seg_escaped = 0;
+		HIPCK(hipMemsetAsync(c->B.seg_tab, 0, (nfine << c->P.seg_shift) * 8, c->st));
+	}
 	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
 	if (c->B.tab_first) { HIPCK(hipMemsetAsync(c->B.tab_first, 0xff, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st)); HIPCK(hipMemsetAsync(c->B.sub_last, 0, 8ULL << c->P.l_pre, c->st)); }
 	c->n_batches = 0;
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
-	c->crowded_last = 0; c->stream_mode = 0;
+	c->crowded_last = 0; c->stream_mode = c->P.seg ? 1 : 0;
 	return 0;
 }
 
@@ -268,6 +311,9 @@ static int fetch_stats_on(bfcg_ctx_t *c, hipStream_t s)
 static int fetch_stats(bfcg_ctx_t *c) { return fetch_stats_on(c, c->st); }
 
 static int table_maintain(bfcg_ctx_t *c);
+static int seg_maintain(bfcg_ctx_t *c);
+static int seg_target_shift(const bfcg_ctx_t *c);
+static int seg_to_legacy(bfcg_ctx_t *c);
 static void note_growth(bfcg_ctx_t *c);
 static int finalise_previous(bfcg_ctx_t *c, int b);
 static int table_target_cshift(const bfcg_ctx_t *c);
@@ -288,6 +334,7 @@ static int batch_times(bfcg_ctx_t *c, int b)
 static int check_health(bfcg_ctx_t *c)
 {
 	if (c->h_stats[ST_ERR_POOL]) return set_err("first-setter pool exhausted in %llu bloom regions: batch too large for max_batch_pos", (unsigned long long)c->h_stats[ST_ERR_POOL]);
+	if (c->P.seg) return seg_maintain(c);
 	if (c->B.table) return table_maintain(c);
 	return 0;
 }
@@ -377,6 +424,99 @@ static int table_maintain(bfcg_ctx_t *c)
 			HIPCK(hipFree(tmp));
 		} else c->h_stats[ST_TAB_OVF] = 0;
 	}
+}
+
+// ---- region-owned table segments (KParams.seg)
+
+// segment size the table should have now.  Upserts probe in LDS, so the segments run fuller than the table in the host's layout: growth
+// at 62 % mean load (a region's load is Poisson around the mean: +5 sigma of 1000 keys is 16 %); a segment that fills up parks its k-mers.
+static int seg_target_shift(const bfcg_ctx_t *c)
+{
+	const KParams &P = c->P;
+	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
+	// growing is one coalesced pass over the segments (k_seg_rehash: c3's 4 GiB in 0.9 ms), a batch into segments that are too full is not:
+	// forecast with the larger of the last two batches' additions
+	const uint64_t need = c->h_stats[ST_KEYS] + c->h_stats[ST_TAB_OVF], g = c->grow[0] > c->grow[1] ? c->grow[0] : c->grow[1];
+	int t = P.seg_shift;
+	while ((double)(need + g) > 0.62 * (double)(nfine << t)) ++t;
+	if (c->h_stats[ST_TAB_OVF] && t == P.seg_shift) ++t; // one full segment under a low overall load
+	return t;
+}
+
+// grow the segments (k_seg_rehash streams every segment through LDS once) and replay parked k-mers until none is left; segments that
+// would no longer fit a CU's LDS send the table to the host's layout for the rest of the run (seg_to_legacy)
+static int seg_maintain(bfcg_ctx_t *c)
+{
+	KParams &P = c->P; BatchBufs &B = c->B;
+	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
+	for (;;) {
+		const uint64_t ovf = c->h_stats[ST_TAB_OVF];
+		const int target = seg_target_shift(c);
+		if (ovf == 0 && target == P.seg_shift) return 0;
+		if (ovf > B.tab_ovf_cap) return set_err("count table overflow list exhausted (%llu parked k-mers)", (unsigned long long)ovf);
+		if (target > BFCG_SEG_MAX_SHIFT) return seg_to_legacy(c);
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ((nfine << target) * 8) + (1ULL << 30) > (uint64_t)free_b)
+				return set_err("count table of %llu keys cannot grow to 2^%d slots per region: %.1f GiB of device memory free", (unsigned long long)c->h_stats[ST_KEYS], target, free_b / 1073741824.0);
+		}
+		const int old_shift = P.seg_shift;
+		unsigned long long *nt = 0;
+		P.seg_shift = target;
+		HIPCK(hipMalloc(&nt, (nfine << target) * 8));
+		run_seg_rehash(P, B.seg_tab, old_shift, nt, (uint32_t)nfine, c->st);
+		HIPCK(hipStreamSynchronize(c->st));
+		HIPCK(hipGetLastError());
+		HIPCK(hipFree(B.seg_tab));
+		B.seg_tab = nt;
+		++c->n_seg_grow;
+		if (ovf) {
+			uint64_t *tmp = 0;
+			HIPCK(hipMalloc(&tmp, ovf * 40));
+			HIPCK(hipMemcpyAsync(tmp, B.tab_ovf, ovf * 40, hipMemcpyDeviceToDevice, c->st));
+			HIPCK(hipMemsetAsync(&B.stats[(size_t)ST_SLOTS * ST_N], 0, 8, c->st));
+			run_seg_replay(P, B.seg_tab, tmp, ovf, B.stats, B.tab_ovf, B.tab_ovf_cap, c->st);
+			if (fetch_stats(c) != 0) return -1;
+			HIPCK(hipFree(tmp));
+		} else c->h_stats[ST_TAB_OVF] = 0;
+	}
+}
+
+// The table in the host's layout (2^l_pre sub-tables, htab.c:45-58) from the segments: for export, for the k-mer coverage kernels, and
+// for runs whose segments outgrow LDS.  The device must be idle.  Afterwards the context counts on in that layout until bfcg_reset.
+static int seg_to_legacy(bfcg_ctx_t *c)
+{
+	KParams &P = c->P; BatchBufs &B = c->B;
+	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
+	const uint64_t keys = c->h_stats[ST_KEYS];
+	int cs = c->prm.tab_cshift > 0 ? c->prm.tab_cshift : 2;
+	while ((1ULL << (P.l_pre + cs)) < 2 * keys + (c->prm.max_batch_pos / 4) && P.l_pre + cs < 36) ++cs;
+	{ // as much as memory allows (the segments live until the table is filled)
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			while (cs > 1 && (8ULL << (P.l_pre + cs)) + (2ULL << 30) > (uint64_t)free_b) --cs;
+	}
+	P.tab_cshift = cs;
+	HIPCK(hipMalloc(&B.table, 8ULL << (P.l_pre + cs)));
+	HIPCK(hipMemsetAsync(B.table, 0, 8ULL << (P.l_pre + cs), c->st));
+	// the keys are counted afresh: k-mers the reference's lossy key cannot tell apart (k >= 38) become one key here
+	HIPCK(hipMemset2DAsync(B.stats + ST_KEYS, sizeof(unsigned long long) * ST_N, 0, sizeof(unsigned long long), ST_SLOTS, c->st));
+	run_seg_to_table(P, B.seg_tab, (uint32_t)nfine, B.table, B.stats, B.tab_ovf, B.tab_ovf_cap, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	HIPCK(hipGetLastError());
+	HIPCK(hipFree(B.seg_tab));
+	B.seg_tab = 0;
+	P.seg = 0; c->seg_escaped = 1;
+	HIPCK(set_bloom_lds_attr(P)); // the aggregation table is back in the bloom kernel's LDS footprint
+	if (fetch_stats(c) != 0) return -1;
+	c->keys_last = c->h_stats[ST_KEYS];
+	return table_maintain(c);
+}
+
+extern "C" int bfcg_table_info(bfcg_ctx_t *c, int out[4])
+{
+	out[0] = c->P.seg; out[1] = c->P.seg ? c->P.seg_shift : 0; out[2] = c->P.seg ? 0 : c->P.tab_cshift; out[3] = (int)c->n_seg_grow;
+	return 0;
 }
 
 // ---- multi-GPU (owner computes): stage A on every rank, exchange by the caller, stage B on the owner
@@ -471,7 +611,7 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 		if (batch_times(c, pb) != 0) return -1;
 		if (fetch_stats_on(c, c->stC) != 0) return -1; // counters may already include part of the running batch: fine for the checks below
 		note_growth(c);
-		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->B.table && table_target_cshift(c) != c->P.tab_cshift)) {
+		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->P.seg ? seg_target_shift(c) != c->P.seg_shift : (c->B.table && table_target_cshift(c) != c->P.tab_cshift))) {
 			c->pend = 1; c->cur = b ^ 1; // make drain() see the batch just enqueued
 			return drain(c);
 		}
@@ -483,17 +623,19 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 // One batch, software-pipelined over two streams: stage A of this batch (ALU-bound K1) is enqueued on stA and runs
 // under stage B of the previous batch (LDS/latency-bound) on st.  The call returns once the PREVIOUS batch is
 // finalised (statistics read, table maintained); bfcg_sync / bfcg_stats / exports drain the pipeline.
-static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
+static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy = 0)
 {
 	const int b = c->cur, nb1 = 1 << c->P.F1;
 	BatchBufs Bt = c->B;
 	Bt.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1; Bt.recs1 = c->recs1[b];
-	if (c->used[b]) HIPCK(hipStreamWaitEvent(c->stA, c->evB[b], 0)); // stage B two batches ago has released this buffer set
+	hipStream_t sA = c->pipeline ? c->stA : c->st; // one stream: the batches' kernels simply follow each other
+	if (c->used[b]) HIPCK(hipStreamWaitEvent(sA, c->evB[b], 0)); // stage B two batches ago has released this buffer set
+	if (!c->pipeline && wait_copy) HIPCK(hipStreamWaitEvent(sA, c->evCopy, 0)); // the host batch is being copied on stream stA
 	if (use_stream(c) != 0) return -1;
 	Bt.stream = c->stream_mode; Bt.stream_out = c->stream_out;
-	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, c->stA, c->evt[b]);
-	HIPCK(hipEventRecord(c->evA[b], c->stA));
+	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
+	HIPCK(hipEventRecord(c->evA[b], sA));
 	HIPCK(hipStreamWaitEvent(c->st, c->evA[b], 0));
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
@@ -583,7 +725,7 @@ extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const 
 	HIPCK(hipMemcpyAsync(c->d_seq2[b], h_seq, n_pos, hipMemcpyHostToDevice, c->stA)); // ordered behind stage A of two batches ago (same stream)
 	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual2[b], h_qual, n_pos, hipMemcpyHostToDevice, c->stA));
 	HIPCK(hipEventRecord(c->evCopy, c->stA));
-	int rc = enqueue_batch(c, c->d_seq2[b], h_qual ? c->d_qual2[b] : NULL, n_pos);
+	int rc = enqueue_batch(c, c->d_seq2[b], h_qual ? c->d_qual2[b] : NULL, n_pos, 1);
 	HIPCK(hipEventSynchronize(c->evCopy)); // the caller may reuse its host buffers now
 	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c);
 	return rc;
@@ -725,8 +867,9 @@ extern "C" bfc_bf_t *bfcg_export_bloom_resident(bfcg_ctx_t *c, int which)
 
 extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 {
-	if (!c->B.table) { set_err("no count table in filter mode"); return NULL; }
+	if (c->P.filter_mode) { set_err("no count table in filter mode"); return NULL; }
 	if (drain(c) != 0) return NULL;
+	if (c->P.seg && seg_to_legacy(c) != 0) return NULL; // the host's (sub-table, key) layout is made now
 	bfc_ch_t *ch = bfc_ch_alloc_raw(c->P.k, c->P.l_pre, c->P.tab_cshift);
 	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
 	if (hipStreamSynchronize(c->st) != hipSuccess || d2h_parallel(c->prm.device, bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift)) != 0) {
@@ -909,8 +1052,9 @@ extern "C" bfcg_kcov_t *bfcg_kcov_create(const bfc_ch_t *ch, int device, uint64_
 // the table stays where the count kernels built it; the context must outlive the returned object and must not count meanwhile
 extern "C" bfcg_kcov_t *bfcg_kcov_attach(bfcg_ctx_t *c, uint64_t max_pos)
 {
-	if (!c || !c->B.table || max_pos == 0) { set_err("bfcg_kcov_attach needs a table-mode context"); return NULL; }
+	if (!c || c->P.filter_mode || max_pos == 0) { set_err("bfcg_kcov_attach needs a table-mode context"); return NULL; }
 	if (drain(c) != 0) return NULL;
+	if (c->P.seg && seg_to_legacy(c) != 0) return NULL; // bfc_ch_kmer_occ probes the host's layout
 	bfcg_kcov_t *t = kcov_new(c->P.k, c->P.l_pre, c->P.tab_cshift, c->prm.device, max_pos);
 	if (!t) return NULL;
 	t->table = c->B.table;

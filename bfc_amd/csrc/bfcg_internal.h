@@ -28,6 +28,10 @@ struct KParams {
 	int track;                  // 1: keep first/last insertion stamps for the byte-identical dump
 	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
 	int bloom_bt;               // threads per workgroup of the bloom kernel: 512 (three workgroups per CU), 1024 when the LDS footprint allows one only
+	int seg;                    // 1: the count table is kept as region-owned segments (seg_tab) and updated through LDS by k_commit_seg
+	int seg_shift;              // log2 slots per segment
+	int seg_lo, seg_hi;         // bits [seg_lo, seg_hi) of y0 are implied by the region (kmer_dev.h: SegGeom)
+	uint32_t f_base;            // global id of this rank's first bloom region
 };
 
 struct BatchBufs {
@@ -43,6 +47,7 @@ struct BatchBufs {
 	uint8_t *seen_out;
 	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
 	uint32_t *stream_out; int stream;     // STREAM mode: seen k-mers as records (k_bloom -> k_commit_stream); on / off for this batch
+	unsigned long long *seg_tab;              // region-owned table segments: [regions][2^seg_shift] slots of id << 14 | high << 8 | count (KParams.seg)
 	unsigned long long *tab_first, *sub_last; // order stamps (NULL unless KParams.track)
 	unsigned long long batch_hi;              // batch number << 32
 };
@@ -59,6 +64,12 @@ void run_streak(int k, float min_frac, const uint8_t *flags, const uint64_t *off
 void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out, hipStream_t st);
 void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap,
                       unsigned long long *first, unsigned long long *sub_last, hipStream_t st);
+// region-owned segments: grow every segment from 2^old_shift to 2^P.seg_shift slots; replay parked k-mers; convert to the (sub-table, key) layout
+void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st);
+void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
+void run_seg_to_table(const KParams &P, const unsigned long long *seg_tab, uint32_t n_fine, unsigned long long *tab, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
+hipError_t set_seg_lds_attr(void);
+#define BFCG_SEG_MAX_SHIFT 14 /* a segment must fit a CU's LDS: 2^14 slots = 128 KiB */
 void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab,
                       const unsigned long long *old_first, unsigned long long *new_first, hipStream_t st);
 

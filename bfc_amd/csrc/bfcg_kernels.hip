@@ -653,6 +653,7 @@ struct BloomArgs {
 	uint64_t *agg_out;             // aggregated seen k-mers: three planes [y0 | y1 | count|high<<16] of [n_fine][ag_cap], or NULL = commit inline
 	uint32_t *agg_cnt;             // entries per fine bucket
 	uint32_t *stream_out;          // STREAM mode: seen k-mers as records, region f's at [start[f], start[f] + agg_cnt[f])
+	unsigned long long *seg_tab;   // region-owned table segments (KParams.seg) or NULL
 	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
 	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
 	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
@@ -1201,6 +1202,150 @@ __global__ __launch_bounds__(256) void k_commit_stream(KParams P, BloomArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// Region-owned table segments (KParams.seg).  Random device-scope CAS on a multi-GiB table ran at the chip's atomic rate (~20 G/s,
+// 218 B of HBM traffic per upsert on config c3: profiles/round1_c3.md).  All k-mers of a bloom region already meet in one workgroup, so the
+// table is kept per region instead: segment f = 2^seg_shift slots of  id << 14 | high << 8 | count  (the 14 low bits exactly as
+// htab.c:7-17; id = the k-mer's y without the bits the region implies, kmer_dev.h), 0 = empty, linear probing inside the segment.
+// k_commit_seg streams segment f through LDS -- coalesced load, upserts by LDS atomics (ds_cmpst_b64), coalesced store -- no global
+// atomics at all.  The host's (sub-table, key) layout (htab.c:45-58) is produced once, at export (k_seg_to_table).
+
+__device__ __forceinline__ SegGeom seg_geom(const KParams &P) { SegGeom g; g.k = P.k; g.lo = P.seg_lo; g.hi = P.seg_hi; return g; }
+
+// returns 1: key created, 0: counts updated, -1: segment full.  (c, h) as in table_upsert: saturating, order independent.
+template <bool LDS>
+__device__ __forceinline__ int seg_upsert(unsigned long long *seg, uint32_t mask, uint64_t id, uint32_t c, uint32_t h)
+{
+	const unsigned long long fresh = (id << 14) | (c < 255 ? c : 255) | ((uint64_t)(h < 63 ? h : 63) << 8);
+	uint32_t p = seg_home(id) & mask;
+	const uint32_t lim = mask < 255u ? mask : 255u; // a run of 256 occupied slots means the segment is (as good as) full: park, the host grows
+	for (uint32_t probe = 0; probe <= lim; ++probe, p = (p + 1) & mask) {
+		unsigned long long cur = LDS ? __hip_atomic_load(&seg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&seg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (cur == 0) {
+			cur = atomicCAS(&seg[p], 0ULL, fresh);
+			if (cur == 0) return 1;
+		}
+		if ((cur >> 14) == id) {
+			for (;;) {
+				const uint32_t nc = (uint32_t)(cur & 0xff) + c, nh = (uint32_t)((cur >> 8) & 0x3f) + h;
+				const unsigned long long nv = (cur & ~0x3fffULL) | (nc < 255 ? nc : 255) | ((uint64_t)(nh < 63 ? nh : 63) << 8);
+				if (nv == cur) return 0;
+				const unsigned long long old = atomicCAS(&seg[p], cur, nv);
+				if (old == cur) return 0;
+				cur = old;
+			}
+		}
+	}
+	return -1;
+}
+
+__device__ __forceinline__ void seg_park(const BloomArgs &A, uint64_t y0, uint64_t y1, uint32_t c, uint32_t h)
+{
+	const unsigned long long o = atomicAdd(A.ovf_cnt, 1ULL); // segment full: the host grows the segments and replays (rare)
+	if (o < A.tab_ovf_cap) { A.tab_ovf[5 * o] = y0; A.tab_ovf[5 * o + 1] = y1; A.tab_ovf[5 * o + 2] = (uint64_t)c | ((uint64_t)h << 32); A.tab_ovf[5 * o + 3] = 0; A.tab_ovf[5 * o + 4] = 0; }
+}
+
+// one workgroup per region: the seen k-mers of region f are the records stream_out[start[f] .. start[f] + agg_cnt[f]) (k_bloom, STREAM)
+template <typename W, int RW, int BT>
+__global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
+	__shared__ uint32_t s_new;
+	const uint32_t f = blockIdx.x;
+	const uint32_t n = A.agg_cnt[f];
+	if (n == 0) return;
+	const uint32_t slots = 1u << P.seg_shift, mask = slots - 1;
+	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift);
+	const uint32_t *recs = A.stream_out + (uint64_t)A.start[f] * RW;
+	const SegGeom G = seg_geom(P);
+	// few k-mers for a large segment: touch their lines only (this workgroup alone owns the segment, the atomics order its own lanes)
+	const bool direct = (uint64_t)n * 16 < slots;
+	uint32_t n_new = 0;
+	if (threadIdx.x == 0) s_new = 0;
+	if (!direct) {
+		const uint4 *src = reinterpret_cast<const uint4 *>(gseg);
+		uint4 *dst = reinterpret_cast<uint4 *>(lseg);
+		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
+	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < n; j += BT) {
+		uint64_t y0, y1; uint32_t idx; bool hi;
+		Rec<RW>::unpack(rec_load<RW>(recs + (uint64_t)j * RW), y0, y1, idx, hi);
+		const uint64_t id = seg_id(G, y0, y1);
+		const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, (uint32_t)hi) : seg_upsert<true>(lseg, mask, id, 1u, (uint32_t)hi);
+		if (r > 0) ++n_new;
+		else if (r < 0) seg_park(A, y0, y1, 1u, (uint32_t)hi);
+	}
+	for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+	if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new, n_new);
+	__syncthreads();
+	if (!direct) {
+		uint4 *dst = reinterpret_cast<uint4 *>(gseg);
+		const uint4 *src = reinterpret_cast<const uint4 *>(lseg);
+		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
+	}
+	if (threadIdx.x == 0 && s_new) atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_KEYS], (unsigned long long)s_new);
+}
+
+// grow: segment f of 2^old_shift slots -> 2^P.seg_shift slots, rebuilt in LDS (all keys are distinct, the new segment is at most half full)
+template <int BT>
+__global__ __launch_bounds__(BT) void k_seg_rehash(KParams P, const unsigned long long *__restrict__ old_tab, int old_shift, unsigned long long *__restrict__ new_tab)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
+	const uint32_t f = blockIdx.x, slots = 1u << P.seg_shift, mask = slots - 1, old_slots = 1u << old_shift;
+	const unsigned long long *src = old_tab + ((uint64_t)f << old_shift);
+	for (uint32_t i = threadIdx.x; i < slots; i += BT) lseg[i] = 0;
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < old_slots; i += BT) {
+		const unsigned long long v = src[i];
+		if (!v) continue;
+		uint32_t p = seg_home(v >> 14) & mask;
+		while (atomicCAS(&lseg[p], 0ULL, v) != 0ULL) p = (p + 1) & mask;
+	}
+	__syncthreads();
+	uint4 *dst = reinterpret_cast<uint4 *>(new_tab + ((uint64_t)f << P.seg_shift));
+	const uint4 *s4 = reinterpret_cast<const uint4 *>(lseg);
+	for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = s4[i];
+}
+
+// parked k-mers (y0, y1, c | h << 32, -, -) into the grown segments, straight in HBM (a handful per batch at most)
+template <typename W>
+__global__ void k_seg_replay(KParams P, unsigned long long *seg_tab, const uint64_t *__restrict__ src, uint64_t n, unsigned long long *stats,
+                             uint64_t *ovf, uint32_t ovf_cap, unsigned long long *ovf_cnt)
+{
+	BloomArgs A; A.tab_ovf = ovf; A.tab_ovf_cap = ovf_cap; A.ovf_cnt = ovf_cnt;
+	const SegGeom G = seg_geom(P);
+	const uint32_t mask = (1u << P.seg_shift) - 1;
+	stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t y0 = src[5 * i], y1 = src[5 * i + 1];
+		const uint32_t c = (uint32_t)src[5 * i + 2], h = (uint32_t)(src[5 * i + 2] >> 32);
+		const uint32_t f = fine_id<W>(P, y0, y1) - P.f_base;
+		const int r = seg_upsert<false>(seg_tab + ((uint64_t)f << P.seg_shift), mask, seg_id(G, y0, y1), c, h);
+		if (r > 0) atomicAdd(&stats[ST_KEYS], 1ULL);
+		else if (r < 0) seg_park(A, y0, y1, c, h);
+	}
+}
+
+// export: every occupied slot of every segment becomes one bfc_ch_insert-equivalent upsert (with its counts) into the table in the
+// host's layout.  Keys that the reference itself cannot tell apart (get_subhash is lossy for k >= 38, htab.c:53-56) meet here and
+// their saturated counts add up, saturating -- what one shared counter would have reached (htab.c:74-79).
+__global__ void k_seg_to_table(KParams P, const unsigned long long *__restrict__ seg_tab, uint32_t n_fine, unsigned long long *tab,
+                               unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, unsigned long long *ovf_cnt)
+{
+	const SegGeom G = seg_geom(P);
+	const uint64_t n = (uint64_t)n_fine << P.seg_shift;
+	TabOrder O; O.first = nullptr; O.sub_last = nullptr;
+	stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const unsigned long long v = seg_tab[i];
+		if (!v) continue;
+		uint64_t y0, y1;
+		seg_unpack(G, (uint64_t)P.f_base + (i >> P.seg_shift), v >> 14, y0, y1);
+		table_upsert<false>(P, tab, y0, y1, (uint32_t)(v & 0xff), (uint32_t)((v >> 8) & 0x3f), stats, ovf, ovf_cap, ovf_cnt, O, 0ULL, 0ULL);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // debug / unit-test kernel: K1 only, one output row per position (y0,y1,flags) ; flags bit0 valid, bit1 high
 template <typename W, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_hash_only(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
@@ -1458,13 +1603,21 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	BloomArgs A;
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_slices = B.pool_slices; A.seen_out = B.seen_out;
-	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine; A.stream_out = nullptr;
+	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine; A.stream_out = nullptr; A.seg_tab = nullptr;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
 		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
 		else if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+	} else if (P.seg && B.seg_tab && B.stream_out) { // region-owned table segments: seen k-mers are streamed to k_commit_seg, one workgroup per region
+		A.stream_out = B.stream_out; A.seg_tab = B.seg_tab; A.table = nullptr; A.agg_out = nullptr;
+		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		if (ev) hipEventRecord(ev[4], st);
+		hipLaunchKernelGGL((k_commit_seg<W, RW, 256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+		if (ev) hipEventRecord(ev[5], st);
+		return;
 	} else if (B.stream && B.stream_out && !P.track && P.n_hashes == 4) { // low-multiplicity batches: no aggregation (ctx decides, see bfcg_ctx.hip)
 		A.stream_out = B.stream_out;
 		hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
@@ -1512,7 +1665,7 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 
 int bloom_lds_bytes(const KParams &P)
 {
-	const size_t second = P.filter_mode ? ((size_t)64 << P.R) : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)); // second filter's slice or aggregation table
+	const size_t second = P.filter_mode ? ((size_t)64 << P.R) : P.seg ? 0 : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)); // second filter's slice or aggregation table
 	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + second + (size_t)P.list_cap * 8 + 16);
 }
 
@@ -1528,6 +1681,8 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_commit_seg<W, RW, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
@@ -1583,6 +1738,21 @@ void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t 
 	int g = (int)((n + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
 	TabOrder O; O.first = first; O.sub_last = sub_last;
 	hipLaunchKernelGGL(k_table_replay, dim3(g), dim3(256), 0, st, P, tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N, O);
+}
+hipError_t set_seg_lds_attr(void) { return hipFuncSetAttribute((const void *)k_seg_rehash<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); }
+void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st)
+{
+	hipLaunchKernelGGL((k_seg_rehash<512>), dim3(n_fine), dim3(512), (size_t)8 << P.seg_shift, st, P, old_tab, old_shift, new_tab);
+}
+void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
+{
+	int g = (int)((n + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
+	if (P.k <= 32) hipLaunchKernelGGL((k_seg_replay<uint32_t>), dim3(g), dim3(256), 0, st, P, seg_tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N);
+	else hipLaunchKernelGGL((k_seg_replay<uint64_t>), dim3(g), dim3(256), 0, st, P, seg_tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N);
+}
+void run_seg_to_table(const KParams &P, const unsigned long long *seg_tab, uint32_t n_fine, unsigned long long *tab, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_seg_to_table, dim3(4096), dim3(256), 0, st, P, seg_tab, n_fine, tab, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N);
 }
 void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab,
                       const unsigned long long *old_first, unsigned long long *new_first, hipStream_t st)

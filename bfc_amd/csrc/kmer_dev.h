@@ -95,6 +95,27 @@ __device__ __forceinline__ uint32_t ch_subkey(int k, int l_pre, uint64_t y0, uin
 	}
 }
 
+// ---- region-owned table segments ----
+// Every occurrence of a k-mer falls into the same bloom region f = block id >> R, and block id = the low bf_shift-9 bits of
+// hash = (h0^h1)<<k | y0 (kmer.h:87): bits [lo, hi) of y0, lo = min(R, k), hi = max(lo, min(k, bf_shift-9)), ARE the low hi-lo bits of f.
+// Inside region f a k-mer is therefore identified by y minus those bits: 2k - (hi - lo) bits, which together with the 14 count bits
+// of htab.c:7-17 fit one 64-bit word for every configuration BASELINE.json names (c2: 46, c3: 48, c4: 46 identity bits).
+struct SegGeom { int k, lo, hi; }; // hi - lo = implied bits
+__host__ __device__ __forceinline__ uint64_t seg_id(const SegGeom g, uint64_t y0, uint64_t y1)
+{
+	const uint64_t low = y0 & ((1ULL << g.lo) - 1), up = g.hi < g.k ? y0 >> g.hi : 0;
+	return low | up << g.lo | y1 << (g.k - (g.hi - g.lo));
+}
+__host__ __device__ __forceinline__ void seg_unpack(const SegGeom g, uint64_t f_global, uint64_t id, uint64_t &y0, uint64_t &y1)
+{
+	const int nimp = g.hi - g.lo, kb = g.k - nimp; // bits of y0 kept in the id
+	const uint64_t imp = f_global & ((1ULL << nimp) - 1);
+	const uint64_t kept = id & ((1ULL << kb) - 1);
+	y0 = (kept & ((1ULL << g.lo) - 1)) | imp << g.lo | (g.hi < g.k ? (kept >> g.lo) << g.hi : 0);
+	y1 = id >> kb;
+}
+__host__ __device__ __forceinline__ uint32_t seg_home(uint64_t id) { return (uint32_t)((id * 0x9E3779B97F4A7C15ULL) >> 38); }
+
 // bbf.c:27-41 -- block id and the n_hashes bit positions (8..511) inside the 512-bit block
 struct BloomAddr {
 	uint64_t blk;

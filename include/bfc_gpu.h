@@ -96,6 +96,8 @@ typedef struct {
 	int debug_seen;             /* allocate the per-position seen-flag buffer (tests) */
 	int track_order;            /* keep per-key first-insert / per-sub-table last-call stamps: bfc_ch_dump becomes byte-identical to `bfc -t1 -d` */
 	int rank, n_ranks;          /* multi-GPU, owner computes: this process is rank of n_ranks (0/0 or 0/1: single GPU) */
+	int table_layout;           /* 0: region-owned table segments updated through LDS wherever the geometry allows (2k minus the bits a bloom region
+	                             * implies <= 50), converted to the host's layout at export; 1: the host's (sub-table, key) layout from the start */
 } bfcg_params_t;
 
 void bfcg_params_default(bfcg_params_t *p);
@@ -144,6 +146,9 @@ void  bfcg_host_free(void *p);
 enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS, BFCG_ST_CROWDED,
        BFCG_ST_TAB_CSHIFT = 8, BFCG_ST_BATCHES, BFCG_ST_N = 16 };
 int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
+/* how the count table is held right now: out[0] 1 = region-owned segments, 0 = the host's layout; out[1] log2 slots per segment;
+ * out[2] log2 slots per sub-table; out[3] segment growths so far */
+int bfcg_table_info(bfcg_ctx_t *c, int out[4]);
 /* batches handled without aggregation (k-mers that hardly repeat inside a batch: seen k-mers are streamed to the table kernel) */
 uint64_t bfcg_stream_batches(bfcg_ctx_t *c);
 

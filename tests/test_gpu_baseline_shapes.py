@@ -76,14 +76,14 @@ def test_g42_reference_goldens(gpu_lib, g42, k, b, n_batches):
     g.close()
 
 
-@pytest.mark.parametrize("batch_reads", [786432, 1572864])
-def test_c2_full_read_set(gpu_lib, batch_reads):
+@pytest.mark.parametrize("batch_reads,layout", [(786432, 0), (1572864, 0), (786432, 1)])
+def test_c2_full_read_set(gpu_lib, batch_reads, layout):
     """Config c2 as bench.py runs it (k=31, -b33, 3.07 M reads at 100x, 4 or 2 batches): equals the reference on the same reads."""
     e = BASE["c2"]
     rs = gen.ReadSet(**e["gen"])
-    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], batch_reads)
-    st = _check_against(g, e)
-    assert st["slow_buckets"] == 0
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], batch_reads, table_layout=layout)
+    assert g.table_info()["segments"] == (layout == 0)  # c2's geometry takes the region-owned table segments (46 identity bits)
+    _check_against(g, e)
     g.close()
 
 
@@ -93,9 +93,28 @@ def test_c3_full_read_set(gpu_lib):
     e = BASE["c3"]
     rs = gen.ReadSet(**e["gen"])
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584)
+    ti = g.table_info()
+    assert ti["segments"] and ti["seg_growths"] >= 1, ti  # 48 identity bits; the segments grow with the 300 M keys
     st = _check_against(g, e)
     assert st["stream_batches"] > 0, "c3 is expected to run (mostly) without in-LDS aggregation"
     g.close()
+
+
+def test_c3_shape_host_layout(gpu_lib):
+    """The same geometry with the table in the host's layout from the start (random-CAS upserts, STREAM decisions, table growth by
+    rehash) on the first 12 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
+    e = dict(gen=dict(seed=3, G=248_000_000, cov=30.0), k=33, b=35)
+    rs = gen.ReadSet(**e["gen"])
+    rs.n_reads = 12_000_000
+    res = []
+    for layout in (0, 1):
+        g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584, table_layout=layout)
+        st = g.stats()
+        t = g.export_table()
+        sizes, slots = t.export_sorted()
+        res.append((st["n_kmers"], st["n_high"], st["n_seen"], st["n_keys"], gen.bitmap_checksums(g.bloom_bytes()), oracle.l1_digest(sizes, slots)))
+        t.close(); g.close()
+    assert res[0] == res[1]
 
 
 def test_c4_parameters(gpu_lib):

@@ -50,6 +50,8 @@ def _draw(seed, scale=1, b_range=(10, 28)):
         kw["region_shift"] = int(rng.integers(4, 11))
     if rng.random() < 0.3:
         kw["tab_cshift"] = int(rng.integers(1, 4))
+    if seed % 3 == 0:
+        kw["table_layout"] = 1  # the host's (sub-table, key) layout from the start; otherwise region-owned segments where the geometry allows
     return dict(k=k, b=b, nh=nh, l_pre=l_pre, q=q, fm=fm), seq, qual, off, cuts, kw
 
 
