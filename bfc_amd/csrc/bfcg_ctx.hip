@@ -61,6 +61,9 @@ struct bfcg_ctx {
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
 	uint64_t n_seg_grow;         // segment growths since creation
+	int seg_cap_shift;           // the allocation behind B.seg_tab holds segments of up to 2^seg_cap_shift slots
+	unsigned long long *seg_spare; int seg_spare_shift; // the buffer the last growth left behind (kept up to 16 GiB): growth rehashes from one into the other,
+	                             // so a context that counts one data set after the other stops calling hipMalloc / hipFree (tens of ms per multi-GiB call)
 };
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
@@ -162,10 +165,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
 	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 20;
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
-	// Stage A of the next batch under stage B of this one (two streams) pays only where both kernels' workgroups fit a CU side by side:
-	// 12-byte records (scatter stage 52 KB of LDS next to the bloom kernel's 53 KB: c2 14.2 vs 15.4 ms per step).  With 16-byte records the
-	// scatter kernels hold 74 KB each, the kernels take turns on every CU and both run several times slower (c3: 389 vs 328 ms per step).
-	{ const char *e = getenv("BFCG_PIPELINE"); c->pipeline = e ? atoi(e) != 0 : c->rw == 12; }
+	// Stage A of the next batch runs under stage B of this one (two streams): c2 14.2 vs 15.4 ms per step.  While the count table was updated by
+	// random device-scope atomics the overlap HURT config c3 (389 vs 328 ms per step: the scatter kernels crawled beside k_commit_stream); with
+	// the table streamed through LDS (k_commit_seg) it is a small gain there too (267.8 vs 273.8 ms).  BFCG_PIPELINE=0: one stream.
+	{ const char *e = getenv("BFCG_PIPELINE"); c->pipeline = e ? atoi(e) != 0 : 1; }
 
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
 	P.idx_rank = n_ranks > 1 ? (uint32_t)prm->rank << (32 - log2n) : 0u;
@@ -209,7 +212,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (prm->tab_cshift <= 0) while (((uint64_t)nfine << sh) < prm->max_batch_pos / 4 && sh < BFCG_SEG_MAX_SHIFT) ++sh;
 		if (sh > BFCG_SEG_MAX_SHIFT) sh = BFCG_SEG_MAX_SHIFT;
 		c->seg_init_shift = sh;
-		P.seg = 1; P.seg_shift = sh;
+		P.seg = 1; P.seg_shift = sh; c->seg_cap_shift = sh;
 		HIPCKN(set_seg_lds_attr());
 		HIPCKN(hipMalloc(&B.seg_tab, ((uint64_t)nfine << sh) * 8));
 		HIPCKN(hipMalloc(&c->stream_out, c->recv_cap * (uint64_t)c->rw));
@@ -251,7 +254,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
-	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab);
+	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -275,13 +278,13 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	if (c->B.bloom_hi) HIPCK(hipMemsetAsync(c->B.bloom_hi, 0, c->bloom_bytes, c->st));
 	if (c->seg_ok) { // back to region-owned segments of the initial size (a run that outgrew them, or an export, left the other layout behind)
 		const uint64_t nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
-		if (c->seg_escaped || c->P.seg_shift != c->seg_init_shift || !c->B.seg_tab) {
+		if (c->seg_escaped || !c->B.seg_tab) {
 			HIPCK(hipStreamSynchronize(c->st));
 			if (c->B.table) { HIPCK(hipFree(c->B.table)); c->B.table = 0; }
 			if (c->B.seg_tab) { HIPCK(hipFree(c->B.seg_tab)); c->B.seg_tab = 0; }
-			c->P.seg_shift = c->seg_init_shift;
+			c->P.seg_shift = c->seg_cap_shift = c->seg_init_shift;
 			HIPCK(hipMalloc(&c->B.seg_tab, (nfine << c->P.seg_shift) * 8));
-		}
+		} else c->P.seg_shift = c->seg_init_shift; // start small again inside the allocation the last run grew to (seg_cap_shift says how far it goes)
 		c->P.seg = 1; c->seg_escaped = 0;
 		HIPCK(hipMemsetAsync(c->B.seg_tab, 0, (nfine << c->P.seg_shift) * 8, c->st));
 	}
@@ -462,13 +465,19 @@ static int seg_maintain(bfcg_ctx_t *c)
 		}
 		const int old_shift = P.seg_shift;
 		unsigned long long *nt = 0;
+		int nt_shift = target;
 		P.seg_shift = target;
-		HIPCK(hipMalloc(&nt, (nfine << target) * 8));
+		if (c->seg_spare && c->seg_spare_shift >= target) { nt = c->seg_spare; nt_shift = c->seg_spare_shift; c->seg_spare = 0; }
+		else {
+			if (c->seg_spare) { HIPCK(hipFree(c->seg_spare)); c->seg_spare = 0; }
+			HIPCK(hipMalloc(&nt, (nfine << target) * 8));
+		}
 		run_seg_rehash(P, B.seg_tab, old_shift, nt, (uint32_t)nfine, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		HIPCK(hipGetLastError());
-		HIPCK(hipFree(B.seg_tab));
-		B.seg_tab = nt;
+		if (((nfine << c->seg_cap_shift) * 8) <= (16ULL << 30)) { c->seg_spare = B.seg_tab; c->seg_spare_shift = c->seg_cap_shift; }
+		else HIPCK(hipFree(B.seg_tab));
+		B.seg_tab = nt; c->seg_cap_shift = nt_shift;
 		++c->n_seg_grow;
 		if (ovf) {
 			uint64_t *tmp = 0;
@@ -489,6 +498,7 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 	KParams &P = c->P; BatchBufs &B = c->B;
 	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
 	const uint64_t keys = c->h_stats[ST_KEYS];
+	if (c->seg_spare) { HIPCK(hipFree(c->seg_spare)); c->seg_spare = 0; }
 	int cs = c->prm.tab_cshift > 0 ? c->prm.tab_cshift : 2;
 	while ((1ULL << (P.l_pre + cs)) < 2 * keys + (c->prm.max_batch_pos / 4) && P.l_pre + cs < 36) ++cs;
 	{ // as much as memory allows (the segments live until the table is filled)

@@ -524,6 +524,8 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	}
 }
 
+__device__ __forceinline__ SegGeom seg_geom(const KParams &P) { SegGeom g; g.k = P.k; g.lo = P.seg_lo; g.hi = P.seg_hi; return g; }
+
 // Optional order bookkeeping for the byte-identical `-d` dump: per slot the stamp (batch << 32 | file index)
 // of the FIRST bfc_ch_insert call that created the key, per sub-table the stamp of the LAST call of any kind.  The host
 // replays khash's growth from them (bfc_host.c).  Both are order-independent (min / max), so parking and replay keep them exact.
@@ -807,7 +809,7 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 // STREAM: no aggregation; every seen k-mer is appended, as the record it came in, to the region's slice of A.stream_out and k_commit_stream
 // applies them.  For batches in which k-mers hardly repeat (a large genome at ~1x per batch) the aggregation table only costs: it fills
 // with singletons and the rest updates the count table from inside this kernel, a returning atomic in a workgroup that lives microseconds.
-template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false, bool STREAM = false>
+template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false, bool STREAM = false, bool SEGOUT = false>
 __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
@@ -909,9 +911,14 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			uint32_t o0 = 0;
 			if (lane == leader) o0 = atomicAdd(&s_agg_n, (uint32_t)__popcll(vote));
 			o0 = __shfl(o0, leader);
-			RecW<RW> w;
-			Rec<RW>::pack(w, r.y0, r.y1, r.idx, r.hi);
-			rec_store<RW>(A.stream_out + ((uint64_t)rs + o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1))) * RW, w);
+			const uint64_t at = (uint64_t)rs + o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1));
+			if constexpr (SEGOUT) { // region-owned table segments: all k_commit_seg needs is the k-mer's identity inside this region and its quality flag
+				reinterpret_cast<unsigned long long *>(A.stream_out)[at] = (seg_id(seg_geom(P), r.y0, r.y1) << 1) | (unsigned long long)r.hi;
+			} else {
+				RecW<RW> w;
+				Rec<RW>::pack(w, r.y0, r.y1, r.idx, r.hi);
+				rec_store<RW>(A.stream_out + at * RW, w);
+			}
 		} else emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx);
 	};
 	// append a k-mer with clear bits to the LDS list: one LDS atomic per wave
@@ -1209,7 +1216,6 @@ __global__ __launch_bounds__(256) void k_commit_stream(KParams P, BloomArgs A)
 // k_commit_seg streams segment f through LDS -- coalesced load, upserts by LDS atomics (ds_cmpst_b64), coalesced store -- no global
 // atomics at all.  The host's (sub-table, key) layout (htab.c:45-58) is produced once, at export (k_seg_to_table).
 
-__device__ __forceinline__ SegGeom seg_geom(const KParams &P) { SegGeom g; g.k = P.k; g.lo = P.seg_lo; g.hi = P.seg_hi; return g; }
 
 // returns 1: key created, 0: counts updated, -1: segment full.  (c, h) as in table_upsert: saturating, order independent.
 template <bool LDS>
@@ -1244,8 +1250,9 @@ __device__ __forceinline__ void seg_park(const BloomArgs &A, uint64_t y0, uint64
 	if (o < A.tab_ovf_cap) { A.tab_ovf[5 * o] = y0; A.tab_ovf[5 * o + 1] = y1; A.tab_ovf[5 * o + 2] = (uint64_t)c | ((uint64_t)h << 32); A.tab_ovf[5 * o + 3] = 0; A.tab_ovf[5 * o + 4] = 0; }
 }
 
-// one workgroup per region: the seen k-mers of region f are the records stream_out[start[f] .. start[f] + agg_cnt[f]) (k_bloom, STREAM)
-template <typename W, int RW, int BT>
+// one workgroup per region: the seen k-mers of region f are the 8-byte entries stream_out[start[f] .. start[f] + agg_cnt[f]) (k_bloom, SEGOUT):
+// identity inside the region << 1 | high-quality flag
+template <int BT>
 __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
@@ -1255,7 +1262,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	if (n == 0) return;
 	const uint32_t slots = 1u << P.seg_shift, mask = slots - 1;
 	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift);
-	const uint32_t *recs = A.stream_out + (uint64_t)A.start[f] * RW;
+	const unsigned long long *recs = reinterpret_cast<const unsigned long long *>(A.stream_out) + A.start[f];
 	const SegGeom G = seg_geom(P);
 	// few k-mers for a large segment: touch their lines only (this workgroup alone owns the segment, the atomics order its own lanes)
 	const bool direct = (uint64_t)n * 16 < slots;
@@ -1268,12 +1275,12 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	}
 	__syncthreads();
 	for (uint32_t j = threadIdx.x; j < n; j += BT) {
-		uint64_t y0, y1; uint32_t idx; bool hi;
-		Rec<RW>::unpack(rec_load<RW>(recs + (uint64_t)j * RW), y0, y1, idx, hi);
-		const uint64_t id = seg_id(G, y0, y1);
-		const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, (uint32_t)hi) : seg_upsert<true>(lseg, mask, id, 1u, (uint32_t)hi);
+		const unsigned long long v = recs[j];
+		const uint64_t id = v >> 1;
+		const uint32_t hi = (uint32_t)(v & 1);
+		const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
 		if (r > 0) ++n_new;
-		else if (r < 0) seg_park(A, y0, y1, 1u, (uint32_t)hi);
+		else if (r < 0) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); }
 	}
 	for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
 	if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new, n_new);
@@ -1612,10 +1619,10 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else if (P.seg && B.seg_tab && B.stream_out) { // region-owned table segments: seen k-mers are streamed to k_commit_seg, one workgroup per region
 		A.stream_out = B.stream_out; A.seg_tab = B.seg_tab; A.table = nullptr; A.agg_out = nullptr;
-		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
-		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
-		hipLaunchKernelGGL((k_commit_seg<W, RW, 256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+		hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
 	} else if (B.stream && B.stream_out && !P.track && P.n_hashes == 4) { // low-multiplicity batches: no aggregation (ctx decides, see bfcg_ctx.hip)
@@ -1681,8 +1688,9 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_commit_seg<W, RW, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_commit_seg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
