@@ -70,6 +70,19 @@ SYMBOLS = {
     "bfcg_batch_limit": (C.c_uint64, [C.c_void_p]),
     "bfcg_mg_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, u32p]),
     "bfcg_mg_process": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
+    "bfcg_group_unique_id": (C.c_int, [C.c_void_p]),
+    "bfcg_group_create": (C.c_void_p, [C.POINTER(BfcgParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int]),
+    "bfcg_group_destroy": (None, [C.c_void_p]),
+    "bfcg_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "bfcg_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "bfcg_group_reset": (C.c_int, [C.c_void_p]),
+    "bfcg_group_count_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),
+    "bfcg_group_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bfcg_group_sync": (C.c_int, [C.c_void_p]),
+    "bfcg_group_stats": (C.c_int, [C.c_void_p, u64p]),
+    "bfcg_group_export_table": (C.c_void_p, [C.c_void_p]),
+    "bfcg_group_export_bloom": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),
+    "bfcg_group_export_bloom_resident": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),
     "bfcg_trim_create": (C.c_void_p, [C.c_int, C.POINTER(BfcBf), C.c_int, C.c_uint64, C.c_uint64]),
     "bfcg_trim_destroy": (None, [C.c_void_p]),
     "bfcg_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_uint64, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

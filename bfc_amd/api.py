@@ -209,14 +209,23 @@ class GpuCounter:
         if not self.ctx:
             raise BfcGpuError("bfcg_create failed: " + self.L.bfcg_last_error().decode())
 
+    @classmethod
+    def _view(cls, ctx, params, n_ranks):
+        """A GpuCounter over a context somebody else owns (a group's rank)."""
+        self = cls.__new__(cls)
+        self.L = _lib.load()
+        self.ctx, self.params, self._borrowed = ctx, params, True
+        self.rank, self.n_ranks, self.bf_shift, self.k = 0, n_ranks, params.bf_shift, params.k
+        return self
+
     def _ck(self, rc):
         if rc != 0:
             raise BfcGpuError(self.L.bfcg_last_error().decode())
 
     def close(self):
-        if self.ctx:
+        if self.ctx and not getattr(self, "_borrowed", False):
             self.L.bfcg_destroy(self.ctx)
-            self.ctx = None
+        self.ctx = None
 
     def __del__(self):
         try:
@@ -325,6 +334,99 @@ class GpuCounter:
         out = np.zeros(n_pos, dtype=np.uint8)
         self._ck(self.L.bfcg_seen_flags(self.ctx, out.ctypes.data, n_pos))
         return out
+
+
+class GpuGroup:
+    """The local ranks of a multi-GPU run, driven inside libbfc_gpu.so (bfcg_group_t): stage A, the exchange of the k-mer records over RCCL
+    (or peer copies between the devices of one process) and stage B, one host thread per rank.  `devices` lists the local ranks' devices --
+    all ranks of the run (one process), or one of them together with `uid` (one process per GPU).  A device may be repeated: ranks emulated
+    on one GPU.  max_batch_pos = positions of ONE rank's share of a global batch."""
+
+    def __init__(self, k, bf_shift, devices, max_batch_pos, n_ranks=None, first_rank=0, uid=None, transport=0, q=20, n_hashes=4, l_pre=20,
+                 filter_mode=0, track_order=False, table_layout=0, region_shift=0, tab_cshift=0):
+        self.L = _lib.load()
+        p = BfcgParams()
+        self.L.bfcg_params_default(C.byref(p))
+        p.k, p.q, p.bf_shift, p.n_hashes, p.l_pre, p.filter_mode = k, q, bf_shift, n_hashes, l_pre, filter_mode
+        p.max_batch_pos, p.region_shift, p.tab_cshift, p.track_order, p.table_layout = int(max_batch_pos), region_shift, tab_cshift, int(track_order), int(table_layout)
+        self.params, self.k, self.bf_shift = p, k, bf_shift
+        self.devices = list(devices)
+        self.n_local = len(self.devices)
+        self.n_ranks = n_ranks if n_ranks is not None else self.n_local
+        dv = (C.c_int * self.n_local)(*self.devices)
+        self._uid = (C.c_uint8 * 128).from_buffer_copy(bytes(uid)) if uid is not None else None
+        self.g = self.L.bfcg_group_create(C.byref(p), self.n_ranks, first_rank, self.n_local, dv, self._uid, transport)
+        if not self.g:
+            raise BfcGpuError("bfcg_group_create failed: " + self.L.bfcg_last_error().decode())
+
+    @staticmethod
+    def unique_id():
+        L = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        if L.bfcg_group_unique_id(buf) != 0:
+            raise BfcGpuError(L.bfcg_last_error().decode())
+        return bytes(buf)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+
+    def close(self):
+        if self.g:
+            self.L.bfcg_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        out = (C.c_int * 6)()
+        self.L.bfcg_group_info(self.g, out)
+        return dict(n_ranks=out[0], n_local=out[1], transport={1: "rccl", 2: "peer"}.get(out[2], out[2]), rec_bytes=out[3], nb1=out[4], first_rank=out[5])
+
+    def ctx(self, i):
+        """Local rank i's counting context as a GpuCounter view (owned by the group)."""
+        return GpuCounter._view(self.L.bfcg_group_ctx(self.g, i), self.params, self.n_ranks)
+
+    def reset(self):
+        self._ck(self.L.bfcg_group_reset(self.g))
+
+    def sync(self):
+        self._ck(self.L.bfcg_group_sync(self.g))
+
+    def count_host(self, seq_stream, qual_stream=None):
+        """One global batch from host memory; the library cuts it into the ranks' shares (every rank local)."""
+        seq_stream = np.ascontiguousarray(seq_stream, dtype=np.uint8)
+        q = np.ascontiguousarray(qual_stream, dtype=np.uint8) if qual_stream is not None else None
+        self._ck(self.L.bfcg_group_count_batch_host(self.g, seq_stream.ctypes.data, q.ctypes.data if q is not None else None, len(seq_stream)))
+
+    def count_dev(self, d_seq, d_qual, n_pos):
+        """One global batch: lists (one entry per local rank) of device pointers on the rank's own device and stream lengths."""
+        n = self.n_local
+        ds = (C.c_void_p * n)(*[int(v) if v else None for v in d_seq])
+        dq = (C.c_void_p * n)(*[int(v) if v else None for v in d_qual]) if d_qual is not None else None
+        npos = (C.c_uint64 * n)(*[int(v) for v in n_pos])
+        self._ck(self.L.bfcg_group_count_batch_dev(self.g, ds, dq, npos))
+
+    def stats(self):
+        out = np.zeros(16, dtype=np.uint64)
+        self._ck(self.L.bfcg_group_stats(self.g, out.ctypes.data_as(u64p)))
+        return {STAT_NAMES[i]: int(out[i]) for i in STAT_NAMES}
+
+    def export_table(self):
+        p = self.L.bfcg_group_export_table(self.g)
+        if not p:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return HostTable(p)
+
+    def export_bloom(self, which=0):
+        p = self.L.bfcg_group_export_bloom(self.g, which)
+        if not p:
+            raise BfcGpuError(self.L.bfcg_last_error().decode())
+        return HostBloom(p)
 
 
 class GpuTrimmer:

@@ -70,12 +70,26 @@ static void *reader_main(void *arg)
 	return 0;
 }
 
+/* BFC_GPU_DEVICES="0,1,2,3" (or a count, "4" = devices 0..3): the GPUs bfc_count and the trim pass of bfc_correct spread a file over.
+ * A device may be named several times (ranks emulated on one GPU).  Returns the number of devices (0: variable not set). */
+int bfcg_env_devices(int *dev, int max)
+{
+	const char *e = getenv("BFC_GPU_DEVICES");
+	int n = 0;
+	if (!e || !*e) return 0;
+	if (!strchr(e, ',')) { int c = atoi(e), i; if (c > max) c = max; if (c < 0) c = 0; for (i = 0; i < c; ++i) dev[i] = i; return c; } /* a count */
+	while (*e && n < max) { dev[n++] = (int)strtol(e, (char**)&e, 10); while (*e == ',' || *e == ' ') ++e; }
+	return n;
+}
+
 /* ------------------------------------------------------------------ bfc_count */
 
 void *bfc_count(const char *fn, const bfc_opt_t *opt)
 {
 	bfcg_params_t prm;
-	bfcg_ctx_t *ctx;
+	bfcg_ctx_t *ctx = 0;
+	bfcg_group_t *grp = 0; /* several GPUs (BFC_GPU_DEVICES): the library's rank threads do stage A, the exchange over RCCL and stage B */
+	int devs[64], n_dev;
 	ingest_t ps;
 	pipe_t pp;
 	pthread_t tid;
@@ -116,9 +130,18 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	prm.max_batch_pos = cap;
 	timing = getenv("BFC_GPU_TIMING") != 0; /* phase times on stderr */
 	tt = now_real();
-	ctx = bfcg_create(&prm);
-	if (timing) fprintf(stderr, "[T::bfc_count] GPU context (buffers for %llu positions per batch): %.3f s\n", (unsigned long long)cap, now_real() - tt);
-	if (ctx == 0) { fprintf(stderr, "[E::%s] cannot set up the GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
+	n_dev = bfcg_env_devices(devs, 64);
+	if (n_dev > 1 && (n_dev & (n_dev - 1))) { fprintf(stderr, "[E::%s] BFC_GPU_DEVICES names %d devices: the bloom regions are dealt to a power of two of GPUs\n", __func__, n_dev); abort(); }
+	if (n_dev > 1) { /* every rank takes 1/n of each batch (cut at read boundaries: shares differ by a read or two) */
+		prm.max_batch_pos = cap / (uint64_t)n_dev + cap / 64 + (1u << 16);
+		grp = bfcg_group_create(&prm, n_dev, 0, n_dev, devs, 0, (env = getenv("BFC_GPU_TRANSPORT")) ? atoi(env) : 0);
+		if (grp == 0) { fprintf(stderr, "[E::%s] cannot set up the multi-GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
+	} else {
+		if (n_dev == 1) prm.device = devs[0];
+		ctx = bfcg_create(&prm);
+		if (ctx == 0) { fprintf(stderr, "[E::%s] cannot set up the GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
+	}
+	if (timing) fprintf(stderr, "[T::bfc_count] GPU context%s (buffers for %llu positions per batch): %.3f s\n", grp ? "s" : "", (unsigned long long)cap, now_real() - tt);
 
 	/* parser threads: -t (the count itself needs no host threads), BFC_GPU_IO_THREADS overrides; 0 = serial parser only */
 	io_threads = (env = getenv("BFC_GPU_IO_THREADS")) ? atoi(env) : opt->n_threads > 1 ? opt->n_threads : 0;
@@ -149,7 +172,8 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		if (b->n_seqs) {
 			double rt, eff;
 			int rc = 0;
-			if (b->has_qual && b->n_noq) { /* mixed batch: its runs of records with / without qualities, one after the other */
+			if (grp) rc = bfcg_group_count_batch_host(grp, b->seq, b->has_qual ? b->qual : 0, b->n_pos); /* (records without qualities inside a FASTQ batch carry '~' here: always high for -q <= 93) */
+			else if (b->has_qual && b->n_noq) { /* mixed batch: its runs of records with / without qualities, one after the other */
 				uint64_t o = 0;
 				int j, kind = (b->n_cut & 1) ? !b->last_kind : b->last_kind; /* kind of the first run: the kinds alternate at every cut */
 				for (j = 0; j <= b->n_cut && rc == 0; ++j, kind = !kind) {
@@ -159,7 +183,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 				}
 			} else rc = bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos);
 			if (rc != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
-			bfcg_stats(ctx, st);
+			if (grp) bfcg_group_stats(grp, st); else bfcg_stats(ctx, st);
 			rt = now_real() - t0; eff = 100. * now_cpu() / (rt + 1e-6);
 			if (!opt->filter_mode)
 				fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, b->n_seqs, (long)st[BFCG_ST_KEYS]);
@@ -179,14 +203,16 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	if (!opt->no_mt_io) pthread_join(tid, 0);
 
 	tt = now_real();
-	ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_export_bloom(ctx, 1) : bfcg_export_bloom_resident(ctx, 1)) /* bf_high also stays in HBM for the trim pass (bfc_trim.c) */
-	                       : (void*)bfcg_export_table(ctx);
+	if (grp) ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_group_export_bloom(grp, 1) : bfcg_group_export_bloom_resident(grp, 1)) /* all-gathered onto every device for the sharded trim pass */
+	                                : (void*)bfcg_group_export_table(grp);
+	else ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_export_bloom(ctx, 1) : bfcg_export_bloom_resident(ctx, 1)) /* bf_high also stays in HBM for the trim pass (bfc_trim.c) */
+	                            : (void*)bfcg_export_table(ctx);
 	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
 	for (i = 0; i < 2; ++i) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); free(pp.b[i].kind_cut); }
 	pthread_mutex_destroy(&pp.mtx); pthread_cond_destroy(&pp.cv);
 	ingest_close(&ps);
-	bfcg_destroy(ctx); /* the first bloom filter dies here, as in count.c:155 */
+	if (grp) bfcg_group_destroy(grp); else bfcg_destroy(ctx); /* the first bloom filter dies here, as in count.c:155 */
 	return ret;
 }
 

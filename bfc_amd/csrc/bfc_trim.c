@@ -32,6 +32,19 @@ static double t_cpu(void)
 }
 
 #include "bfc_ingest.h"
+#include <pthread.h>
+
+int bfcg_env_devices(int *dev, int max); /* bfc_count.c: BFC_GPU_DEVICES */
+
+/* the trim pass is embarrassingly parallel over reads: with several GPUs every batch's reads are dealt to them in
+ * contiguous ranges, one host thread per device; each device holds the whole of bf_high (left there by bfc_count, or uploaded) */
+typedef struct { bfcg_trim_t *tr; const uint8_t *seq; uint64_t n_pos; uint64_t *off; uint64_t n; float min_frac; int32_t *st, *en; int rc; } trim_job_t;
+static void *trim_worker(void *p)
+{
+	trim_job_t *j = (trim_job_t*)p;
+	j->rc = j->n ? bfcg_trim_batch(j->tr, j->seq, 0, j->n_pos, j->off, j->n, j->min_frac, j->st, j->en) : 0;
+	return 0;
+}
 
 typedef struct { uint64_t off_hdr, off_cmt; int has_comment, has_qual; } rinfo_t; /* name and comment (as bseq_read copied them) in hdrs[] */
 
@@ -40,8 +53,9 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	const bfc_bf_t *bf = (const bfc_bf_t*)ptr;
 	parser_t ps;
 	batch_t b;
-	bfcg_trim_t *tr;
-	uint64_t cap, max_reads, *off;
+	bfcg_trim_t *tr, *trs[64];
+	int devs[64], n_dev, d;
+	uint64_t cap, max_reads, *off, *off2 = 0;
 	int32_t *st, *en;
 	rinfo_t *ri;
 	char *hdrs = 0; size_t l_hdrs, m_hdrs = 0;
@@ -60,8 +74,17 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	if (cap < (1u << 16)) cap = 1u << 16;
 	cap += cap / 64 + (1u << 20);
 	max_reads = cap / 16 + 1024;
-	tr = bfcg_trim_create(opt->k, bf, (env = getenv("BFC_GPU_DEVICE")) ? atoi(env) : 0, cap, max_reads);
-	if (!tr) { fprintf(stderr, "[E::%s] cannot set up the GPU trim pass: %s\n", __func__, bfcg_last_error()); abort(); }
+	n_dev = bfcg_env_devices(devs, 64);
+	if (n_dev == 0) { n_dev = 1; devs[0] = (env = getenv("BFC_GPU_DEVICE")) ? atoi(env) : 0; }
+	for (d = 0; d < n_dev; ++d) {
+		int dup = 0, j;
+		for (j = 0; j < d; ++j) if (devs[j] == devs[d]) dup = 1; /* a device named twice: its first context serves both shares' turns */
+		(void)dup;
+		trs[d] = bfcg_trim_create(opt->k, bf, devs[d], n_dev > 1 ? cap / (uint64_t)n_dev + cap / 64 + (1u << 16) : cap, n_dev > 1 ? max_reads / (uint64_t)n_dev + 1024 : max_reads);
+		if (!trs[d]) { fprintf(stderr, "[E::%s] cannot set up the GPU trim pass: %s\n", __func__, bfcg_last_error()); abort(); }
+	}
+	tr = trs[0];
+	if (n_dev > 1) off2 = (uint64_t*)malloc((max_reads + 1 + (uint64_t)n_dev) * 8);
 
 	memset(&ps, 0, sizeof(ps));
 	ps.keep_hdr = 1;
@@ -105,8 +128,26 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_ec_cb", (int)n); /* correct.c:582, once per bseq_read call */
 		if (n == 0 && ++empties >= (opt->no_mt_io ? 1 : 2)) last = 1; /* each of the pipeline's workers ends on its own empty batch (kthread.c:88-106, correct.c:644) */
 		if (n) {
-			if (bfcg_trim_batch(tr, b.seq, 0, b.n_pos, off, n, opt->min_frac, st, en) != 0) {
-				fprintf(stderr, "[E::%s] GPU trim pass failed: %s\n", __func__, bfcg_last_error()); abort();
+			if (n_dev == 1) {
+				if (bfcg_trim_batch(tr, b.seq, 0, b.n_pos, off, n, opt->min_frac, st, en) != 0) {
+					fprintf(stderr, "[E::%s] GPU trim pass failed: %s\n", __func__, bfcg_last_error()); abort();
+				}
+			} else { /* reads [n*d/N, n*(d+1)/N) on device d: their part of the stream, offsets rebased to its start */
+				trim_job_t job[64];
+				pthread_t th[64];
+				uint64_t o2 = 0;
+				for (d = 0; d < n_dev; ++d) {
+					const uint64_t r0 = n * (uint64_t)d / (uint64_t)n_dev, r1 = n * (uint64_t)(d + 1) / (uint64_t)n_dev;
+					uint64_t q;
+					job[d].tr = trs[d]; job[d].seq = b.seq + off[r0]; job[d].n_pos = off[r1] - off[r0]; job[d].n = r1 - r0;
+					job[d].off = off2 + o2; job[d].min_frac = opt->min_frac; job[d].st = st + r0; job[d].en = en + r0; job[d].rc = 0;
+					for (q = r0; q <= r1; ++q) off2[o2++] = off[q] - off[r0];
+					pthread_create(&th[d], 0, trim_worker, &job[d]);
+				}
+				for (d = 0; d < n_dev; ++d) {
+					pthread_join(th[d], 0);
+					if (job[d].rc != 0) { fprintf(stderr, "[E::%s] GPU trim pass failed on device %d: %s\n", __func__, devs[d], bfcg_last_error()); abort(); }
+				}
 			}
 			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_ec_cb", t_real() - t0, 100. * t_cpu() / (t_real() - t0 + 1e-6), (int)n);
 			for (r = 0; r < n; ++r) { /* correct.c:595-611 */
@@ -123,7 +164,8 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 		}
 		if (last) break;
 	}
-	bfcg_trim_destroy(tr);
+	for (d = 0; d < n_dev; ++d) bfcg_trim_destroy(trs[d]);
+	free(off2);
 	gzclose(ps.rd.fp);
 	free(ps.rd.buf); free(ps.rd.line); free(ps.seq); free(ps.qual); free(ps.hdr); free(ps.cmt);
 	bfcg_host_free(b.seq); free(b.qual); free(b.kind_cut); free(off); free(st); free(en); free(ri); free(hdrs);

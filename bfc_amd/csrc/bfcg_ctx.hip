@@ -67,6 +67,7 @@ struct bfcg_ctx {
 };
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
+extern "C" void bfcg_set_error(const char *msg) { set_err("%s", msg); } // bfcg_mg.hip reports through the same channel
 
 extern "C" void bfcg_params_default(bfcg_params_t *p)
 {
@@ -566,7 +567,10 @@ extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_
 // Stage B is ENQUEUED (stream st) and left running: the call returns once the PREVIOUS batch is finalised (statistics read,
 // table maintained), so the caller's next bfcg_mg_scatter and exchange overlap with it.  d_recv must stay untouched until the
 // next bfcg_mg_process (or bfcg_sync) returns: callers alternate between two receive buffers.
-extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt)
+extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
+extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt) { return bfcg_mg_process_ev(c, d_recv, seg_cnt, 0, 0); }
+// the same with stage B ordered behind `wait[0..n_wait)` (events of the exchange that fills d_recv, on other streams / devices): no host wait
+extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait)
 {
 	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, n_seg = nb_loc * N, b = c->cur;
 	HIPCK(hipSetDevice(c->prm.device));
@@ -588,6 +592,7 @@ extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t
 	}
 	bucket_start[nb_loc] = (uint32_t)tot;
 	uint32_t *d = c->d_seg + (size_t)b * c->seg_words;
+	for (int i = 0; i < n_wait; ++i) HIPCK(hipStreamWaitEvent(c->st, wait[i], 0));
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
 	HIPCK(hipMemcpyAsync(d, seg_beg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
@@ -836,25 +841,41 @@ extern "C" bfc_bf_t *bfcg_export_bloom(bfcg_ctx_t *c, int which)
 // which bfcg_trim_create adopts instead of uploading 2^(b-3) bytes again.  The copy is dropped when the host object is destroyed or
 // written to through this library (bfc_bf_destroy / bfc_bf_insert call bfcg_resident_drop).
 struct resident_t { const void *bf; void *dev; int device, n_shift; };
-static resident_t g_res[8];
+static resident_t g_res[16];
 static std::atomic<int> g_res_n{0};
 static std::mutex g_res_mu;
 
 extern "C" void bfcg_resident_drop(const void *bf)
 {
 	if (g_res_n.load(std::memory_order_relaxed) == 0) return;
-	void *dev = 0; int device = 0;
-	{
-		std::lock_guard<std::mutex> lk(g_res_mu);
-		for (int i = 0; i < 8; ++i) if (g_res[i].dev && g_res[i].bf == bf) { dev = g_res[i].dev; device = g_res[i].device; g_res[i].dev = 0; g_res_n.fetch_sub(1); break; }
+	for (;;) { // a filter counted on several GPUs has a copy on each of them
+		void *dev = 0; int device = 0;
+		{
+			std::lock_guard<std::mutex> lk(g_res_mu);
+			for (int i = 0; i < 16; ++i) if (g_res[i].dev && g_res[i].bf == bf) { dev = g_res[i].dev; device = g_res[i].device; g_res[i].dev = 0; g_res_n.fetch_sub(1); break; }
+		}
+		if (!dev) return;
+		int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(device); (void)hipFree(dev); (void)hipSetDevice(cur);
 	}
-	if (dev) { int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(device); (void)hipFree(dev); (void)hipSetDevice(cur); }
+}
+// a full copy of host filter `bf` that sits at `dev` on `device` (bfcg_mg.hip: gathered from the ranks' slices); 0, or -1 if the registry is full
+extern "C" int bfcg_resident_register(const void *bf, void *dev, int device, int n_shift)
+{
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	for (int i = 0; i < 16; ++i) if (!g_res[i].dev) { g_res[i] = resident_t{bf, dev, device, n_shift}; g_res_n.fetch_add(1); return 0; }
+	return -1;
+}
+// the slice of filter `which` this context owns, in place (device memory), and its size in bytes
+extern "C" void *bfcg_bloom_slice(bfcg_ctx_t *c, int which, uint64_t *bytes)
+{
+	if (bytes) *bytes = c->bloom_bytes;
+	return which ? (void *)c->B.bloom_hi : (void *)c->B.bloom;
 }
 static void *resident_take(const bfc_bf_t *bf, int device)
 {
 	if (g_res_n.load(std::memory_order_relaxed) == 0) return 0;
 	std::lock_guard<std::mutex> lk(g_res_mu);
-	for (int i = 0; i < 8; ++i)
+	for (int i = 0; i < 16; ++i)
 		if (g_res[i].dev && g_res[i].bf == (const void *)bf && g_res[i].device == device && g_res[i].n_shift == bf->n_shift) {
 			void *dev = g_res[i].dev; g_res[i].dev = 0; g_res_n.fetch_sub(1); return dev;
 		}
@@ -870,7 +891,7 @@ extern "C" bfc_bf_t *bfcg_export_bloom_resident(bfcg_ctx_t *c, int which)
 	if (hipMemcpyAsync(dev, which ? c->B.bloom_hi : c->B.bloom, c->bloom_bytes, hipMemcpyDeviceToDevice, c->st) != hipSuccess ||
 	    hipStreamSynchronize(c->st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return b; }
 	std::lock_guard<std::mutex> lk(g_res_mu);
-	for (int i = 0; i < 8; ++i) if (!g_res[i].dev) { g_res[i] = resident_t{b, dev, c->prm.device, c->P.bf_shift}; g_res_n.fetch_add(1); return b; }
+	for (int i = 0; i < 16; ++i) if (!g_res[i].dev) { g_res[i] = resident_t{b, dev, c->prm.device, c->P.bf_shift}; g_res_n.fetch_add(1); return b; }
 	(void)hipFree(dev); // registry full
 	return b;
 }

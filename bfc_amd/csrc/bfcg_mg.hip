@@ -1,0 +1,450 @@
+// bfcg_mg.hip -- multi-GPU counting in C (include/bfc_gpu.h, PART 2: bfcg_group_*): the owner-computes partition of DESIGN.md section 5
+// driven from inside the library, so that bfc_count() itself fans a file out over the GPUs of a node (the reference fans reads out over
+// threads inside bfc_count: count.c:106 kt_for, count.c:143 kt_pipeline).
+//
+// A *group* owns the LOCAL ranks of a run of n_ranks: all of them in one process (bfc_count with BFC_GPU_DEVICES=0,1,...), or one per
+// process (bench.py under torch.distributed.run; the RCCL unique id travels out of band).  Every local rank has its own device, counting
+// context (bfcg_ctx_t with rank / n_ranks), exchange buffers, exchange stream and host thread.  Per global batch, on every rank:
+//     stage A    K1 + level-1 scatter of the rank's share into its send buffer, grouped by level-1 bucket          (bfcg_mg_scatter)
+//     sizes      every rank learns every rank's bucket sizes: shared memory between local ranks, ncclAllGather between processes
+//     records    bucket b belongs to rank b / nb_loc: grouped ncclSend / ncclRecv, ring-shifted peer order, <= 256 MiB per message
+//                (RCCL over xGMI), or -- local ranks only -- direct peer copies (hipMemcpyPeerAsync, the xGMI DMA path without RCCL)
+//     stage B    level 2 + bloom regions + table on the owner, ordered behind the exchange by events, left running        (bfcg_mg_process)
+// No bitmap reduce and no table merge arithmetic: slices and key sets are disjoint by construction (the union of the ranks' tables IS the
+// reference's table, bfc_ch_union).  File order is rank-major inside a global batch.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <vector>
+#include "bfc_gpu.h"
+#include "bfcg_internal.h"
+#include "bfc_host.h"
+
+extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
+extern "C" void bfcg_set_error(const char *msg);
+extern "C" int bfcg_resident_register(const void *bf, void *dev, int device, int n_shift);
+extern "C" void *bfcg_bloom_slice(bfcg_ctx_t *c, int which, uint64_t *bytes);
+
+namespace {
+
+enum { XP_RCCL = 1, XP_PEER = 2 };
+const uint64_t MSG_BYTES = 256ull << 20; // this image's RCCL truncates single messages above 1 GiB (measured): stay far below
+
+struct rank_t {
+	int rank, device;
+	bfcg_ctx_t *ctx;
+	hipStream_t xs;            // exchange stream
+	hipEvent_t ev_x;           // this rank's part of the exchange is done (its receives with RCCL; its outgoing copies with peer copies)
+	uint8_t *send, *recv[2];
+	uint64_t send_cap, recv_cap; // bytes
+	uint32_t *counts;          // this rank's level-1 bucket sizes of the current batch (host)
+	uint32_t *d_counts;        // multi-process: all ranks' sizes, device side of the all-gather
+	ncclComm_t comm;
+	uint8_t *d_seq, *d_qual; uint64_t in_cap; // staging of host batches
+	// the current batch's share
+	const uint8_t *in_seq, *in_qual; uint64_t in_pos; int in_host;
+	pthread_t th;
+	int rc;
+};
+
+} // namespace
+
+struct bfcg_group {
+	bfcg_params_t prm;
+	int n_ranks, first, n_local, xp, rec_bytes, nb1, nb_loc;
+	int mp;                     // one rank per process: sizes travel by ncclAllGather, records by ncclSend / ncclRecv between the processes
+	uint64_t kmer_limit;        // k-mers of a global batch one rank's regions take at full speed
+	std::vector<rank_t> r;
+	uint32_t *all_counts;       // [n_ranks][nb1], host (pinned): every rank's bucket sizes of the current batch
+	pthread_barrier_t bar;      // local ranks
+	pthread_mutex_t mu; pthread_cond_t cv;
+	uint64_t job, done_job; int n_done, quit, failed, go;
+	uint64_t t;                 // global batches so far
+	char err[512];
+};
+
+static void grp_err(bfcg_group_t *g, const char *fmt, ...)
+{
+	pthread_mutex_lock(&g->mu);
+	if (!g->failed) {
+		va_list ap; va_start(ap, fmt); vsnprintf(g->err, sizeof(g->err), fmt, ap); va_end(ap);
+		g->failed = 1;
+	}
+	pthread_mutex_unlock(&g->mu);
+}
+// a failing call marks the whole group as failed; the rank threads never leave a batch early -- they all walk through the same barriers
+#define GHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) grp_err(g, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define GNCCL(call) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) grp_err(g, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// stage B of one global batch on the owner.  When the rank received more k-mers than its bloom regions take at full speed the sources are
+// processed in consecutive groups, each its own stage B: the receive buffer is source-major and the global order rank-major, so a group's
+// records all precede the next group's -- the result is that of one big batch without every region overflowing its LDS list.  Not with
+// order stamps (the batch number is part of a stamp and must agree across ranks).
+static int process_in_groups(bfcg_group_t *g, rank_t &R, const uint8_t *recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait)
+{
+	const int N = g->n_ranks, nb_loc = g->nb_loc;
+	std::vector<uint64_t> per_src((size_t)N, 0);
+	uint64_t total = 0;
+	for (int s = 0; s < N; ++s) { for (int k = 0; k < nb_loc; ++k) per_src[s] += seg_cnt[(size_t)s * nb_loc + k]; total += per_src[s]; }
+	if (g->prm.track_order || total <= g->kmer_limit || N == 1) return bfcg_mg_process_ev(R.ctx, recv, seg_cnt, wait, n_wait);
+	std::vector<uint32_t> seg((size_t)N * nb_loc);
+	uint64_t off = 0;
+	int s0 = 0, launched = 0;
+	while (s0 < N) {
+		uint64_t acc = per_src[s0]; int s1 = s0 + 1;
+		while (s1 < N && acc + per_src[s1] <= g->kmer_limit) acc += per_src[s1++];
+		if (acc) {
+			memset(seg.data(), 0, seg.size() * sizeof(uint32_t));
+			memcpy(&seg[(size_t)s0 * nb_loc], &seg_cnt[(size_t)s0 * nb_loc], sizeof(uint32_t) * (size_t)(s1 - s0) * nb_loc);
+			if (launched) { // stage A and stage B come in pairs (buffer sets, timing events): an empty stage A opens the next pair
+				std::vector<uint32_t> dummy((size_t)g->nb1);
+				if (bfcg_mg_scatter(R.ctx, 0, 0, 0, 0, dummy.data()) != 0) return -1;
+			}
+			if (bfcg_mg_process_ev(R.ctx, recv + off * (uint64_t)g->rec_bytes, seg.data(), launched ? 0 : wait, launched ? 0 : n_wait) != 0) return -1;
+			++launched;
+		}
+		for (int s = s0; s < s1; ++s) off += per_src[s];
+		s0 = s1;
+	}
+	if (!launched) return bfcg_mg_process_ev(R.ctx, recv, seg_cnt, wait, n_wait);
+	return 0;
+}
+
+// one global batch on local rank i (runs on the rank's own host thread)
+static int rank_batch(bfcg_group_t *g, int i)
+{
+	rank_t &R = g->r[i];
+	const int N = g->n_ranks, nb1 = g->nb1, nb_loc = g->nb_loc, me = R.rank;
+	const uint64_t rb = (uint64_t)g->rec_bytes;
+	int ok = !g->failed;
+	GHIP(hipSetDevice(R.device));
+	// ---- stage A (the send buffer is free: the previous exchange of this rank was waited for below, before stage B was enqueued)
+	if (ok) {
+		const uint8_t *ds = R.in_seq, *dq = R.in_qual;
+		if (R.in_host && R.in_pos) {
+			if (R.in_pos > R.in_cap) { grp_err(g, "share of %llu positions exceeds the staging buffer", (unsigned long long)R.in_pos); ok = 0; }
+			else {
+				GHIP(hipMemcpyAsync(R.d_seq, R.in_seq, R.in_pos, hipMemcpyHostToDevice, R.xs));
+				if (R.in_qual) GHIP(hipMemcpyAsync(R.d_qual, R.in_qual, R.in_pos, hipMemcpyHostToDevice, R.xs));
+				GHIP(hipStreamSynchronize(R.xs));
+				ds = R.d_seq; dq = R.in_qual ? R.d_qual : 0;
+			}
+		}
+		if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, R.send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+	}
+	if (!ok) memset(R.counts, 0, sizeof(uint32_t) * (size_t)nb1);
+	memcpy(g->all_counts + (size_t)me * nb1, R.counts, sizeof(uint32_t) * (size_t)nb1);
+	// ---- every rank's bucket sizes
+	if (g->mp) { // between processes: all-gather over RCCL (the local ranks of a multi-process group are one per process)
+		GHIP(hipMemcpyAsync(R.d_counts + (size_t)me * nb1, R.counts, sizeof(uint32_t) * (size_t)nb1, hipMemcpyHostToDevice, R.xs));
+		GNCCL(ncclAllGather(R.d_counts + (size_t)me * nb1, R.d_counts, (size_t)nb1, ncclUint32, R.comm, R.xs));
+		GHIP(hipMemcpyAsync(g->all_counts, R.d_counts, sizeof(uint32_t) * (size_t)N * nb1, hipMemcpyDeviceToHost, R.xs));
+		GHIP(hipStreamSynchronize(R.xs));
+	}
+	pthread_barrier_wait(&g->bar); // all local ranks have published their sizes
+	if (i == 0) g->go = !g->failed; // one decision for all local ranks: a group that failed so far skips the exchange on every rank
+	pthread_barrier_wait(&g->bar);
+	const uint32_t *C = g->all_counts;
+	// what I send to rank p: my buckets [p*nb_loc, (p+1)*nb_loc); what I get from rank p: its buckets [me*nb_loc, ...), stored source-major
+	std::vector<uint64_t> s_off((size_t)N + 1, 0), r_off((size_t)N + 1, 0);
+	for (int p = 0; p < N; ++p) {
+		uint64_t s = 0, q = 0;
+		for (int k = 0; k < nb_loc; ++k) { s += C[(size_t)me * nb1 + (size_t)p * nb_loc + k]; q += C[(size_t)p * nb1 + (size_t)me * nb_loc + k]; }
+		s_off[p + 1] = s_off[p] + s; r_off[p + 1] = r_off[p] + q;
+	}
+	uint8_t *recv = R.recv[g->t & 1];
+	ok = g->go;
+	// every rank can compute every rank's receive size: an overflow anywhere stops the exchange everywhere
+	for (int p = 0; p < N && ok; ++p) {
+		uint64_t q = 0;
+		for (int s2 = 0; s2 < N; ++s2) for (int k = 0; k < nb_loc; ++k) q += C[(size_t)s2 * nb1 + (size_t)p * nb_loc + k];
+		if (q * rb > R.recv_cap) { grp_err(g, "rank %d receives %llu records of one global batch, its buffer holds %llu: smaller shares or a larger filter", p, (unsigned long long)q, (unsigned long long)(R.recv_cap / rb)); ok = 0; }
+	}
+	// ---- records
+	if (g->xp == XP_RCCL) {
+		if (ok) {
+			if (s_off[me + 1] > s_off[me]) GHIP(hipMemcpyAsync(recv + r_off[me] * rb, R.send + s_off[me] * rb, (s_off[me + 1] - s_off[me]) * rb, hipMemcpyDeviceToDevice, R.xs));
+			if (N > 1) GNCCL(ncclGroupStart());
+			for (int step = 1; step < N; ++step) { // ring-shifted peer order: every rank talks to a different peer at any time
+				const int to = (me + step) % N, from = (me - step + N) % N;
+				const uint64_t n_to = (s_off[to + 1] - s_off[to]) * rb, n_from = (r_off[from + 1] - r_off[from]) * rb;
+				for (uint64_t c0 = 0; c0 < (n_to > n_from ? n_to : n_from); c0 += MSG_BYTES) {
+					if (c0 < n_to) GNCCL(ncclSend(R.send + s_off[to] * rb + c0, (size_t)(n_to - c0 < MSG_BYTES ? n_to - c0 : MSG_BYTES), ncclUint8, to, R.comm, R.xs));
+					if (c0 < n_from) GNCCL(ncclRecv(recv + r_off[from] * rb + c0, (size_t)(n_from - c0 < MSG_BYTES ? n_from - c0 : MSG_BYTES), ncclUint8, from, R.comm, R.xs));
+				}
+			}
+			if (N > 1) GNCCL(ncclGroupEnd());
+			GHIP(hipEventRecord(R.ev_x, R.xs));
+		}
+	} else { // peer copies: I push my records into every owner's receive buffer (all ranks are local)
+		if (ok) {
+			for (int step = 0; step < N; ++step) {
+				const int to = (me + step) % N;
+				const rank_t &T = g->r[to - g->first];
+				const uint64_t n_to = (s_off[to + 1] - s_off[to]) * rb;
+				// my block in `to`'s buffer starts behind the blocks of the sources before me
+				uint64_t at = 0;
+				for (int p = 0; p < me; ++p) for (int k = 0; k < nb_loc; ++k) at += C[(size_t)p * nb1 + (size_t)to * nb_loc + k];
+				if (n_to) GHIP(hipMemcpyPeerAsync(T.recv[g->t & 1] + at * rb, T.device, R.send + s_off[to] * rb, R.device, n_to, R.xs));
+			}
+			GHIP(hipEventRecord(R.ev_x, R.xs));
+		}
+		pthread_barrier_wait(&g->bar); // every sender's event is recorded: the owners may wait for them
+	}
+	// ---- stage B behind the exchange
+	if (ok && !g->failed) {
+		std::vector<uint32_t> seg((size_t)N * nb_loc);
+		for (int s = 0; s < N; ++s) memcpy(&seg[(size_t)s * nb_loc], &C[(size_t)s * nb1 + (size_t)me * nb_loc], sizeof(uint32_t) * (size_t)nb_loc);
+		std::vector<hipEvent_t> ev;
+		if (g->xp == XP_RCCL) ev.push_back(R.ev_x);
+		else for (int j = 0; j < g->n_local; ++j) ev.push_back(g->r[j].ev_x);
+		if (process_in_groups(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+	}
+	// the send buffer and (with peer copies) the other ranks' reads of all_counts: the next batch may start when my exchange has drained
+	(void)hipStreamSynchronize(R.xs);
+	pthread_barrier_wait(&g->bar);
+	return g->failed ? -1 : 0;
+}
+
+static void *rank_main(void *arg)
+{
+	bfcg_group_t *g = (bfcg_group_t *)((void **)arg)[0];
+	const int i = (int)(intptr_t)((void **)arg)[1];
+	free(arg);
+	uint64_t seen = 0;
+	for (;;) {
+		pthread_mutex_lock(&g->mu);
+		while (g->job == seen && !g->quit) pthread_cond_wait(&g->cv, &g->mu);
+		if (g->quit) { pthread_mutex_unlock(&g->mu); return 0; }
+		seen = g->job;
+		pthread_mutex_unlock(&g->mu);
+		g->r[i].rc = rank_batch(g, i);
+		pthread_mutex_lock(&g->mu);
+		if (++g->n_done == g->n_local) { g->done_job = seen; pthread_cond_broadcast(&g->cv); }
+		pthread_mutex_unlock(&g->mu);
+	}
+}
+
+static int run_job(bfcg_group_t *g)
+{
+	pthread_mutex_lock(&g->mu);
+	g->n_done = 0; ++g->job;
+	pthread_cond_broadcast(&g->cv);
+	while (g->done_job != g->job) pthread_cond_wait(&g->cv, &g->mu);
+	pthread_mutex_unlock(&g->mu);
+	++g->t;
+	if (g->failed) { bfcg_set_error(g->err); return -1; }
+	return 0;
+}
+
+extern "C" int bfcg_group_unique_id(uint8_t uid[BFCG_UID_BYTES])
+{
+	ncclUniqueId id;
+	if (ncclGetUniqueId(&id) != ncclSuccess) { bfcg_set_error("ncclGetUniqueId failed"); return -1; }
+	memcpy(uid, &id, BFCG_UID_BYTES);
+	return 0;
+}
+
+extern "C" void bfcg_group_destroy(bfcg_group_t *g)
+{
+	if (!g) return;
+	pthread_mutex_lock(&g->mu); g->quit = 1; pthread_cond_broadcast(&g->cv); pthread_mutex_unlock(&g->mu);
+	for (auto &R : g->r) if (R.th) pthread_join(R.th, 0);
+	for (auto &R : g->r) {
+		(void)hipSetDevice(R.device);
+		if (R.ctx) (void)bfcg_sync(R.ctx);
+		if (R.comm) (void)ncclCommDestroy(R.comm);
+		(void)hipFree(R.send); (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
+		if (R.ev_x) (void)hipEventDestroy(R.ev_x);
+		if (R.xs) (void)hipStreamDestroy(R.xs);
+		free(R.counts);
+		if (R.ctx) bfcg_destroy(R.ctx);
+	}
+	if (g->all_counts) (void)hipHostFree(g->all_counts);
+	pthread_barrier_destroy(&g->bar); pthread_mutex_destroy(&g->mu); pthread_cond_destroy(&g->cv);
+	delete g;
+}
+
+extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks, int first_rank, int n_local, const int *devices, const uint8_t *uid, int transport)
+{
+	if (n_ranks < 1 || n_local < 1 || first_rank < 0 || first_rank + n_local > n_ranks || (n_local < n_ranks && n_local != 1) || (n_local < n_ranks && !uid) || (uid && n_local != 1)) {
+		bfcg_set_error("bfcg_group_create: the local ranks are either all n_ranks of the run, or one per process with the RCCL unique id of the run"); return NULL;
+	}
+	bfcg_group_t *g = new bfcg_group();
+	g->prm = *prm; g->n_ranks = n_ranks; g->first = first_rank; g->n_local = n_local;
+	g->job = g->done_job = 0; g->n_done = 0; g->quit = 0; g->failed = 0; g->t = 0; g->err[0] = 0; g->all_counts = 0;
+	pthread_barrier_init(&g->bar, 0, (unsigned)n_local); pthread_mutex_init(&g->mu, 0); pthread_cond_init(&g->cv, 0);
+	g->mp = uid != NULL;
+	g->xp = transport ? transport : XP_RCCL;
+	if (g->mp) g->xp = XP_RCCL;
+	if (n_local == n_ranks && g->xp == XP_RCCL) // RCCL refuses two ranks on one device: repeated devices (emulation on a single GPU) take the peer-copy path
+		for (int i = 0; i < n_local; ++i) for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) g->xp = XP_PEER;
+	if (g->xp == XP_PEER && n_local < n_ranks) { bfcg_set_error("peer copies need every rank in this process"); bfcg_group_destroy(g); return NULL; }
+	g->r.resize((size_t)n_local);
+	for (auto &R : g->r) memset(&R, 0, sizeof(R));
+	for (int i = 0; i < n_local; ++i) {
+		rank_t &R = g->r[i];
+		R.rank = first_rank + i; R.device = devices[i];
+		bfcg_params_t p = *prm;
+		p.device = R.device; p.rank = R.rank; p.n_ranks = n_ranks;
+		R.ctx = bfcg_create(&p);
+		if (!R.ctx) { bfcg_group_destroy(g); return NULL; }
+	}
+	{
+		int info[4];
+		bfcg_mg_info(g->r[0].ctx, info);
+		g->nb1 = info[0]; g->nb_loc = info[1]; g->rec_bytes = info[2];
+		g->kmer_limit = (uint64_t)((double)bfcg_batch_limit(g->r[0].ctx) / 0.95);
+	}
+	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * g->nb1, hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
+	const uint64_t cap = prm->max_batch_pos, rcap = n_ranks > 1 ? cap + cap / 4 + (1u << 20) : cap; // = the contexts' level-2 capacity
+	std::vector<ncclComm_t> comms((size_t)n_local, (ncclComm_t)0);
+	if (g->xp == XP_RCCL && !g->mp && n_ranks > 1) {
+		if (ncclCommInitAll(comms.data(), n_local, devices) != ncclSuccess) { bfcg_set_error("ncclCommInitAll failed"); bfcg_group_destroy(g); return NULL; }
+	}
+	for (int i = 0; i < n_local; ++i) {
+		rank_t &R = g->r[i];
+		hipError_t e = hipSetDevice(R.device);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&R.xs, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_x, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipMalloc(&R.send, R.send_cap = cap * (uint64_t)g->rec_bytes);
+		R.recv_cap = rcap * (uint64_t)g->rec_bytes;
+		if (e == hipSuccess) e = hipMalloc(&R.recv[0], R.recv_cap);
+		if (e == hipSuccess) e = hipMalloc(&R.recv[1], R.recv_cap);
+		if (e == hipSuccess) e = hipMalloc(&R.d_counts, sizeof(uint32_t) * (size_t)n_ranks * g->nb1);
+		R.in_cap = cap;
+		if (e == hipSuccess) e = hipMalloc(&R.d_seq, cap);
+		if (e == hipSuccess) e = hipMalloc(&R.d_qual, cap);
+		R.counts = (uint32_t *)calloc((size_t)g->nb1, sizeof(uint32_t));
+		if (e != hipSuccess) { bfcg_set_error(hipGetErrorString(e)); bfcg_group_destroy(g); return NULL; }
+		if (g->xp == XP_PEER) for (int j = 0; j < n_local; ++j) if (devices[j] != R.device) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+		if (g->xp == XP_RCCL && (n_ranks > 1 || g->mp)) {
+			if (!g->mp) R.comm = comms[i];
+			else {
+				ncclUniqueId id; memcpy(&id, uid, BFCG_UID_BYTES);
+				if (ncclCommInitRank(&R.comm, n_ranks, id, R.rank) != ncclSuccess) { bfcg_set_error("ncclCommInitRank failed"); bfcg_group_destroy(g); return NULL; }
+			}
+		}
+	}
+	(void)hipGetLastError(); // hipDeviceEnablePeerAccess on an already enabled pair
+	for (int i = 0; i < n_local; ++i) {
+		void **arg = (void **)malloc(2 * sizeof(void *));
+		arg[0] = g; arg[1] = (void *)(intptr_t)i;
+		if (pthread_create(&g->r[i].th, 0, rank_main, arg) != 0) { g->r[i].th = 0; free(arg); bfcg_set_error("pthread_create failed"); bfcg_group_destroy(g); return NULL; }
+	}
+	return g;
+}
+
+extern "C" int bfcg_group_info(bfcg_group_t *g, int out[6])
+{
+	out[0] = g->n_ranks; out[1] = g->n_local; out[2] = g->xp; out[3] = g->rec_bytes; out[4] = g->nb1; out[5] = g->first;
+	return 0;
+}
+extern "C" bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i) { return i >= 0 && i < g->n_local ? g->r[i].ctx : NULL; }
+
+extern "C" int bfcg_group_reset(bfcg_group_t *g)
+{
+	for (auto &R : g->r) if (bfcg_reset(R.ctx) != 0) return -1;
+	return 0;
+}
+extern "C" int bfcg_group_sync(bfcg_group_t *g)
+{
+	for (auto &R : g->r) if (bfcg_sync(R.ctx) != 0) return -1;
+	return 0;
+}
+
+extern "C" int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos)
+{
+	for (int i = 0; i < g->n_local; ++i) { g->r[i].in_seq = d_seq[i]; g->r[i].in_qual = d_qual ? d_qual[i] : 0; g->r[i].in_pos = n_pos[i]; g->r[i].in_host = 0; }
+	return run_job(g);
+}
+
+static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
+
+// One global batch from host memory (all ranks local): the stream is cut into n_ranks contiguous shares at separator bytes (no k-mer spans
+// one) -- rank r takes the r-th share, which is the rank-major file order the exchange assumes.
+extern "C" int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)
+{
+	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_count_batch_host needs every rank in this process"); return -1; }
+	const int N = g->n_ranks;
+	uint64_t o = 0;
+	for (int i = 0; i < N; ++i) {
+		uint64_t e = i + 1 == N ? n_pos : n_pos * (uint64_t)(i + 1) / (uint64_t)N;
+		if (e < o) e = o;
+		while (e < n_pos && e > o && is_acgt(h_seq[e - 1])) ++e; // forward to just behind the next byte that ends a k-mer
+		if (i + 1 == N) e = n_pos;
+		g->r[i].in_seq = h_seq + o; g->r[i].in_qual = h_qual ? h_qual + o : 0; g->r[i].in_pos = e - o; g->r[i].in_host = 1;
+		o = e;
+	}
+	return run_job(g);
+}
+
+// sums over the local ranks (a multi-process caller adds the processes' sums up); table geometry of rank `first`
+extern "C" int bfcg_group_stats(bfcg_group_t *g, uint64_t out[BFCG_ST_N])
+{
+	memset(out, 0, sizeof(uint64_t) * BFCG_ST_N);
+	for (auto &R : g->r) {
+		uint64_t st[BFCG_ST_N];
+		if (bfcg_stats(R.ctx, st) != 0) return -1;
+		for (int i = 0; i < BFCG_ST_N; ++i) if (i != BFCG_ST_TAB_CSHIFT && i != BFCG_ST_BATCHES) out[i] += st[i];
+		out[BFCG_ST_TAB_CSHIFT] = st[BFCG_ST_TAB_CSHIFT]; out[BFCG_ST_BATCHES] = st[BFCG_ST_BATCHES];
+	}
+	return 0;
+}
+
+// THE count table of the run (all ranks local): the union of the ranks' disjoint tables
+extern "C" bfc_ch_t *bfcg_group_export_table(bfcg_group_t *g)
+{
+	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_export_table needs every rank in this process (else: export per rank, bfc_ch_union)"); return NULL; }
+	std::vector<bfc_ch_t *> t;
+	bfc_ch_t *u = 0;
+	for (auto &R : g->r) { bfc_ch_t *x = bfcg_export_table(R.ctx); if (!x) break; t.push_back(x); }
+	if ((int)t.size() == g->n_local) u = g->n_local == 1 ? t[0] : bfc_ch_union((const bfc_ch_t *const *)t.data(), g->n_local);
+	if (!u) bfcg_set_error("union of the ranks' tables failed");
+	if (g->n_local > 1 || !u) for (auto x : t) bfc_ch_destroy(x);
+	return u;
+}
+
+// THE bloom filter of the run (all ranks local): rank r owns the r-th 1/n_ranks of the bitmap
+extern "C" bfc_bf_t *bfcg_group_export_bloom(bfcg_group_t *g, int which)
+{
+	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_export_bloom needs every rank in this process"); return NULL; }
+	bfc_bf_t *b = bfc_bf_alloc_raw(g->prm.bf_shift, g->prm.n_hashes);
+	if (!b) { bfcg_set_error("host allocation of the bloom filter failed"); return NULL; }
+	const uint64_t slice = (1ULL << (g->prm.bf_shift - 3)) / (uint64_t)g->n_ranks;
+	for (int i = 0; i < g->n_local; ++i)
+		if (bfcg_bloom_to_host(g->r[i].ctx, which, b->b + (uint64_t)i * slice) != 0) { bfc_bf_destroy(b); return NULL; }
+	return b;
+}
+
+// The same, and every local device keeps a FULL copy of the filter in HBM behind the returned host object, all-gathered from the ranks'
+// slices by peer copies over xGMI: `bfc -1` queries bf_high for every k-mer of every read next (correct.c:556), and the trim pass shards
+// the reads over the same devices (bfc_trim.c) -- each of its contexts adopts the copy on its device instead of uploading 2^(b-3) bytes.
+extern "C" bfc_bf_t *bfcg_group_export_bloom_resident(bfcg_group_t *g, int which)
+{
+	bfc_bf_t *b = bfcg_group_export_bloom(g, which);
+	if (!b) return NULL;
+	const uint64_t full = 1ULL << (g->prm.bf_shift - 3);
+	for (int i = 0; i < g->n_local; ++i) {
+		const int dev = g->r[i].device;
+		int dup = 0;
+		for (int j = 0; j < i; ++j) if (g->r[j].device == dev) dup = 1;
+		if (dup) continue;
+		void *d = 0;
+		if (hipSetDevice(dev) != hipSuccess || hipMalloc(&d, full) != hipSuccess) { (void)hipGetLastError(); continue; } // no room here: the host copy is a complete answer
+		hipError_t e = hipSuccess;
+		for (int j = 0; j < g->n_local && e == hipSuccess; ++j) {
+			uint64_t bytes = 0;
+			void *src = bfcg_bloom_slice(g->r[j].ctx, which, &bytes);
+			e = hipMemcpyPeerAsync((char *)d + (uint64_t)j * bytes, dev, src, g->r[j].device, bytes, g->r[i].xs);
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(g->r[i].xs);
+		if (e != hipSuccess || bfcg_resident_register(b, d, dev, g->prm.bf_shift) != 0) { (void)hipGetLastError(); (void)hipFree(d); }
+	}
+	return b;
+}

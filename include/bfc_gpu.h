@@ -135,6 +135,38 @@ uint64_t bfcg_batch_limit(bfcg_ctx_t *c);
 int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts);
 int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt);
 
+enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS, BFCG_ST_CROWDED,
+       BFCG_ST_TAB_CSHIFT = 8, BFCG_ST_BATCHES, BFCG_ST_N = 16 };
+
+/* Multi-GPU in C.  A GROUP drives the local ranks of an owner-computes run of n_ranks GPUs from inside the library -- stage A, the
+ * exchange of the k-mer records (grouped ncclSend / ncclRecv over RCCL, or direct peer copies between the devices of one process) and
+ * stage B, one host thread per local rank, no Python and no torch in the data path.  Either every rank is local (one process, n_ranks
+ * devices: what bfc_count does with BFC_GPU_DEVICES=0,1,...; a device may be named several times to emulate ranks on one GPU), or
+ * exactly one is (one process per GPU, as torch.distributed.run launches bench.py): then `uid` is the run's RCCL unique id, made by
+ * bfcg_group_unique_id on one process and handed to the others out of band.  `prm` as for bfcg_create (device / rank / n_ranks are set
+ * per rank; max_batch_pos = positions of ONE RANK's share of a global batch).  transport: 0 auto, 1 RCCL, 2 peer copies.
+ * A global batch is the ranks' shares in rank order (rank-major file order): results are those of `bfc -t1` on that order.
+ * reference: count.c:106 (kt_for over reads), count.c:143 (kt_pipeline) -- the fan-out lives inside bfc_count. */
+typedef struct bfcg_group bfcg_group_t;
+#define BFCG_UID_BYTES 128
+int bfcg_group_unique_id(uint8_t uid[BFCG_UID_BYTES]);
+bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks, int first_rank, int n_local, const int *devices, const uint8_t *uid, int transport);
+void bfcg_group_destroy(bfcg_group_t *g);
+int bfcg_group_info(bfcg_group_t *g, int out[6]);     /* n_ranks, n_local, transport in use (1 RCCL, 2 peer copies), bytes per record, 2^F1, first rank */
+bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i);  /* local rank i's context (statistics, exports of its slice); owned by the group */
+int bfcg_group_reset(bfcg_group_t *g);
+/* one global batch: local rank i contributes the stream d_seq[i] / d_qual[i] (on ITS device) of n_pos[i] positions (0 = nothing) */
+int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos);
+/* one global batch from host memory, cut by the library into n_ranks contiguous shares at read boundaries (all ranks local) */
+int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos);
+int bfcg_group_sync(bfcg_group_t *g);
+int bfcg_group_stats(bfcg_group_t *g, uint64_t out[BFCG_ST_N]);   /* sums over the local ranks */
+bfc_ch_t *bfcg_group_export_table(bfcg_group_t *g);              /* all ranks local: THE table (union of the ranks' disjoint tables) */
+bfc_bf_t *bfcg_group_export_bloom(bfcg_group_t *g, int which);   /* all ranks local: THE filter (the ranks' slices in rank order) */
+/* the same, and every local device keeps a full copy of the filter in HBM (all-gathered from the slices by peer copies) for the sharded
+ * trim pass of `bfc -1` to adopt (bfcg_trim_create on that device), until bfc_bf_destroy */
+bfc_bf_t *bfcg_group_export_bloom_resident(bfcg_group_t *g, int which);
+
 /* device memory helpers so that callers (bench.py) can stage inputs without another runtime */
 void *bfcg_dev_alloc(bfcg_ctx_t *c, uint64_t bytes);
 void  bfcg_dev_free(bfcg_ctx_t *c, void *p);
@@ -143,8 +175,6 @@ int   bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes);
 void *bfcg_host_alloc(uint64_t bytes);   /* pinned host memory */
 void  bfcg_host_free(void *p);
 
-enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS, BFCG_ST_CROWDED,
-       BFCG_ST_TAB_CSHIFT = 8, BFCG_ST_BATCHES, BFCG_ST_N = 16 };
 int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
 /* how the count table is held right now: out[0] 1 = region-owned segments, 0 = the host's layout; out[1] log2 slots per segment;
  * out[2] log2 slots per sub-table; out[3] segment growths so far */

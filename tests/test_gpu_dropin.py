@@ -372,3 +372,24 @@ def test_dropin_with_the_largest_filter(g1_fq, tmp_path):
     import re
     m = re.search(rb"buffers for (\d+) positions per batch", g.stderr)
     assert m and int(m.group(1)) < 4 * os.path.getsize(g1_fq)
+
+
+@needs_dropin
+@pytest.mark.usefixtures("gputrim_bin")
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_dropin_on_several_gpus(g1_fq, tmp_path, devices):
+    """BFC_GPU_DEVICES: bfc_count itself spreads the file over the GPUs (bfcg_group_*: stage A, exchange, stage B in C) and the trim
+    pass of `bfc -1` shards every batch's reads over them; ranks emulated on the one device here.  The reference's unmodified main()
+    writes the reference's bytes: byte-identical dump with order stamps, corrected reads, trimmed reads."""
+    env = dict(os.environ, BFC_GPU_DEVICES=devices, BFC_GPU_EXACT_DUMP="1")
+    dump = str(tmp_path / "g1.hash")
+    r = subprocess.run([DROPIN, "-E", "-k", "31", "-b", "26", "-L", "300000", "-d", dump, g1_fq], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert oracle.md5_file(dump) == "d686549d10dd4c71243269013119784a"            # SURVEY B.3: `bfc -t1 -E -d`
+    env.pop("BFC_GPU_EXACT_DUMP")
+    r = subprocess.run([GPUTRIM, "-k", "31", "-b", "26", "-t", "4", g1_fq], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == "06a4284e5010e34a1645d1d8015d6da9"   # full pipeline
+    for extra in ([], ["-L", "200000"]):
+        r = subprocess.run([GPUTRIM, "-1", "-k", "51", "-b", "26", "-t", "2"] + extra + [g1_fq], capture_output=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        assert hashlib.md5(r.stdout).hexdigest() == "f751f7b1aa28fd74b23194bc7f70158c"                     # `bfc -1`

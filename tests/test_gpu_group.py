@@ -1,0 +1,132 @@
+"""GPU tests (-m gpu) of the multi-GPU path IN C (bfcg_group_*, bfc_amd/csrc/bfcg_mg.hip): stage A, the exchange and stage B driven by
+the library's own rank threads.  Only one GPU is here, so the ranks of a group are emulated on device 0 (a device may be named several
+times; RCCL refuses that, the records then travel by peer copies through the very same bookkeeping), and the RCCL calls are exercised
+with a one-rank run that is set up like one process of a multi-process run (unique id, ncclCommInitRank, ncclAllGather of the sizes).
+The bar is the usual one: bloom bitmap, statistics and table bit for bit the sequential oracle's for the batches in rank-major order."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from bfc_amd import gen
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(k, b, seq, qual, off, **kw):
+    oc = oracle.Counter(k, b, **kw)
+    oc.count(seq, qual, off)
+    return oc
+
+
+def _compare(grp, oc, fm=0):
+    st, ost = grp.stats(), oc.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"]), (st, ost)
+    bf = grp.export_bloom(0)
+    assert np.array_equal(bf.bytes(), oc.bloom_bytes()), "first filter differs (L0)"
+    bf.close()
+    if fm:
+        bf = grp.export_bloom(1)
+        assert np.array_equal(bf.bytes(), oc.bloom_bytes(True)), "second filter differs"
+        bf.close()
+    else:
+        t = grp.export_table()
+        sizes, slots = t.export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl), "table differs (L1)"
+        assert t.count() == st["n_keys"]
+        t.close()
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 4, 8])
+@pytest.mark.parametrize("k,b,fm", [(31, 26, 0), (33, 24, 0), (51, 25, 1)])
+def test_group_host_batches(gpu_lib, g1, n_ranks, k, b, fm):
+    """bfcg_group_count_batch_host: the library cuts every global batch into the ranks' shares; 3 global batches of fixture g1."""
+    rs, (seq, qual, off) = g1
+    oc = _oracle(k, b, seq, qual, off, filter_mode=fm)
+    n = rs.n_reads
+    grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=(n // 3 + 2) * (rs.L + 1) // n_ranks + 4096, filter_mode=fm)
+    assert grp.info()["transport"] == ("peer" if n_ranks > 1 else "rccl")
+    for a in range(0, n, n // 3 + 1):
+        e = min(n, a + n // 3 + 1)
+        grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
+    _compare(grp, oc, fm)
+    grp.close(); oc.close()
+
+
+def test_group_device_shares_uneven(gpu_lib, g1):
+    """bfcg_group_count_batch_dev with ragged shares, a rank that contributes nothing, FASTA (no qualities) and a second pass after reset"""
+    rs, (seq, qual, off) = g1
+    k, b, N = 27, 25, 4
+    n = rs.n_reads
+    grp = gpu_lib.GpuGroup(k, b, [0] * N, max_batch_pos=n * (rs.L + 1) + 64)
+    ctx = [grp.ctx(i) for i in range(N)]
+    for rep in range(2):
+        oc = _oracle(k, b, seq, None, off)
+        cuts = [0, n // 7, n // 7, n // 2, n]  # rank 1 gets nothing
+        ptrs, lens = [], []
+        for i in range(N):
+            s = gen.to_stream(seq[cuts[i] * rs.L:cuts[i + 1] * rs.L], rs.L, 10)
+            d = ctx[i].dev_alloc(max(len(s), 16))
+            if len(s):
+                ctx[i].h2d(d, s)
+            ptrs.append(d); lens.append(len(s))
+        grp.count_dev(ptrs, None, lens)
+        grp.sync()
+        _compare(grp, oc)
+        for i in range(N):
+            ctx[i].dev_free(ptrs[i])
+        oc.close()
+        grp.reset()
+    grp.close()
+
+
+def test_group_rccl_single_rank_as_one_process_of_many(gpu_lib, g1):
+    """The multi-process set-up with a world of one: unique id -> ncclCommInitRank, the sizes through ncclAllGather, stage B behind the
+    exchange stream's event.  (ncclSend / ncclRecv need a second device: the driver's multi-GPU bench is their first run.)"""
+    rs, (seq, qual, off) = g1
+    k, b = 31, 26
+    oc = _oracle(k, b, seq, qual, off)
+    uid = gpu_lib.GpuGroup.unique_id()
+    assert len(uid) == 128 and any(uid)
+    grp = gpu_lib.GpuGroup(k, b, [0], max_batch_pos=rs.n_reads * (rs.L + 1) + 64, n_ranks=1, first_rank=0, uid=uid)
+    assert grp.info()["transport"] == "rccl"
+    c = grp.ctx(0)
+    s, q = gen.to_stream(seq, rs.L, 10), gen.to_stream(qual, rs.L, 33)
+    ds, dq = c.dev_alloc(len(s)), c.dev_alloc(len(q))
+    c.h2d(ds, s); c.h2d(dq, q)
+    half = (rs.n_reads // 2) * (rs.L + 1)
+    grp.count_dev([ds], [dq], [half])
+    grp.count_dev([ds + half], [dq + half], [len(s) - half])
+    st, ost = grp.stats(), oc.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert np.array_equal(c.bloom_bytes(), oc.bloom_bytes())
+    t = c.export_table()
+    sizes, slots = t.export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    t.close(); c.dev_free(ds); c.dev_free(dq); grp.close(); oc.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_group_random_configurations(gpu_lib, seed):
+    """the GPU fuzz's draws through groups of 2 / 4 / 8 emulated ranks, every cut of the draw one global batch from host memory"""
+    from test_gpu_fuzz import _draw
+    prm, seq, qual, off, cuts, kw = _draw(41000 + seed, scale=3)
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([2, 4, 8]))
+    if prm["b"] < 21:
+        prm["b"] = int(rng.integers(21, 27))  # more bloom regions (2^(b-17)) than ranks
+    kw.pop("region_shift", None)
+    oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
+    oc.count(seq, qual, off)
+    n = len(off) - 1
+    grp = gpu_lib.GpuGroup(prm["k"], prm["b"], [0] * N, max_batch_pos=len(seq) + n + 64, q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"],
+                           filter_mode=prm["fm"], **kw)
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        if e > a:
+            o = off[a:e + 1] - off[a]
+            grp.count_host(gpu_lib.to_stream(seq[int(off[a]):int(off[e])], o), gpu_lib.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None)
+    _compare(grp, oc, prm["fm"])
+    grp.close(); oc.close()
