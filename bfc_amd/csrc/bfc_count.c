@@ -82,7 +82,35 @@ int bfcg_env_devices(int *dev, int max)
 	return n;
 }
 
+/* context creation (device buffers, zeroed filter and table: 0.1-0.3 s) runs on its own thread while the input is opened, the host buffers
+ * are pinned and the first batch is parsed */
+typedef struct { bfcg_params_t prm; int n_dev; int *devs; bfcg_ctx_t *ctx; bfcg_group_t *grp; char err[512]; } create_job_t;
+static void *create_main(void *arg)
+{
+	create_job_t *j = (create_job_t*)arg;
+	const char *env;
+	if (j->n_dev > 1) j->grp = bfcg_group_create(&j->prm, j->n_dev, 0, j->n_dev, j->devs, 0, (env = getenv("BFC_GPU_TRANSPORT")) ? atoi(env) : 0);
+	else j->ctx = bfcg_create(&j->prm);
+	if (!j->grp && !j->ctx) { strncpy(j->err, bfcg_last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; } /* the message is thread-local */
+	return 0;
+}
+
 /* ------------------------------------------------------------------ bfc_count */
+
+/* count.c:110-114, for every submitted reader batch that is complete on the GPU by now (in order) */
+static void print_progress(bfcg_ctx_t *ctx, const bfc_opt_t *opt, double t0, const uint64_t *pend_call, const int *pend_seqs, unsigned *lo, unsigned hi)
+{
+	uint64_t final = 0, keys[64];
+	bfcg_progress(ctx, 0, &final, keys, 63);
+	while (*lo != hi && pend_call[*lo & 63] <= final && final - pend_call[*lo & 63] < 63) {
+		const double rt = now_real() - t0, eff = 100. * now_cpu() / (rt + 1e-6);
+		if (!opt->filter_mode)
+			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, pend_seqs[*lo & 63], (long)keys[final - pend_call[*lo & 63]]);
+		else
+			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, pend_seqs[*lo & 63]);
+		++*lo;
+	}
+}
 
 void *bfc_count(const char *fn, const bfc_opt_t *opt)
 {
@@ -92,14 +120,16 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	int devs[64], n_dev;
 	ingest_t ps;
 	pipe_t pp;
-	pthread_t tid;
+	pthread_t tid, ctid;
+	create_job_t cj;
 	void *ret;
 	const char *env;
 	double t0 = (&bfc_real_time && bfc_real_time > 0.) ? bfc_real_time : now_real();
 	uint64_t cap, bases;
-	int i, cur = 0, io_threads, timing;
+	int i, cur = 0, io_threads, timing, small_input = 0, pin;
 	double tt, t_wait = 0, t_submit = 0;
 	uint64_t st[BFCG_ST_N];
+	uint64_t pend_call[64]; int pend_seqs[64]; unsigned n_pend_lo = 0, n_pend_hi = 0; /* reader batches submitted, their progress line not printed yet */
 
 	bfcg_params_default(&prm);
 	prm.k = opt->k; prm.q = opt->q; prm.bf_shift = opt->bf_shift; prm.n_hashes = opt->n_hashes;
@@ -122,6 +152,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 			int c0 = fgetc(fp), c1 = fgetc(fp);
 			fclose(fp);
 			if (!(c0 == 0x1f && c1 == 0x8b) && (uint64_t)sb.st_size + 4096 < cap) cap = (uint64_t)sb.st_size + 4096;
+			if ((uint64_t)sb.st_size < (3ULL << 30)) small_input = 1;
 		}
 	}                 /* the batch boundary is bseq_read's: the read that brings a batch to `bases` is its last */
 	if (cap < (1u << 16)) cap = 1u << 16;
@@ -132,31 +163,33 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	tt = now_real();
 	n_dev = bfcg_env_devices(devs, 64);
 	if (n_dev > 1 && (n_dev & (n_dev - 1))) { fprintf(stderr, "[E::%s] BFC_GPU_DEVICES names %d devices: the bloom regions are dealt to a power of two of GPUs\n", __func__, n_dev); abort(); }
-	if (n_dev > 1) { /* every rank takes 1/n of each batch (cut at read boundaries: shares differ by a read or two) */
-		prm.max_batch_pos = cap / (uint64_t)n_dev + cap / 64 + (1u << 16);
-		grp = bfcg_group_create(&prm, n_dev, 0, n_dev, devs, 0, (env = getenv("BFC_GPU_TRANSPORT")) ? atoi(env) : 0);
-		if (grp == 0) { fprintf(stderr, "[E::%s] cannot set up the multi-GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
-	} else {
-		if (n_dev == 1) prm.device = devs[0];
-		ctx = bfcg_create(&prm);
-		if (ctx == 0) { fprintf(stderr, "[E::%s] cannot set up the GPU count path: %s\n", __func__, bfcg_last_error()); abort(); }
-	}
-	if (timing) fprintf(stderr, "[T::bfc_count] GPU context%s (buffers for %llu positions per batch): %.3f s\n", grp ? "s" : "", (unsigned long long)cap, now_real() - tt);
+	if (n_dev > 1) prm.max_batch_pos = cap / (uint64_t)n_dev + cap / 64 + (1u << 16); /* every rank takes 1/n of each batch (cut at read boundaries: shares differ by a read or two) */
+	else if (n_dev == 1) prm.device = devs[0];
+	memset(&cj, 0, sizeof(cj));
+	cj.prm = prm; cj.n_dev = n_dev; cj.devs = devs;
+	pthread_create(&ctid, 0, create_main, &cj);
 
 	/* parser threads: -t (the count itself needs no host threads), BFC_GPU_IO_THREADS overrides; 0 = serial parser only */
 	io_threads = (env = getenv("BFC_GPU_IO_THREADS")) ? atoi(env) : opt->n_threads > 1 ? opt->n_threads : 0;
 	if (ingest_open(&ps, fn, bases, io_threads, opt->no_mt_io ? 1 : 2) != 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
 
+	pin = (env = getenv("BFC_GPU_PIN")) ? atoi(env) != 0 : !small_input;
 	memset(&pp, 0, sizeof(pp));
 	pp.ps = &ps;
 	pthread_mutex_init(&pp.mtx, 0); pthread_cond_init(&pp.cv, 0);
 	for (i = 0; i < 2; ++i) {
 		pp.b[i].cap = cap;
-		pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap);
+		/* pinning costs ~0.35 ms per MB (4 buffers of a batch each): it pays from a few GB of input on; below, plain memory and staged copies */
+		if (pin) { pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap); }
+		else { pp.b[i].seq = (uint8_t*)malloc(cap); pp.b[i].qual = (uint8_t*)malloc(cap); }
 		if (!pp.b[i].seq || !pp.b[i].qual) { fprintf(stderr, "[E::%s] cannot pin %llu bytes of host memory\n", __func__, (unsigned long long)cap); abort(); }
 	}
 	if (timing) fprintf(stderr, "[T::bfc_count] input opened (%s), pinned buffers: %.3f s\n", ps.fast.active ? "mapped, multi-threaded fast path" : "serial parser", now_real() - tt);
 	if (!opt->no_mt_io) pthread_create(&tid, 0, reader_main, &pp);
+	pthread_join(ctid, 0);
+	ctx = cj.ctx; grp = cj.grp;
+	if (!ctx && !grp) { fprintf(stderr, "[E::%s] cannot set up the GPU count path: %s\n", __func__, cj.err); abort(); }
+	if (timing) fprintf(stderr, "[T::bfc_count] GPU context%s ready (buffers for %llu positions per batch): %.3f s\n", grp ? "s" : "", (unsigned long long)cap, now_real() - tt);
 
 	for (;;) {
 		batch_t *b = &pp.b[cur];
@@ -170,7 +203,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		t_wait += now_real() - tt; tt = now_real();
 		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs); /* count.c:99, once per bseq_read call */
 		if (b->n_seqs) {
-			double rt, eff;
+			double rt = 0, eff = 0;
 			int rc = 0;
 			if (grp) rc = bfcg_group_count_batch_host(grp, b->seq, b->has_qual ? b->qual : 0, b->n_pos); /* (records without qualities inside a FASTQ batch carry '~' here: always high for -q <= 93) */
 			else if (b->has_qual && b->n_noq) { /* mixed batch: its runs of records with / without qualities, one after the other */
@@ -183,12 +216,20 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 				}
 			} else rc = bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos);
 			if (rc != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
-			if (grp) bfcg_group_stats(grp, st); else bfcg_stats(ctx, st);
-			rt = now_real() - t0; eff = 100. * now_cpu() / (rt + 1e-6);
-			if (!opt->filter_mode)
-				fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, b->n_seqs, (long)st[BFCG_ST_KEYS]);
-			else
-				fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, b->n_seqs);
+			if (grp) { /* several GPUs: the ranks' statistics, summed (waits for the batch) */
+				bfcg_group_stats(grp, st);
+				rt = now_real() - t0; eff = 100. * now_cpu() / (rt + 1e-6);
+				if (!opt->filter_mode)
+					fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, b->n_seqs, (long)st[BFCG_ST_KEYS]);
+				else
+					fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, b->n_seqs);
+			} else { /* the line of count.c:110-114 is printed when the batch is COMPLETE on the GPU -- without waiting for it here: the kernels of
+			          * this batch run under the parsing and the copies of the next (the reference's two pipeline steps interleave their lines too) */
+				uint64_t calls = 0;
+				bfcg_progress(ctx, &calls, 0, 0, 0);
+				pend_call[n_pend_hi & 63] = calls; pend_seqs[n_pend_hi & 63] = b->n_seqs; ++n_pend_hi;
+				print_progress(ctx, opt, t0, pend_call, pend_seqs, &n_pend_lo, n_pend_hi);
+			}
 		}
 		t_submit += now_real() - tt;
 		if (b->last) break; /* the last of the pipeline workers has got an empty batch */
@@ -201,6 +242,10 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		cur ^= 1;
 	}
 	if (!opt->no_mt_io) pthread_join(tid, 0);
+	if (ctx) { /* the batches still in flight */
+		if (bfcg_sync(ctx) != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
+		print_progress(ctx, opt, t0, pend_call, pend_seqs, &n_pend_lo, n_pend_hi);
+	}
 
 	tt = now_real();
 	if (grp) ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_group_export_bloom(grp, 1) : bfcg_group_export_bloom_resident(grp, 1)) /* all-gathered onto every device for the sharded trim pass */
@@ -209,7 +254,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	                            : (void*)bfcg_export_table(ctx);
 	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
-	for (i = 0; i < 2; ++i) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); free(pp.b[i].kind_cut); }
+	for (i = 0; i < 2; ++i) { if (pin) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); } else { free(pp.b[i].seq); free(pp.b[i].qual); } free(pp.b[i].kind_cut); }
 	pthread_mutex_destroy(&pp.mtx); pthread_cond_destroy(&pp.cv);
 	ingest_close(&ps);
 	if (grp) bfcg_group_destroy(grp); else bfcg_destroy(ctx); /* the first bloom filter dies here, as in count.c:155 */

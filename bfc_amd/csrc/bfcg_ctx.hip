@@ -43,6 +43,11 @@ struct bfcg_ctx {
 	int used[2];
 	uint8_t *d_seq, *d_qual;     // = d_seq2[0], d_qual2[0]
 	unsigned long long *h_stats; // pinned mirror
+	unsigned long long *h_snap[2]; // pinned: the counters as they stood when stage B of the batch in this slot ended (copied on stream st right behind it:
+	                             // keys and seen are touched by stage B alone, so these two are EXACT per batch without draining the pipeline)
+	uint64_t call_no, slot_call[2]; // top-level count calls so far; the call a slot's batch belongs to
+	int call_depth;
+	uint64_t final_call, call_keys[64]; // last call with a finalised batch; distinct keys after the last finalised batch of call (no % 64)
 	uint64_t n_batches;
 	float last_ms[6];
 	double sum_ms[6]; uint64_t n_timed; // cumulative per-stage GPU time of finalised batches (bfcg_stage_ms)
@@ -56,6 +61,8 @@ struct bfcg_ctx {
 	uint64_t crowded_last;       // ST_CROWDED at the last finalised batch
 	int stream_mode;             // 1: the batches' k-mers hardly repeat -- seen k-mers are streamed to k_commit_stream instead of aggregated
 	uint32_t *stream_out; uint64_t n_stream_batches;
+	int cold;                    // the filter is (nearly) empty: most k-mers of the next batch will find clear bits and go through a region's LDS list
+	uint64_t seen_last, pos_final, slot_pos[2]; // seen k-mers at the last finalised batch; positions of the batch(es) finalised since; positions of a slot's batch
 	int pipeline;                // stage A of batch t+1 on its own stream under stage B of batch t
 	int seg_ok;                  // the geometry allows region-owned table segments (KParams.seg): every reset starts in that layout
 	int seg_init_shift;          // log2 slots per segment after a reset
@@ -226,9 +233,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	// half its k-mers, bloom false positives aside
 	{ uint64_t cap = prm->max_batch_pos / 2; if (cap < (1u << 20)) cap = 1u << 20; if (cap > (1u << 28)) cap = 1u << 28; B.tab_ovf_cap = (uint32_t)cap; }
 	HIPCKN(hipMalloc(&B.tab_ovf, (uint64_t)B.tab_ovf_cap * 40));
-	// HBM first-setter pool for regions whose LDS tables overflow: 1024 slices (more than the workgroups resident at once) of
-	// 2 entries per region bit (the most a region can need), each behind a lock word -- no input can exhaust it
-	B.pool_slices = 1024;
+	// HBM first-setter pool for regions whose LDS tables overflow: 256 slices of 2 entries per region bit (the most a region can need), each
+	// behind a lock word.  A workgroup takes any free slice and waits for one if all are taken (their holders never wait for anything), so no
+	// input can exhaust the pool; 512 MiB instead of the 2 GiB that one slice per possibly resident workgroup cost at every context creation
+	B.pool_slices = 256;
 	{
 		const uint64_t pool_words = (uint64_t)B.pool_slices + (uint64_t)B.pool_slices * ((uint64_t)1024 << P.R);
 		HIPCKN(hipMalloc(&B.pool, pool_words * 8));
@@ -242,6 +250,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	for (int b = 0; b < 2; ++b) { HIPCKN(hipMalloc(&c->d_seq2[b], prm->max_batch_pos)); HIPCKN(hipMalloc(&c->d_qual2[b], prm->max_batch_pos)); }
 	c->d_seq = c->d_seq2[0]; c->d_qual = c->d_qual2[0];
 	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 2)));
+	for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_snap[b], sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1)));
 	HIPCKN(set_bloom_lds_attr(P));
 	if (bfcg_reset(c) != 0) { bfcg_destroy(c); return NULL; }
 	return c;
@@ -257,7 +266,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
-	(void)hipHostFree(c->h_stats); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
+	(void)hipHostFree(c->h_stats); (void)hipHostFree(c->h_snap[0]); (void)hipHostFree(c->h_snap[1]); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
 	(void)hipEventDestroy(c->evCopy);
 	(void)hipStreamDestroy(c->st); (void)hipStreamDestroy(c->stA); (void)hipStreamDestroy(c->stC);
@@ -294,6 +303,8 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	c->n_batches = 0;
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
 	c->crowded_last = 0; c->stream_mode = c->P.seg ? 1 : 0;
+	c->cold = 1; c->seen_last = c->pos_final = 0;
+	c->call_no = c->final_call = 0; c->call_depth = 0; memset(c->call_keys, 0, sizeof(c->call_keys));
 	return 0;
 }
 
@@ -313,6 +324,19 @@ static int fetch_stats_on(bfcg_ctx_t *c, hipStream_t s)
 }
 
 static int fetch_stats(bfcg_ctx_t *c) { return fetch_stats_on(c, c->st); }
+// the snapshot of slot b (complete once evB[b] has fired) folded into h_stats
+static void fold_snapshot(bfcg_ctx_t *c, int b)
+{
+	const unsigned long long *raw = c->h_snap[b];
+	for (int i = 0; i < ST_N; ++i) {
+		unsigned long long s = 0;
+		for (int j = 0; j < ST_SLOTS; ++j) s += raw[(size_t)j * ST_N + i];
+		c->h_stats[i] = s;
+	}
+	c->h_stats[ST_TAB_OVF] = raw[(size_t)ST_SLOTS * ST_N];
+	c->final_call = c->slot_call[b]; c->call_keys[c->slot_call[b] & 63] = c->h_stats[ST_KEYS];
+	c->pos_final += c->slot_pos[b]; c->slot_pos[b] = 0;
+}
 
 static int table_maintain(bfcg_ctx_t *c);
 static int seg_maintain(bfcg_ctx_t *c);
@@ -352,6 +376,8 @@ static int drain(bfcg_ctx_t *c)
 	c->pend = 0;
 	if (batch_times(c, c->cur ^ 1) != 0) return -1;
 	if (fetch_stats(c) != 0) return -1;
+	c->final_call = c->call_no; c->call_keys[c->call_no & 63] = c->h_stats[ST_KEYS];
+	c->pos_final += c->slot_pos[0] + c->slot_pos[1]; c->slot_pos[0] = c->slot_pos[1] = 0;
 	note_growth(c);
 	return check_health(c);
 }
@@ -364,6 +390,13 @@ static uint64_t growth_forecast(const bfcg_ctx_t *c) { return c->grow[0] < c->gr
 static void note_growth(bfcg_ctx_t *c)
 {
 	const uint64_t keys = c->h_stats[ST_KEYS];
+	{ // fewer than half of the last batch's k-mers were seen before: the filter is still filling up
+		// (the seen counter is exact per batch -- stage B alone moves it -- the k-mer counter is not: stage A of the next batch runs ahead;
+		// so the batch's size is taken from its positions, of which ~0.8 are k-mers)
+		const uint64_t ds = c->h_stats[ST_SEEN] - c->seen_last, np = c->pos_final;
+		if (np) c->cold = ds * 5 < np * 2;
+		c->seen_last = c->h_stats[ST_SEEN]; c->pos_final = 0;
+	}
 	c->grow[1] = c->grow[0]; c->grow[0] = keys > c->keys_last ? keys - c->keys_last : 0; c->keys_last = keys;
 	// more than half of the regions filled their aggregation table in the batch(es) just finalised: aggregation does not pay here
 	const uint64_t crowded = c->h_stats[ST_CROWDED], nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
@@ -600,6 +633,8 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	if (use_stream(c) != 0) return -1;
 	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
 	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
+	c->slot_call[b] = ++c->call_no; c->slot_pos[b] = off;
 	HIPCK(hipEventRecord(c->evB[b], c->st));
 	HIPCK(hipGetLastError());
 	c->used[b] = 1;
@@ -624,7 +659,7 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 		const int pb = b ^ 1;
 		HIPCK(hipEventSynchronize(c->evB[pb]));
 		if (batch_times(c, pb) != 0) return -1;
-		if (fetch_stats_on(c, c->stC) != 0) return -1; // counters may already include part of the running batch: fine for the checks below
+		fold_snapshot(c, pb); // the counters as they stood at the end of that batch's stage B (k-mer / high counts may include the next batch's stage A)
 		note_growth(c);
 		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->P.seg ? seg_target_shift(c) != c->P.seg_shift : (c->B.table && table_target_cshift(c) != c->P.tab_cshift))) {
 			c->pend = 1; c->cur = b ^ 1; // make drain() see the batch just enqueued
@@ -655,6 +690,8 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
 	run_stage_b(c->P, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
+	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
+	c->slot_call[b] = c->call_no; c->slot_pos[b] = n_pos;
 	HIPCK(hipEventRecord(c->evB[b], c->st));
 	HIPCK(hipGetLastError());
 	c->used[b] = 1;
@@ -665,6 +702,17 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 // A batch much larger than the filter's regions can take at full speed (list_cap k-mers with clear bits per region) is cut into
 // sub-batches here.  Any byte that is not ACGTacgt is a cut point -- no k-mer spans it (count.c:83,88) -- and batch boundaries never
 // change results, so this is invisible except in speed (every region of an oversized batch takes the exact but slow HBM path).
+// Into a COLD filter every k-mer of a batch brings clear bits, and a region's load spreads far wider than sqrt(mean): there the cut sits
+// at 0.85 of the list capacity and applies from the limit itself on (a batch just above the limit went whole into the empty filter and put
+// every region on the slow path: c3 at 4 M reads per batch 0.66 s instead of 0.45 s).  Into a warm filter only new k-mers take list entries:
+// callers split from 7/6 of the limit on -- just above it a few hundred slow regions cost less than a second pass over the bitmap.
+static uint64_t split_limit(const bfcg_ctx_t *c);
+static void split_rule(const bfcg_ctx_t *c, uint64_t *from, uint64_t *target_max)
+{
+	const uint64_t lim = split_limit(c);
+	if (c->cold) { *target_max = lim - lim / 10; *from = *target_max; }
+	else { *target_max = lim; *from = lim + lim / 6; }
+}
 static uint64_t split_limit(const bfcg_ctx_t *c)
 {
 	const uint64_t nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
@@ -701,8 +749,10 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 	if (n_pos == 0) return 0;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
-	const uint64_t lim = split_limit(c);
-	if (!c->B.seen_out && n_pos > lim + lim / 6) { // oversized for this filter: equal sub-batches of at most `lim` positions
+	uint64_t from, lim;
+	split_rule(c, &from, &lim);
+	struct depth_guard { bfcg_ctx_t *c; depth_guard(bfcg_ctx_t *c_) : c(c_) { if (c->call_depth++ == 0) ++c->call_no; } ~depth_guard() { --c->call_depth; } } guard(c);
+	if (!c->B.seen_out && n_pos > from) { // oversized for this filter: equal sub-batches of at most `lim` positions
 		const uint64_t target = n_pos / ((n_pos + lim - 1) / lim) + 1;
 		uint64_t o = 0;
 		while (n_pos - o > target + target / 8) {
@@ -724,8 +774,10 @@ extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const 
 	if (n_pos == 0) return 0;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
-	const uint64_t lim = split_limit(c);
-	if (!c->B.seen_out && n_pos > lim + lim / 6) { // oversized for this filter: equal sub-batches of at most `lim` positions (see bfcg_count_batch_dev)
+	uint64_t from, lim;
+	split_rule(c, &from, &lim);
+	struct depth_guard { bfcg_ctx_t *c; depth_guard(bfcg_ctx_t *c_) : c(c_) { if (c->call_depth++ == 0) ++c->call_no; } ~depth_guard() { --c->call_depth; } } guard(c);
+	if (!c->B.seen_out && n_pos > from) { // oversized for this filter: equal sub-batches of at most `lim` positions (see bfcg_count_batch_dev)
 		const uint64_t target = n_pos / ((n_pos + lim - 1) / lim) + 1;
 		uint64_t o = 0;
 		while (n_pos - o > target + target / 8) {
@@ -757,6 +809,19 @@ extern "C" int bfcg_h2d(bfcg_ctx_t *c, void *dst, const void *src, uint64_t byte
 { HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stC)); HIPCK(hipStreamSynchronize(c->stC)); return 0; }
 extern "C" int bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes)
 { HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stC)); HIPCK(hipStreamSynchronize(c->stC)); return 0; }
+
+// Progress WITHOUT draining the pipeline: calls = bfcg_count_batch_* calls made so far (numbered from 1 after a reset), final = the last
+// call all of whose batches are known to be complete, keys_of[final - i], i < n: distinct keys after call final - i (exact: stage B alone
+// creates keys, and its counters are copied out right behind it).  bfc_count prints the reference's progress lines from this.
+extern "C" int bfcg_progress(bfcg_ctx_t *c, uint64_t *calls, uint64_t *final, uint64_t *keys_of, int n)
+{
+	// a call is complete when a batch of a LATER call has been finalised, or when nothing is in flight
+	const uint64_t fin = c->pend ? (c->final_call ? c->final_call - 1 : 0) : c->call_no;
+	if (calls) *calls = c->call_no;
+	if (final) *final = fin;
+	for (int i = 0; i < n && (uint64_t)i < fin && i < 63; ++i) keys_of[i] = c->call_keys[(fin - i) & 63];
+	return 0;
+}
 
 extern "C" int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N])
 {

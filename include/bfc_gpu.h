@@ -175,7 +175,11 @@ int   bfcg_d2h(bfcg_ctx_t *c, void *dst, const void *src, uint64_t bytes);
 void *bfcg_host_alloc(uint64_t bytes);   /* pinned host memory */
 void  bfcg_host_free(void *p);
 
-int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);
+int bfcg_stats(bfcg_ctx_t *c, uint64_t out[BFCG_ST_N]);   /* drains the pipeline first */
+/* progress without draining: *calls = bfcg_count_batch_* calls since the last reset, *final = the last of them whose batches are all
+ * complete, keys_of[i] (i < n) = distinct keys in the table after call *final - i.  Exact, because the table's counters are copied out
+ * right behind every batch's table stage (count.c:113 prints the count after every chunk; bfc_count prints it from here). */
+int bfcg_progress(bfcg_ctx_t *c, uint64_t *calls, uint64_t *final, uint64_t *keys_of, int n);
 /* how the count table is held right now: out[0] 1 = region-owned segments, 0 = the host's layout; out[1] log2 slots per segment;
  * out[2] log2 slots per sub-table; out[3] segment growths so far */
 int bfcg_table_info(bfcg_ctx_t *c, int out[4]);

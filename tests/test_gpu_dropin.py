@@ -287,6 +287,11 @@ def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
             want = [l for l in r.stderr.decode().splitlines() if l.startswith("[M::bfc_count_cb] read")]
             got = [l for l in g.stderr.decode().splitlines() if l.startswith("[M::bfc_count_cb] read")]
             assert got == want, (seed, chunk, t)
+            # ... and so are the `processed N sequences; # distinct k-mers: K` lines (count.c:113; time stamps aside): K after every chunk is
+            # exact although the GPU path prints them without waiting for the chunk (bfcg_progress)
+            import re
+            pk = lambda txt: re.findall(r"processed (\d+) sequences; # distinct k-mers: (\d+)", txt)  # noqa: E731
+            assert pk(g.stderr.decode()) == pk(r.stderr.decode()) and (len(pk(r.stderr.decode())) > 1 or chunk != "50000"), (seed, chunk, t)
 
 
 @pytest.mark.usefixtures("gputrim_bin", "ref_bin")
