@@ -8,6 +8,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <sys/mman.h>
+#include <time.h>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -171,12 +172,17 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	P.track = (prm->track_order && !prm->filter_mode) ? 1 : 0;
 	// one workgroup per CU (regions of 32 KiB and more: -b36, -b37) runs 1024 threads so that the CU still has 16 waves; no such variant with order stamps
 	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
-	c->rw = P.k <= 31 ? 12 : P.k <= 47 ? 16 : 20;
+	// records do not store the bits of y0 that their level-1 bucket implies (bfcg_kernels.hip: RecGeom) -- where the bucket IS a bit field of y0:
+	// k >= bf_shift - 9 (the bloom block id is the low bf_shift-9 bits of the hash, and those are y0's, kmer.h:87)
+	// -- and where it makes the record smaller (c3: k=33, 9 bucket bits: 12 instead of 16 bytes; c2's k=31 records are 12 bytes anyway)
+	{ const char *e = getenv("BFCG_REC_DROP"); P.rec_n = (P.k >= P.bf_shift - 9 && bfcg_rec_dwords(P.k, P.F1) < bfcg_rec_dwords(P.k, 0) && !(e && atoi(e) == 0)) ? P.F1 : 0; P.rec_lo = P.R + P.F2; }
+	c->rw = 4 * bfcg_rec_dwords(P.k, P.rec_n);
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
 	// Stage A of the next batch runs under stage B of this one (two streams): c2 14.2 vs 15.4 ms per step.  While the count table was updated by
 	// random device-scope atomics the overlap HURT config c3 (389 vs 328 ms per step: the scatter kernels crawled beside k_commit_stream); with
-	// the table streamed through LDS (k_commit_seg) it is a small gain there too (267.8 vs 273.8 ms).  BFCG_PIPELINE=0: one stream.
-	{ const char *e = getenv("BFCG_PIPELINE"); c->pipeline = e ? atoi(e) != 0 : 1; }
+	// the table streamed through LDS (k_commit_seg) it is neither (265.9 vs 269.0 ms): batches of half a billion positions keep the chip busy on
+	// their own, and under rocprofv3 the overlapped kernels stretch.  So: two streams for batches up to 2^28 positions.  BFCG_PIPELINE=0/1 overrides.
+	{ const char *e = getenv("BFCG_PIPELINE"); c->pipeline = e ? atoi(e) != 0 : prm->max_batch_pos <= (1ULL << 28); }
 
 	if (n_ranks > 1 && log2n > P.F1) { set_err("multi-GPU needs a two-level partition with 2^F1=%d >= n_ranks (bf_shift=%d is too small)", 1 << P.F1, P.bf_shift); free(c); return NULL; }
 	P.idx_rank = n_ranks > 1 ? (uint32_t)prm->rank << (32 - log2n) : 0u;
@@ -194,7 +200,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	HIPCKN(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
 	{
-		const uint64_t tile = (uint64_t)bfcg_tile_of(P.k);
+		const uint64_t tile = (uint64_t)bfcg_tile_of_rw(c->rw / 4);
 		const uint64_t tiles1 = (prm->max_batch_pos + tile - 1) / tile, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
 		const uint64_t rows2 = c->recv_cap / tile + nb1 + 1;
 		for (int b = 0; b < 2; ++b) {
@@ -275,8 +281,11 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 
 static int drain(bfcg_ctx_t *c);
 
+static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
 {
+	const double t_dbg = dbg_now();
+	struct dbg_guard { double t; ~dbg_guard() { if (getenv("BFCG_DEBUG")) fprintf(stderr, "[D::reset] %.3f ms\n", (dbg_now() - t) * 1e3); } } dg{t_dbg};
 	HIPCK(hipSetDevice(c->prm.device));
 	if (c->pend && drain(c) != 0) return -1;
 	// the statistics first: stage A of the next batch (stream stA) adds to them and only has to wait for that small memset; the
@@ -486,6 +495,8 @@ static int seg_maintain(bfcg_ctx_t *c)
 {
 	KParams &P = c->P; BatchBufs &B = c->B;
 	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
+	const double t_dbg = dbg_now();
+	struct dbg_guard { double t; int s0; const int *s1; ~dbg_guard() { if (getenv("BFCG_DEBUG") && *s1 != s0) fprintf(stderr, "[D::seg_maintain] shift %d -> %d: %.3f ms\n", s0, *s1, (dbg_now() - t) * 1e3); } } dg{t_dbg, P.seg_shift, &P.seg_shift};
 	for (;;) {
 		const uint64_t ovf = c->h_stats[ST_TAB_OVF];
 		const int target = seg_target_shift(c);
@@ -616,7 +627,7 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 			seg_beg[seg] = (uint32_t)off; off += seg_cnt[s * nb_loc + k]; seg_end[seg] = (uint32_t)off;
 		}
 	if (off > c->recv_cap) return set_err("received %llu records for this rank's buckets, capacity %llu", (unsigned long long)off, (unsigned long long)c->recv_cap);
-	const uint32_t tile2 = (uint32_t)bfcg_tile_of(c->P.k);
+	const uint32_t tile2 = (uint32_t)bfcg_tile_of_rw(c->rw / 4);
 	for (int seg = 0; seg < n_seg; ++seg) { row_base[seg] = (uint32_t)rows; rows += (seg_end[seg] - seg_beg[seg] + tile2 - 1) / tile2; }
 	row_base[n_seg] = (uint32_t)rows;
 	for (int k = 0; k < nb_loc; ++k) {
@@ -710,7 +721,7 @@ static uint64_t split_limit(const bfcg_ctx_t *c);
 static void split_rule(const bfcg_ctx_t *c, uint64_t *from, uint64_t *target_max)
 {
 	const uint64_t lim = split_limit(c);
-	if (c->cold) { *target_max = lim - lim / 10; *from = *target_max; }
+	if (c->cold) { const char *e = getenv("BFCG_COLD_FRAC"); *target_max = e ? (uint64_t)((double)lim * atof(e)) : lim - lim / 10; *from = *target_max; }
 	else { *target_max = lim; *from = lim + lim / 6; }
 }
 static uint64_t split_limit(const bfcg_ctx_t *c)

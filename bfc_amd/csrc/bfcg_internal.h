@@ -5,7 +5,9 @@
 #define BFCG_TILE2 4096
 #define BFCG_SCAN_CH 64
 /* records per scatter tile: 20-byte records (k > 47) take 3072 so that two workgroups' stages fit a CU's LDS */
-static inline int bfcg_tile_of(int k) { return k > 47 ? 3072 : 4096; }
+/* dwords per k-mer record: y0 (minus rec_n bucket bits), y1, the quality flag and the 32-bit file index in 96 or 128 bits, else 20 bytes */
+static inline int bfcg_rec_dwords(int k, int rec_n) { const int bits = 2 * k - rec_n + 33; return bits <= 96 ? 3 : bits <= 128 ? 4 : 5; }
+static inline int bfcg_tile_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
 #define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */
 #include <stdint.h>
 
@@ -32,6 +34,7 @@ struct KParams {
 	int seg_shift;              // log2 slots per segment
 	int seg_lo, seg_hi;         // bits [seg_lo, seg_hi) of y0 are implied by the region (kmer_dev.h: SegGeom)
 	uint32_t f_base;            // global id of this rank's first bloom region
+	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
 };
 
 struct BatchBufs {

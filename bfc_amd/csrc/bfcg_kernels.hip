@@ -128,9 +128,19 @@ __device__ __forceinline__ bool kmer_at(const uint32_t *planes, int r, int k, W 
 // ------------------------------------------------------------------------------------------
 // records
 
-// A record is RD dwords:  RD=3 (k <= 31): y0 | is_high<<31, y1, file index   -- 12 bytes
-//                         RD=4 (k <= 47): two u64 = y0 | is_high<<47 | index[15:0]<<48, y1 | index[31:16]<<48
-//                         RD=5 (k <= 63): u64 y0 | is_high<<63, u64 y1, u32 index             -- 20 bytes (4-byte aligned)
+// A k-mer record is RD dwords: y0, y1 (the two words of bfc_kmer_hash, kmer.h:79-88), the high-quality flag and the file-order index
+// (position in the batch, 32 bit).  After the level-1 scatter a record sits in the bucket its bloom block id selects, and for k >= bf_shift-9
+// that id is a bit field of y0 (kmer_dev.h: the low bf_shift-9 bits of the hash are y0's): bits [rec_lo, rec_lo + rec_n) of y0 ARE the
+// level-1 bucket.  They are not stored (RecGeom): config c3's records (k=33) take 12 instead of 16 bytes, c5's (k=51) 16 instead of 20.
+//   RD=3: u64 A = y0' | y1 << a | hi << (a+k)   (a = k - rec_n kept bits of y0; a + k + 1 <= 64), u32 index          -- 12 bytes
+//   RD=4: one 128-bit word  y0' | y1 << a | hi << (a+k) | index << (a+k+1)                       (a + k + 33 <= 128)  -- 16 bytes
+//   RD=5: u64 y0 | is_high<<63, u64 y1, u32 index (nothing dropped)                                                    -- 20 bytes (4-byte aligned)
+struct RecGeom { int k, a, lo, n; };
+__device__ __forceinline__ RecGeom rec_geom(const KParams &P) { RecGeom g; g.k = P.k; g.n = P.rec_n; g.a = P.k - P.rec_n; g.lo = P.rec_lo; return g; }
+__device__ __forceinline__ uint64_t y0_drop(const RecGeom g, uint64_t y0) { return g.n ? (y0 & ((1ULL << g.lo) - 1)) | ((y0 >> (g.lo + g.n)) << g.lo) : y0; }
+__device__ __forceinline__ uint64_t y0_join(const RecGeom g, uint64_t y0c, uint32_t imp)
+{ return g.n ? (y0c & ((1ULL << g.lo) - 1)) | ((uint64_t)imp << g.lo) | ((y0c >> g.lo) << (g.lo + g.n)) : y0c; }
+
 template <int RD> struct RecW { uint32_t d[RD]; };
 
 template <int RD> __device__ __forceinline__ RecW<RD> rec_load(const uint32_t *p);
@@ -148,34 +158,47 @@ template <> __device__ __forceinline__ void rec_store<4>(uint32_t *p, const RecW
 template <> __device__ __forceinline__ void rec_store<5>(uint32_t *p, const RecW<5> &r)
 { p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; p[3] = r.d[3]; p[4] = r.d[4]; }
 
+// pack: y0 is the FULL word (the bucket's bits are dropped here); unpack: imp = the record's (global) level-1 bucket
 template <int RD> struct Rec;
 template <> struct Rec<3> {
-	static __device__ __forceinline__ void pack(RecW<3> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
-	{ r.d[0] = (uint32_t)y0 | ((uint32_t)hi << 31); r.d[1] = (uint32_t)y1; r.d[2] = idx; }
-	static __device__ __forceinline__ void unpack(const RecW<3> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
-	{ y0 = r.d[0] & 0x7fffffffu; hi = r.d[0] >> 31; y1 = r.d[1]; idx = r.d[2]; }
+	static __device__ __forceinline__ void pack(RecW<3> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	{
+		const uint64_t A = y0_drop(g, y0) | (y1 << g.a) | ((uint64_t)hi << (g.a + g.k));
+		r.d[0] = (uint32_t)A; r.d[1] = (uint32_t)(A >> 32); r.d[2] = idx;
+	}
+	static __device__ __forceinline__ void unpack(const RecW<3> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	{
+		const uint64_t A = r.d[0] | ((uint64_t)r.d[1] << 32);
+		y0 = y0_join(g, A & ((1ULL << g.a) - 1), imp);
+		y1 = (A >> g.a) & ((1ULL << g.k) - 1);
+		hi = (A >> (g.a + g.k)) & 1; idx = r.d[2];
+	}
 };
 template <> struct Rec<4> {
-	static __device__ __forceinline__ void pack(RecW<4> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	static __device__ __forceinline__ void pack(RecW<4> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
 	{
-		const uint64_t a = y0 | ((uint64_t)hi << 47) | ((uint64_t)(idx & 0xffffu) << 48), b = y1 | ((uint64_t)(idx >> 16) << 48);
-		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)b; r.d[3] = (uint32_t)(b >> 32);
+		typedef unsigned __int128 u128;
+		const u128 v = (u128)y0_drop(g, y0) | ((u128)y1 << g.a) | ((u128)hi << (g.a + g.k)) | ((u128)idx << (g.a + g.k + 1));
+		const uint64_t lo = (uint64_t)v, hi64 = (uint64_t)(v >> 64);
+		r.d[0] = (uint32_t)lo; r.d[1] = (uint32_t)(lo >> 32); r.d[2] = (uint32_t)hi64; r.d[3] = (uint32_t)(hi64 >> 32);
 	}
-	static __device__ __forceinline__ void unpack(const RecW<4> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	static __device__ __forceinline__ void unpack(const RecW<4> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
 	{
-		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32), b = r.d[2] | ((uint64_t)r.d[3] << 32);
-		y0 = a & ((1ULL << 47) - 1); hi = (a >> 47) & 1;
-		y1 = b & ((1ULL << 48) - 1);
-		idx = (uint32_t)(a >> 48) | ((uint32_t)(b >> 48) << 16);
+		typedef unsigned __int128 u128;
+		const u128 v = (u128)(r.d[0] | ((uint64_t)r.d[1] << 32)) | ((u128)(r.d[2] | ((uint64_t)r.d[3] << 32)) << 64);
+		y0 = y0_join(g, (uint64_t)v & ((1ULL << g.a) - 1), imp);
+		y1 = (uint64_t)(v >> g.a) & (g.k >= 64 ? ~0ULL : (1ULL << g.k) - 1);
+		hi = (uint64_t)(v >> (g.a + g.k)) & 1;
+		idx = (uint32_t)(v >> (g.a + g.k + 1));
 	}
 };
 template <> struct Rec<5> {
-	static __device__ __forceinline__ void pack(RecW<5> &r, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	static __device__ __forceinline__ void pack(RecW<5> &r, const RecGeom, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
 	{
 		const uint64_t a = y0 | ((uint64_t)hi << 63);
 		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)y1; r.d[3] = (uint32_t)(y1 >> 32); r.d[4] = idx;
 	}
-	static __device__ __forceinline__ void unpack(const RecW<5> &r, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	static __device__ __forceinline__ void unpack(const RecW<5> &r, const RecGeom, uint32_t, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
 	{
 		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32);
 		y0 = a & ~(1ULL << 63); hi = a >> 63; y1 = r.d[2] | ((uint64_t)r.d[3] << 32); idx = r.d[4];
@@ -289,6 +312,30 @@ __global__ __launch_bounds__(256) void k_apply(uint32_t *__restrict__ rows, int 
 	}
 }
 
+// Exclusive scan of nb <= 2*BT bucket counters in LDS (in place) by the whole workgroup: every thread takes one or two consecutive
+// entries, waves scan with shuffles, the waves' totals meet in wsum[BT/64].  Two barriers (the Hillis-Steele loop it replaces took
+// 2 log2(nb)); returns the grand total to every thread.  The caller synchronises before using cnt[].
+template <int BT>
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t *cnt, int nb, uint32_t *wsum)
+{
+	constexpr int NW = BT / WAVE;
+	const int E = (nb + BT - 1) / BT, i0 = threadIdx.x * E, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+	uint32_t v0 = i0 < nb ? cnt[i0] : 0, v1 = (E > 1 && i0 + 1 < nb) ? cnt[i0 + 1] : 0;
+	const uint32_t s = v0 + v1;
+	uint32_t inc = s;
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+	if (lane == WAVE - 1) wsum[wave] = inc;
+	__syncthreads();
+	uint32_t woff = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < NW; ++w) { const uint32_t x = wsum[w]; if (w < wave) woff += x; tot += x; }
+	const uint32_t ex = woff + inc - s;
+	if (i0 < nb) cnt[i0] = ex;
+	if (E > 1 && i0 + 1 < nb) cnt[i0 + 1] = ex + v0;
+	return tot;
+}
+
 // pass B: K1 again; the tile's records are ordered by level-1 bucket in LDS and copied out run by run with
 // neighbouring lanes (coalesced stores), at rows1[tile][bucket] (absolute offsets after the scan).
 template <typename W, int RW, int TILE, int BT>
@@ -299,14 +346,16 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
-	// bucket of each staged record -- kept for 12-byte records only: with 16- and 20-byte records the 8 KiB would cost the second resident
-	// workgroup, and the bucket is recomputed from the staged record instead
-	constexpr bool KEEP_BK = false;
+	// bucket of each staged record: kept (2 bytes per record) where the record itself no longer says it (RecGeom: the bucket's bits of y0 are
+	// not stored); otherwise it is recomputed from the staged record -- the 8 KiB would cost 20-byte records their second resident workgroup
+	const bool KEEP_BK = P.rec_n > 0 && RW != 5;
+	const RecGeom RG = rec_geom(P);
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4);
 	__shared__ uint32_t planes[4 * PW];
 	__shared__ uint32_t s_total;
 	const int nb1 = 1 << P.F1;
-	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *loff = cnt + nb1, *gdelta = loff + nb1; // 3 x nb1 counters behind the stage
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *gdelta = cnt + nb1; // 2 x nb1 counters behind the stage
+	__shared__ uint32_t wsum1[BT / WAVE];
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
 	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
@@ -324,29 +373,16 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 		if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
 			const uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
 			const uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
-			Rec<RW>::pack(w[j], (uint64_t)y0, (uint64_t)y1, idx, hi);
+			Rec<RW>::pack(w[j], RG, (uint64_t)y0, (uint64_t)y1, idx, hi);
 			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
 		}
 	}
 	__syncthreads();
-	{ // exclusive scan of the bucket counters (Hillis-Steele in LDS)
-		for (int i = threadIdx.x; i < nb1; i += BT) loff[i] = cnt[i];
+	{ // bucket counters -> exclusive offsets inside the stage; gdelta = where the bucket's run goes in the output
+		const uint32_t tot = block_scan_excl<BT>(cnt, nb1, wsum1);
+		if (threadIdx.x == 0) s_total = tot;
 		__syncthreads();
-		for (int o = 1; o < nb1; o <<= 1) {
-			uint32_t v[BFCG_MAXB / BT > 0 ? BFCG_MAXB / BT : 1];
-			int q = 0;
-			for (int i = threadIdx.x; i < nb1; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
-			__syncthreads();
-			q = 0;
-			for (int i = threadIdx.x; i < nb1; i += BT, ++q) loff[i] += v[q];
-			__syncthreads();
-		}
-		if (threadIdx.x == 0) s_total = loff[nb1 - 1];
-		for (int i = threadIdx.x; i < nb1; i += BT) {
-			const uint32_t ex = loff[i] - cnt[i];
-			gdelta[i] = rows1[tile * nb1 + i] - ex; // global record index = staged position + gdelta[bucket] (u32 modular)
-			cnt[i] = ex;
-		}
+		for (int i = threadIdx.x; i < nb1; i += BT) gdelta[i] = rows1[tile * nb1 + i] - cnt[i]; // global record index = staged position + gdelta[bucket] (u32 modular)
 	}
 	__syncthreads();
 #pragma unroll
@@ -366,7 +402,7 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
 		uint32_t b;
 		if (KEEP_BK) b = sbk[pos];
-		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) >> P.F2; }
+		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, RG, 0u, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) >> P.F2; } // (nothing dropped here)
 		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
 		rec_store<RW>(out + dst * RW, rec);
 	}
@@ -386,9 +422,10 @@ __device__ __forceinline__ int row_bucket(const uint32_t *__restrict__ row_base,
 
 template <typename W, int RW, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
-                                              const uint32_t *__restrict__ seg_end, int n_seg,
+                                              const uint32_t *__restrict__ seg_end, int n_seg, int segs_per_bucket,
                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2)
 {
+	const RecGeom RG = rec_geom(P);
 	__shared__ uint32_t hist[BFCG_MAXB];
 	const int nb2 = 1 << P.F2;
 	const uint32_t n_rows = row_base[n_seg];
@@ -397,6 +434,7 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restr
 	const int b1 = row_bucket(row_base, n_seg, (uint32_t)row); // segment = one level-1 bucket (from one source rank)
 	const uint32_t tile = (uint32_t)row - row_base[b1];
 	const uint32_t s = seg_beg[b1], e = seg_end[b1];
+	const uint32_t imp = (P.f_base >> P.F2) + (uint32_t)(b1 / segs_per_bucket); // the segment's level-1 bucket (global): the bits its records do not store
 	for (int i = threadIdx.x; i < nb2; i += BT) hist[i] = 0;
 	__syncthreads();
 #pragma unroll
@@ -404,7 +442,7 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restr
 		uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(rec_load<RW>(in + i * RW), y0, y1, idx, hi);
+			Rec<RW>::unpack(rec_load<RW>(in + i * RW), RG, imp, y0, y1, idx, hi);
 			atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
 		}
 	}
@@ -447,23 +485,26 @@ __global__ __launch_bounds__(BFCG_MAXB) void k_scan2(KParams P, const uint32_t *
 // records measured 2x WRITE_SIZE inflation and ~1.1 TB/s).
 template <typename W, int RW, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
-                                                 const uint32_t *__restrict__ seg_end, int n_seg,
+                                                 const uint32_t *__restrict__ seg_end, int n_seg, int segs_per_bucket,
                                                  const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ rows2,
                                                  uint32_t *__restrict__ out)
 {
+	const RecGeom RG = rec_geom(P);
 	constexpr int S = TILE / BT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem2);                              // TILE * RW dwords
 	constexpr bool KEEP_BK = false;
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 4); // bucket of each staged record
 	const int nb2 = 1 << P.F2;
-	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *loff = cnt + nb2, *gdelta = loff + nb2; // 3 x nb2 counters behind the stage
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *gdelta = cnt + nb2; // 2 x nb2 counters behind the stage
+	__shared__ uint32_t wsum2[BT / WAVE];
 	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
 	if (row >= n_rows) return;
 	const int b1 = row_bucket(row_base, n_seg, (uint32_t)row);
 	const uint32_t tile = (uint32_t)row - row_base[b1];
 	const uint32_t s = seg_beg[b1], e = seg_end[b1];
+	const uint32_t imp = (P.f_base >> P.F2) + (uint32_t)(b1 / segs_per_bucket);
 	const uint32_t *rowp = rows2 + (size_t)row * nb2;
 	for (int i = threadIdx.x; i < nb2; i += BT) cnt[i] = 0;
 	__syncthreads();
@@ -476,29 +517,16 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
 			w[j] = rec_load<RW>(in + i * RW);
-			Rec<RW>::unpack(w[j], y0, y1, idx, hi);
+			Rec<RW>::unpack(w[j], RG, imp, y0, y1, idx, hi);
 			uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
 			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
 		}
 	}
 	__syncthreads();
-	{ // exclusive scan of the bucket counters (Hillis-Steele in LDS)
-		for (int i = threadIdx.x; i < nb2; i += BT) loff[i] = cnt[i];
+	{ // bucket counters -> exclusive offsets inside the stage; gdelta = where the bucket's run goes in the output
+		block_scan_excl<BT>(cnt, nb2, wsum2);
 		__syncthreads();
-		for (int o = 1; o < nb2; o <<= 1) {
-			uint32_t v[BFCG_MAXB / BT > 0 ? BFCG_MAXB / BT : 1];
-			int q = 0;
-			for (int i = threadIdx.x; i < nb2; i += BT, ++q) v[q] = i >= o ? loff[i - o] : 0;
-			__syncthreads();
-			q = 0;
-			for (int i = threadIdx.x; i < nb2; i += BT, ++q) loff[i] += v[q];
-			__syncthreads();
-		}
-		for (int i = threadIdx.x; i < nb2; i += BT) {
-			uint32_t ex = loff[i] - cnt[i];
-			gdelta[i] = rowp[i] - ex; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
-			cnt[i] = ex;              // reuse cnt as the exclusive offsets
-		}
+		for (int i = threadIdx.x; i < nb2; i += BT) gdelta[i] = rowp[i] - cnt[i]; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
 	}
 	__syncthreads();
 #pragma unroll
@@ -518,7 +546,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
 		uint32_t b;
 		if (KEEP_BK) b = sbk[pos];
-		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) & (uint32_t)(nb2 - 1); }
+		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, RG, imp, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) & (uint32_t)(nb2 - 1); }
 		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
 		rec_store<RW>(out + dst * RW, rec);
 	}
@@ -727,10 +755,10 @@ __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, 
 struct KRec { uint64_t y0, y1; uint32_t idx, bl, h1, h2; bool hi; };
 
 template <typename W, int RW>
-__device__ __forceinline__ KRec decode_rec(const KParams &P, const RecW<RW> &w, W m, uint32_t rmask)
+__device__ __forceinline__ KRec decode_rec(const KParams &P, const RecW<RW> &w, W m, uint32_t rmask, uint32_t imp)
 {
 	KRec r;
-	Rec<RW>::unpack(w, r.y0, r.y1, r.idx, r.hi);
+	Rec<RW>::unpack(w, rec_geom(P), imp, r.y0, r.y1, r.idx, r.hi);
 	BloomAddr a = bloom_addr(bloom_hash<W>(P.k, (W)r.y0, (W)r.y1, m), P.bf_shift);
 	r.bl = (uint32_t)a.blk & rmask; r.h1 = a.h1; r.h2 = a.h2;
 	return r;
@@ -846,6 +874,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	unsigned int *g_region_hi = FM ? reinterpret_cast<unsigned int *>(A.bloom_hi) + (uint64_t)f * region_dw : nullptr;
 	const W m = kmask<W>(P.k);
 	const uint32_t rmask = region_blocks - 1;
+	const uint32_t imp = (P.f_base + f) >> P.F2; // the region's level-1 bucket: the bits of y0 its records do not store
 	const int nh = NH ? NH : P.n_hashes;
 
 	const bool timing = (P.ablate & 64) && threadIdx.x == 0;
@@ -916,7 +945,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 				reinterpret_cast<unsigned long long *>(A.stream_out)[at] = (seg_id(seg_geom(P), r.y0, r.y1) << 1) | (unsigned long long)r.hi;
 			} else {
 				RecW<RW> w;
-				Rec<RW>::pack(w, r.y0, r.y1, r.idx, r.hi);
+				Rec<RW>::pack(w, rec_geom(P), r.y0, r.y1, r.idx, r.hi);
 				rec_store<RW>(A.stream_out + at * RW, w);
 			}
 		} else emit_seen<W, TRACK>(P, A, G, r.y0, r.y1, r.hi, r.idx);
@@ -943,7 +972,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		for (int u = 0; u < PF; ++u) {
 			act[u] = base + threadIdx.x + u * BT < n;
 			um[u] = 0;
-			if (act[u]) { r[u] = decode_rec<W, RW>(P, rw[u], m, rmask); um[u] = clear_mask(r[u]); }
+			if (act[u]) { r[u] = decode_rec<W, RW>(P, rw[u], m, rmask, imp); um[u] = clear_mask(r[u]); }
 		}
 #pragma unroll
 		for (int u = 0; u < PF; ++u) {
@@ -984,7 +1013,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			RecW<RW> w;
 			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
-			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			KRec r = decode_rec<W, RW>(P, w, m, rmask, imp);
 			const uint32_t um = list_b[li] >> 20;
 			uint32_t z = r.h1;
 #pragma unroll
@@ -1014,7 +1043,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 				RecW<RW> w;
 				if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 				else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
-				KRec r = decode_rec<W, RW>(P, w, m, rmask);
+				KRec r = decode_rec<W, RW>(P, w, m, rmask, imp);
 				const uint32_t um = list_b[li] >> 20;
 				uint32_t z = r.h1;
 #pragma unroll
@@ -1031,7 +1060,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			RecW<RW> w;
 			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
-			KRec r = decode_rec<W, RW>(P, w, m, rmask);
+			KRec r = decode_rec<W, RW>(P, w, m, rmask, imp);
 			const uint32_t um = list_b[li] >> 20;
 			uint32_t z = r.h1; bool first = !s_fs_used;
 			if (!first) {
@@ -1076,7 +1105,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		__syncthreads();
 		const uint32_t gmask = cap - 1;
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask);
+			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask, imp);
 			uint32_t z = r.h1;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, r.h2);
@@ -1086,7 +1115,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		__threadfence();
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask);
+			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask, imp);
 			uint32_t z = r.h1; bool first = false, unresolved = false;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, r.h2), fi;
@@ -1202,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_commit_stream(KParams P, BloomArgs A)
 		const uint64_t base = A.start[f];
 		for (uint32_t j = lane; j < n; j += 64) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(rec_load<RW>(A.stream_out + (base + j) * RW), y0, y1, idx, hi);
+			Rec<RW>::unpack(rec_load<RW>(A.stream_out + (base + j) * RW), rec_geom(P), (P.f_base + f) >> P.F2, y0, y1, idx, hi);
 			commit_seen<W, false>(P, A, y0, y1, 1u, (uint32_t)hi, 0u, 0u);
 		}
 	}
@@ -1585,7 +1614,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, T2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4) + (size_t)12 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1601,9 +1630,9 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		constexpr int T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
 		// rows of level 2 <= records/T2 + one ragged row per segment; surplus blocks exit at once
 		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
-		hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2);
+		hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2);
 		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)12 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, row_base, B.rows2, (uint32_t *)B.recs2);
+		hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2, (uint32_t *)B.recs2);
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
@@ -1654,7 +1683,10 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	if (ev) hipEventRecord(ev[5], st);
 }
 
-#define DISPATCH_W(fn, ...) do { if (P.k <= 31) fn<uint32_t, 3>(__VA_ARGS__); else if (P.k == 32) fn<uint32_t, 4>(__VA_ARGS__); else if (P.k <= 47) fn<uint64_t, 4>(__VA_ARGS__); else fn<uint64_t, 5>(__VA_ARGS__); } while (0)
+// W: 32-bit k-mer arithmetic up to k = 32; RW: dwords per record (bfcg_rec_dwords: 12 bytes up to 2k - rec_n + 33 <= 96 bits, 16 up to 128, else 20)
+#define DISPATCH_W(fn, ...) do { const int rw_ = bfcg_rec_dwords(P.k, P.rec_n); \
+	if (P.k <= 32) { if (rw_ == 3) fn<uint32_t, 3>(__VA_ARGS__); else fn<uint32_t, 4>(__VA_ARGS__); } \
+	else if (rw_ == 3) fn<uint64_t, 3>(__VA_ARGS__); else if (rw_ == 4) fn<uint64_t, 4>(__VA_ARGS__); else fn<uint64_t, 5>(__VA_ARGS__); } while (0)
 
 void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
 { DISPATCH_W(run_stage_a_t, P, B, seq, qual, n_pos, (uint32_t *)out1, st, ev); }
@@ -1680,8 +1712,8 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
 	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2;
-	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 12 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
@@ -1699,9 +1731,10 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 hipError_t set_bloom_lds_attr(const KParams &P)
 {
 	int lds = bloom_lds_bytes(P);
-	if (P.k <= 31) return set_attr_t<uint32_t, 3>(lds);
-	if (P.k == 32) return set_attr_t<uint32_t, 4>(lds);
-	if (P.k <= 47) return set_attr_t<uint64_t, 4>(lds);
+	const int rw = bfcg_rec_dwords(P.k, P.rec_n);
+	if (P.k <= 32) return rw == 3 ? set_attr_t<uint32_t, 3>(lds) : set_attr_t<uint32_t, 4>(lds);
+	if (rw == 3) return set_attr_t<uint64_t, 3>(lds);
+	if (rw == 4) return set_attr_t<uint64_t, 4>(lds);
 	return set_attr_t<uint64_t, 5>(lds);
 }
 
