@@ -62,6 +62,7 @@ struct bfcg_ctx {
 	uint64_t crowded_last;       // ST_CROWDED at the last finalised batch
 	int stream_mode;             // 1: the batches' k-mers hardly repeat -- seen k-mers are streamed to k_commit_stream instead of aggregated
 	uint32_t *stream_out; uint64_t n_stream_batches;
+	double seen_per_pos;         // seen k-mers per stream position in the last finalised batch
 	int cold;                    // the filter is (nearly) empty: most k-mers of the next batch will find clear bits and go through a region's LDS list
 	uint64_t seen_last, pos_final, slot_pos[2]; // seen k-mers at the last finalised batch; positions of the batch(es) finalised since; positions of a slot's batch
 	int pipeline;                // stage A of batch t+1 on its own stream under stage B of batch t
@@ -403,7 +404,7 @@ static void note_growth(bfcg_ctx_t *c)
 		// (the seen counter is exact per batch -- stage B alone moves it -- the k-mer counter is not: stage A of the next batch runs ahead;
 		// so the batch's size is taken from its positions, of which ~0.8 are k-mers)
 		const uint64_t ds = c->h_stats[ST_SEEN] - c->seen_last, np = c->pos_final;
-		if (np) c->cold = ds * 5 < np * 2;
+		if (np) { c->cold = ds * 5 < np * 2; c->seen_per_pos = (double)ds / (double)np; }
 		c->seen_last = c->h_stats[ST_SEEN]; c->pos_final = 0;
 	}
 	c->grow[1] = c->grow[0]; c->grow[0] = keys > c->keys_last ? keys - c->keys_last : 0; c->keys_last = keys;
@@ -520,8 +521,12 @@ static int seg_maintain(bfcg_ctx_t *c)
 		run_seg_rehash(P, B.seg_tab, old_shift, nt, (uint32_t)nfine, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		HIPCK(hipGetLastError());
-		if (((nfine << c->seg_cap_shift) * 8) <= (16ULL << 30)) { c->seg_spare = B.seg_tab; c->seg_spare_shift = c->seg_cap_shift; }
-		else HIPCK(hipFree(B.seg_tab));
+		if (((nfine << nt_shift) * 8) <= (16ULL << 30)) {
+			// the buffer left behind becomes the spare the NEXT growth rehashes into; one that is smaller than its successor could not
+			// take that growth after a reset: replace it now, so that from the second data set on a context never allocates
+			if (c->seg_cap_shift < nt_shift) { HIPCK(hipFree(B.seg_tab)); c->seg_spare = 0; if (hipMalloc(&c->seg_spare, (nfine << nt_shift) * 8) != hipSuccess) { (void)hipGetLastError(); c->seg_spare = 0; } c->seg_spare_shift = nt_shift; }
+			else { c->seg_spare = B.seg_tab; c->seg_spare_shift = c->seg_cap_shift; }
+		} else HIPCK(hipFree(B.seg_tab));
 		B.seg_tab = nt; c->seg_cap_shift = nt_shift;
 		++c->n_seg_grow;
 		if (ovf) {
@@ -722,7 +727,14 @@ static void split_rule(const bfcg_ctx_t *c, uint64_t *from, uint64_t *target_max
 {
 	const uint64_t lim = split_limit(c);
 	if (c->cold) { const char *e = getenv("BFCG_COLD_FRAC"); *target_max = e ? (uint64_t)((double)lim * atof(e)) : lim - lim / 10; *from = *target_max; }
-	else { *target_max = lim; *from = lim + lim / 6; }
+	else { // warm: only the k-mers that still find clear bits take list entries -- about (0.79 - seen per position) of the positions, as the last batch
+	       // showed; aim at 60 % of the list capacity, at most 3x the cold limit
+		double unseen = 0.79 - c->seen_per_pos;
+		if (unseen < 0.2) unseen = 0.2;
+		double w = getenv("BFCG_NO_WARM_BATCHES") ? 1.0 : 0.6 / 0.95 / unseen;
+		if (w < 1.0) w = 1.0;
+		*target_max = (uint64_t)((double)lim * w); *from = *target_max + *target_max / 6;
+	}
 }
 static uint64_t split_limit(const bfcg_ctx_t *c)
 {
