@@ -70,6 +70,8 @@ struct bfcg_ctx {
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
 	uint64_t n_seg_grow;         // segment growths since creation
+	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
+	int seg_no_grow;             // the next segment size does not fit (memory / LDS): grow only when a segment overflows or the load passes 85 %
 	int seg_cap_shift;           // the allocation behind B.seg_tab holds segments of up to 2^seg_cap_shift slots
 	unsigned long long *seg_spare; int seg_spare_shift; // the buffer the last growth left behind (kept up to 16 GiB): growth rehashes from one into the other,
 	                             // so a context that counts one data set after the other stops calling hipMalloc / hipFree (tens of ms per multi-GiB call)
@@ -304,7 +306,17 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 			if (c->B.seg_tab) { HIPCK(hipFree(c->B.seg_tab)); c->B.seg_tab = 0; }
 			c->P.seg_shift = c->seg_cap_shift = c->seg_init_shift;
 			HIPCK(hipMalloc(&c->B.seg_tab, (nfine << c->P.seg_shift) * 8));
-		} else c->P.seg_shift = c->seg_init_shift; // start small again inside the allocation the last run grew to (seg_cap_shift says how far it goes)
+		} else {
+			c->P.seg_shift = c->seg_init_shift; // start small again inside the allocation the last run grew to (seg_cap_shift says how far it goes)
+			if (c->n_batches && c->seg_spare && c->seg_spare_shift < c->seg_cap_shift && ((nfine << c->seg_cap_shift) * 8) <= (16ULL << 30)) {
+				// second data set on this context: make the spare as large as the segments grew, so that this run's growths find their target ready
+				HIPCK(hipStreamSynchronize(c->st));
+				HIPCK(hipFree(c->seg_spare)); c->seg_spare = 0;
+				if (hipMalloc(&c->seg_spare, (nfine << c->seg_cap_shift) * 8) != hipSuccess) { (void)hipGetLastError(); c->seg_spare = 0; }
+				c->seg_spare_shift = c->seg_cap_shift;
+			}
+		}
+		if (c->n_batches) c->reused = 1;
 		c->P.seg = 1; c->seg_escaped = 0;
 		HIPCK(hipMemsetAsync(c->B.seg_tab, 0, (nfine << c->P.seg_shift) * 8, c->st));
 	}
@@ -313,7 +325,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	c->n_batches = 0;
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
 	c->crowded_last = 0; c->stream_mode = c->P.seg ? 1 : 0;
-	c->cold = 1; c->seen_last = c->pos_final = 0;
+	c->cold = 1; c->seen_last = c->pos_final = 0; c->seg_no_grow = 0;
 	c->call_no = c->final_call = 0; c->call_depth = 0; memset(c->call_keys, 0, sizeof(c->call_keys));
 	return 0;
 }
@@ -485,8 +497,11 @@ static int seg_target_shift(const bfcg_ctx_t *c)
 	// forecast with the larger of the last two batches' additions
 	const uint64_t need = c->h_stats[ST_KEYS] + c->h_stats[ST_TAB_OVF], g = c->grow[0] > c->grow[1] ? c->grow[0] : c->grow[1];
 	int t = P.seg_shift;
-	while ((double)(need + g) > 0.62 * (double)(nfine << t)) ++t;
+	const double full = c->seg_no_grow ? 0.85 : 0.62;
+	while ((double)(need + (c->seg_no_grow ? 0 : g)) > full * (double)(nfine << t)) ++t;
 	if (c->h_stats[ST_TAB_OVF] && t == P.seg_shift) ++t; // one full segment under a low overall load
+	if (t != P.seg_shift && getenv("BFCG_DEBUG")) fprintf(stderr, "[D::seg_target] shift %d -> %d: keys %llu parked %llu forecast %llu slots %llu\n", P.seg_shift, t,
+		(unsigned long long)c->h_stats[ST_KEYS], (unsigned long long)c->h_stats[ST_TAB_OVF], (unsigned long long)g, (unsigned long long)(nfine << P.seg_shift));
 	return t;
 }
 
@@ -503,11 +518,15 @@ static int seg_maintain(bfcg_ctx_t *c)
 		const int target = seg_target_shift(c);
 		if (ovf == 0 && target == P.seg_shift) return 0;
 		if (ovf > B.tab_ovf_cap) return set_err("count table overflow list exhausted (%llu parked k-mers)", (unsigned long long)ovf);
-		if (target > BFCG_SEG_MAX_SHIFT) return seg_to_legacy(c);
-		{
+		{ // the old segments live until the new ones are filled.  No room (or no LDS: s > 14) for the next size: run fuller instead while nothing is
+		  // parked and the mean load stays below 85 % (probing happens in LDS: a fuller segment costs probes, not HBM traffic) ...
 			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ((nfine << target) * 8) + (1ULL << 30) > (uint64_t)free_b)
+			const bool no_room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && ((nfine << target) * 8) + (1ULL << 30) > (uint64_t)free_b + (c->seg_spare && c->seg_spare_shift >= target ? (nfine << c->seg_spare_shift) * 8 : 0);
+			if (no_room || target > BFCG_SEG_MAX_SHIFT) {
+				if (ovf == 0 && (double)c->h_stats[ST_KEYS] < 0.85 * (double)(nfine << P.seg_shift)) { c->seg_no_grow = 1; return 0; }
+				if (target > BFCG_SEG_MAX_SHIFT) return seg_to_legacy(c); // ... else the host's layout takes over (random CAS upserts, any size)
 				return set_err("count table of %llu keys cannot grow to 2^%d slots per region: %.1f GiB of device memory free", (unsigned long long)c->h_stats[ST_KEYS], target, free_b / 1073741824.0);
+			}
 		}
 		const int old_shift = P.seg_shift;
 		unsigned long long *nt = 0;
@@ -524,7 +543,8 @@ static int seg_maintain(bfcg_ctx_t *c)
 		if (((nfine << nt_shift) * 8) <= (16ULL << 30)) {
 			// the buffer left behind becomes the spare the NEXT growth rehashes into; one that is smaller than its successor could not
 			// take that growth after a reset: replace it now, so that from the second data set on a context never allocates
-			if (c->seg_cap_shift < nt_shift) { HIPCK(hipFree(B.seg_tab)); c->seg_spare = 0; if (hipMalloc(&c->seg_spare, (nfine << nt_shift) * 8) != hipSuccess) { (void)hipGetLastError(); c->seg_spare = 0; } c->seg_spare_shift = nt_shift; }
+			// (a fresh multi-GiB hipMalloc costs ~35 ms per GiB on this box: only contexts that are being reused pay for the second buffer)
+			if (c->seg_cap_shift < nt_shift && c->reused) { HIPCK(hipFree(B.seg_tab)); c->seg_spare = 0; if (hipMalloc(&c->seg_spare, (nfine << nt_shift) * 8) != hipSuccess) { (void)hipGetLastError(); c->seg_spare = 0; } c->seg_spare_shift = nt_shift; }
 			else { c->seg_spare = B.seg_tab; c->seg_spare_shift = c->seg_cap_shift; }
 		} else HIPCK(hipFree(B.seg_tab));
 		B.seg_tab = nt; c->seg_cap_shift = nt_shift;

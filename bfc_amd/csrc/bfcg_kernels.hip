@@ -1252,8 +1252,9 @@ __device__ __forceinline__ int seg_upsert(unsigned long long *seg, uint32_t mask
 {
 	const unsigned long long fresh = (id << 14) | (c < 255 ? c : 255) | ((uint64_t)(h < 63 ? h : 63) << 8);
 	uint32_t p = seg_home(id) & mask;
-	const uint32_t lim = mask < 255u ? mask : 255u; // a run of 256 occupied slots means the segment is (as good as) full: park, the host grows
-	for (uint32_t probe = 0; probe <= lim; ++probe, p = (p + 1) & mask) {
+	// (linear probing: among 5 G keys in segments half full the longest run of occupied slots passes 256 -- measured on config c4 -- so the
+	// probe sequence is bounded by the segment, not by a constant; a segment that is really full parks the k-mer and the host grows)
+	for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
 		unsigned long long cur = LDS ? __hip_atomic_load(&seg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&seg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (cur == 0) {
 			cur = atomicCAS(&seg[p], 0ULL, fresh);

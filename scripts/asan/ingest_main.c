@@ -48,7 +48,7 @@ int main(int argc, char **argv)
 		if (b.last) break;
 	}
 	printf("%llu %llu %llu %llx %llx %llx\n", (unsigned long long)out[0], (unsigned long long)out[1], (unsigned long long)out[2], (unsigned long long)hs, (unsigned long long)hq, (unsigned long long)hb);
-	free(b.seq); free(b.qual);
+	free(b.seq); free(b.qual); free(b.kind_cut);
 	ingest_close(&in);
 	return 0;
 }
