@@ -1652,7 +1652,11 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
-		hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+		// a CU's LDS holds 160 KB / segment size workgroups: keep its 2048 lanes busy whatever that number is (c4's 64 KiB segments at 256
+		// threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
+		if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
+		else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)8 << P.seg_shift, st, P, A);
+		else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
 	} else if (B.stream && B.stream_out && !P.track && P.n_hashes == 4) { // low-multiplicity batches: no aggregation (ctx decides, see bfcg_ctx.hip)
@@ -1724,6 +1728,8 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_commit_seg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_commit_seg<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
