@@ -41,6 +41,17 @@ def test_no_gpu_means_loud_failure(gpu_lib):
     assert "LOUD" in r.stdout and "no CPU fallback" in (r.stdout + r.stderr)
 
 
+def test_no_gpu_means_loud_failure_for_groups_too(gpu_lib):
+    """the multi-GPU entry (bfcg_group_create) has no CPU path either; the RCCL unique id needs no device"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import bfc_amd\n"
+            "try:\n    bfc_amd.GpuGroup(31, 26, [0, 0], max_batch_pos=1 << 20)\nexcept bfc_amd.BfcGpuError as e:\n    print('LOUD', e)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert "LOUD" in r.stdout and "no CPU fallback" in (r.stdout + r.stderr)
+
+
 def test_host_bloom_matches_oracle(gpu_lib):
     """bfc_bf_init/insert/get (bbf.c): same bits, same return values; bad shifts give NULL (bbf.c:9)."""
     L = oracle.lib()
