@@ -293,6 +293,11 @@ class GpuCounter:
         self.L.bfcg_table_info(self.ctx, out)
         return dict(segments=bool(out[0]), seg_shift=out[1], tab_cshift=out[2], seg_growths=out[3])
 
+    def partition_info(self):
+        out = (C.c_uint64 * 2)()
+        self.L.bfcg_partition_info(self.ctx, out)
+        return dict(one_pass=bool(out[0]), replayed_batches=int(out[1]))
+
     def last_batch_ms(self):
         out = np.zeros(6, dtype=np.float32)
         self.L.bfcg_last_batch_ms(self.ctx, out.ctypes.data_as(f32p))

@@ -70,6 +70,13 @@ struct bfcg_ctx {
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
 	uint64_t n_seg_grow;         // segment growths since creation
+	// one-pass level-1 partition (K1 once per batch; single-rank contexts).  A batch whose slabs overflow (few, often repeated k-mers) poisons itself and
+	// the batches behind it on the device; the host then replays them, in order, through the two-pass partition and stays there until the next reset.
+	int onepass_ok, onepass;     // the buffers exist / the current run still uses the one-pass partition
+	uint32_t *op_cursor[2], *op_seg[2], *op_flags, *h_flags[2];
+	uint32_t op_cap; uint64_t op_min_pos;
+	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
+	uint64_t n_replayed;
 	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
 	int seg_no_grow;             // the next segment size does not fit (memory / LDS): grow only when a segment overflows or the load passes 85 %
 	int seg_cap_shift;           // the allocation behind B.seg_tab holds segments of up to 2^seg_cap_shift slots
@@ -205,7 +212,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	{
 		const uint64_t tile = (uint64_t)bfcg_tile_of_rw(c->rw / 4);
 		const uint64_t tiles1 = (prm->max_batch_pos + tile - 1) / tile, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
-		const uint64_t rows2 = c->recv_cap / tile + nb1 + 1;
+		const uint64_t rows2 = c->recv_cap / tile + (uint64_t)nb1 * 8 + 1; // one ragged row per segment at most (one-pass level 1: 8 segments per bucket)
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->rows1[b], sizeof(uint32_t) * tiles1 * nb1));
 			HIPCKN(hipMalloc(&c->chunk1[b], sizeof(uint32_t) * chunks1 * nb1));
@@ -217,7 +224,26 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 			HIPCKN(hipMalloc(&B.start2, sizeof(uint32_t) * (nfine + 1)));
 		}
 	}
-	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], B.max_kmers * c->rw));
+	{ // one-pass level 1: 8 slabs per bucket, together 9/8 of the batch's positions (a stream holds ~0.8 k-mers per position: a quarter of head room)
+		const char *e = getenv("BFCG_ONEPASS");
+		c->onepass_ok = n_ranks == 1 && P.F2 > 0 && !(e && atoi(e) == 0); // level 2 gathers a bucket's slabs: filters of 2^26 bits and more
+		uint64_t cap = (B.max_kmers + B.max_kmers / 8) / ((uint64_t)nb1 * 8) + 1;
+		while (cap * nb1 * 8 > 0xffffffffULL) --cap;
+		c->op_cap = (uint32_t)cap;
+		// a slab should expect ~1000 records or more: below that its fill scatters by more than the head room, and the batch would be replayed
+		c->op_min_pos = (e = getenv("BFCG_ONEPASS_MIN_TILES")) ? (uint64_t)atoi(e) * 4096 : (uint64_t)nb1 * 8 * 1024;
+	}
+	const uint64_t recs1_n = c->onepass_ok ? (uint64_t)c->op_cap * nb1 * 8 : B.max_kmers;
+	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], recs1_n * c->rw));
+	if (c->onepass_ok) {
+		for (int b = 0; b < 2; ++b) {
+			HIPCKN(hipMalloc(&c->op_cursor[b], sizeof(uint32_t) * 8 * nb1 * 32));
+			HIPCKN(hipMalloc(&c->op_seg[b], sizeof(uint32_t) * ((size_t)25 * nb1 + 8)));
+			HIPCKN(hipHostMalloc(&c->h_flags[b], 2 * sizeof(uint32_t)));
+		}
+		HIPCKN(hipMalloc(&c->op_flags, 2 * sizeof(uint32_t)));
+		HIPCKN(hipMemset(c->op_flags, 0, 2 * sizeof(uint32_t)));
+	}
 	B.recs1 = c->recs1[0];
 	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw));
 	c->seg_words = (size_t)4 * nb1 + 8;
@@ -274,6 +300,8 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
+	for (int b = 0; b < 2; ++b) { (void)hipFree(c->op_cursor[b]); (void)hipFree(c->op_seg[b]); if (c->h_flags[b]) (void)hipHostFree(c->h_flags[b]); }
+	(void)hipFree(c->op_flags);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipHostFree(c->h_snap[0]); (void)hipHostFree(c->h_snap[1]); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -283,6 +311,8 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 }
 
 static int drain(bfcg_ctx_t *c);
+static int replay_poisoned(bfcg_ctx_t *c);
+static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats);
 
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
@@ -294,6 +324,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	// the statistics first: stage A of the next batch (stream stA) adds to them and only has to wait for that small memset; the
 	// filters and the table are touched by stage B alone, on this same stream, so zeroing them needs no host synchronisation
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
+	if (c->onepass_ok) HIPCK(hipMemsetAsync(c->op_flags, 0, 2 * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
 	HIPCK(hipEventRecord(c->evCopy, c->st));
 	HIPCK(hipStreamWaitEvent(c->stA, c->evCopy, 0));
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
@@ -326,6 +357,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
 	c->crowded_last = 0; c->stream_mode = c->P.seg ? 1 : 0;
 	c->cold = 1; c->seen_last = c->pos_final = 0; c->seg_no_grow = 0;
+	c->onepass = c->onepass_ok; c->n_opq = 0;
 	c->call_no = c->final_call = 0; c->call_depth = 0; memset(c->call_keys, 0, sizeof(c->call_keys));
 	return 0;
 }
@@ -397,6 +429,12 @@ static int drain(bfcg_ctx_t *c)
 	HIPCK(hipGetLastError());
 	c->pend = 0;
 	if (batch_times(c, c->cur ^ 1) != 0) return -1;
+	if (c->n_opq) { // batches that went through the one-pass partition: were their slabs large enough?
+		uint32_t fl[2] = {0, 0};
+		HIPCK(hipMemcpy(fl, c->op_flags, sizeof(fl), hipMemcpyDeviceToHost));
+		if (fl[1]) return replay_poisoned(c);
+		c->n_opq = 0;
+	}
 	if (fetch_stats(c) != 0) return -1;
 	c->final_call = c->call_no; c->call_keys[c->call_no & 63] = c->h_stats[ST_KEYS];
 	c->pos_final += c->slot_pos[0] + c->slot_pos[1]; c->slot_pos[0] = c->slot_pos[1] = 0;
@@ -405,6 +443,26 @@ static int drain(bfcg_ctx_t *c)
 }
 
 extern "C" int bfcg_sync(bfcg_ctx_t *c) { return drain(c); }
+
+// The one-pass partition gave up on a batch (a level-1 slab overflowed: few, often repeated k-mers): that batch and every batch enqueued behind it
+// changed NOTHING on the device (k_seg_setup handed level 2 empty segments).  The device is idle.  Replay them in order through the two-pass
+// partition -- their k-mers were counted the first time -- and stay with it until the next reset: the input is skewed.
+static int replay_poisoned(bfcg_ctx_t *c)
+{
+	const int n = c->n_opq;
+	bfcg_ctx::opq_t q[4];
+	for (int i = 0; i < n; ++i) q[i] = c->opq[i];
+	c->n_opq = 0; c->onepass = 0;
+	HIPCK(hipMemset(c->op_flags, 0, 2 * sizeof(uint32_t)));
+	if (fetch_stats(c) != 0) return -1;
+	c->n_batches -= (uint64_t)n; // the batches keep their places in the count (order stamps carry the batch number)
+	for (int i = 0; i < n; ++i) {
+		if (enqueue_batch(c, q[i].seq, q[i].qual, q[i].n_pos, 0, 1) != 0) return -1;
+		if (drain(c) != 0) return -1;
+		++c->n_replayed;
+	}
+	return 0;
+}
 
 // keys the next batch is expected to add: the smaller of the last two batches' additions (one batch alone says nothing:
 // the first batch of a high-coverage read set brings nearly all keys, the following ones almost none)
@@ -593,6 +651,10 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 	return table_maintain(c);
 }
 
+// partition of the current run: out[0] 1 = one-pass level 1 (K1 once per batch) still in use, out[1] batches replayed through the two-pass partition
+// since the context was created (a slab overflowed: few, often repeated k-mers)
+extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)c->onepass; out[1] = c->n_replayed; return 0; }
+
 extern "C" int bfcg_table_info(bfcg_ctx_t *c, int out[4])
 {
 	out[0] = c->P.seg; out[1] = c->P.seg ? c->P.seg_shift : 0; out[2] = c->P.seg ? 0 : c->P.tab_cshift; out[3] = (int)c->n_seg_grow;
@@ -695,6 +757,11 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 		const int pb = b ^ 1;
 		HIPCK(hipEventSynchronize(c->evB[pb]));
 		if (batch_times(c, pb) != 0) return -1;
+		if (c->n_opq && c->opq[0].slot == pb) { // the batch just finished went through the one-pass partition: clean?
+			if (c->h_flags[pb][1]) { c->pend = 1; c->cur = b ^ 1; return drain(c); } // a slab overflowed: drain() replays it and what was enqueued behind it
+			for (int i = 1; i < c->n_opq; ++i) c->opq[i - 1] = c->opq[i];
+			--c->n_opq;
+		}
 		fold_snapshot(c, pb); // the counters as they stood at the end of that batch's stage B (k-mer / high counts may include the next batch's stage A)
 		note_growth(c);
 		if (c->h_stats[ST_ERR_POOL] || c->h_stats[ST_TAB_OVF] || (c->P.seg ? seg_target_shift(c) != c->P.seg_shift : (c->B.table && table_target_cshift(c) != c->P.tab_cshift))) {
@@ -709,7 +776,7 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 // One batch, software-pipelined over two streams: stage A of this batch (ALU-bound K1) is enqueued on stA and runs
 // under stage B of the previous batch (LDS/latency-bound) on st.  The call returns once the PREVIOUS batch is
 // finalised (statistics read, table maintained); bfcg_sync / bfcg_stats / exports drain the pipeline.
-static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy = 0)
+static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats)
 {
 	const int b = c->cur, nb1 = 1 << c->P.F1;
 	BatchBufs Bt = c->B;
@@ -720,12 +787,25 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	if (!c->pipeline && wait_copy) HIPCK(hipStreamWaitEvent(sA, c->evCopy, 0)); // the host batch is being copied on stream stA
 	if (use_stream(c) != 0) return -1;
 	Bt.stream = c->stream_mode; Bt.stream_out = c->stream_out;
-	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
+	KParams Pt = c->P;
+	Pt.no_kstats = no_kstats;
+	const int op = c->onepass && !no_kstats && n_pos >= c->op_min_pos; // (a handful of tiles cannot fill 8 slabs per bucket evenly)
+	if (op) {
+		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags; Bt.op_cap = c->op_cap;
+		run_stage_a_onepass(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
+	} else run_stage_a(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
 	HIPCK(hipEventRecord(c->evA[b], sA));
 	HIPCK(hipStreamWaitEvent(c->st, c->evA[b], 0));
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
-	run_stage_b(c->P, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
+	if (op) {
+		uint32_t *sg = c->op_seg[b];
+		run_stage_b(Pt, Bt, Bt.recs1, sg, sg + 8 * nb1, 8 * nb1, 8, sg + 16 * nb1, sg + 24 * nb1 + 1, n_pos, c->st, c->evt[b]);
+		HIPCK(hipMemcpyAsync(c->h_flags[b], c->op_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
+		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
+		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; ++c->n_opq;
+	} else
+	run_stage_b(Pt, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
 	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
 	c->slot_call[b] = c->call_no; c->slot_pos[b] = n_pos;
 	HIPCK(hipEventRecord(c->evB[b], c->st));
@@ -806,7 +886,7 @@ extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const u
 		}
 		if (o) return o < n_pos ? bfcg_count_batch_dev(c, d_seq + o, d_qual ? d_qual + o : 0, n_pos - o) : 0;
 	}
-	int rc = enqueue_batch(c, d_seq, d_qual, n_pos);
+	int rc = enqueue_batch(c, d_seq, d_qual, n_pos, 0, 0);
 	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c); // debug aids want one batch at a time
 	return rc;
 }
@@ -835,7 +915,7 @@ extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const 
 	HIPCK(hipMemcpyAsync(c->d_seq2[b], h_seq, n_pos, hipMemcpyHostToDevice, c->stA)); // ordered behind stage A of two batches ago (same stream)
 	if (h_qual) HIPCK(hipMemcpyAsync(c->d_qual2[b], h_qual, n_pos, hipMemcpyHostToDevice, c->stA));
 	HIPCK(hipEventRecord(c->evCopy, c->stA));
-	int rc = enqueue_batch(c, c->d_seq2[b], h_qual ? c->d_qual2[b] : NULL, n_pos, 1);
+	int rc = enqueue_batch(c, c->d_seq2[b], h_qual ? c->d_qual2[b] : NULL, n_pos, 1, 0);
 	HIPCK(hipEventSynchronize(c->evCopy)); // the caller may reuse its host buffers now
 	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c);
 	return rc;

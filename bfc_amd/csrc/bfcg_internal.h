@@ -34,6 +34,7 @@ struct KParams {
 	int seg_shift;              // log2 slots per segment
 	int seg_lo, seg_hi;         // bits [seg_lo, seg_hi) of y0 are implied by the region (kmer_dev.h: SegGeom)
 	uint32_t f_base;            // global id of this rank's first bloom region
+	int no_kstats;              // stage A does not count k-mers / high-quality k-mers (a batch that is replayed was counted the first time)
 	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
 };
 
@@ -50,12 +51,17 @@ struct BatchBufs {
 	uint8_t *seen_out;
 	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
 	uint32_t *stream_out; int stream;     // STREAM mode: seen k-mers as records (k_bloom -> k_commit_stream); on / off for this batch
+	// one-pass level 1 (K1 once per batch): 8 slabs of op_cap records per level-1 bucket in recs1, their cursors (one per 128-byte line), the overflow /
+	// poison flags, and the segment arrays level 2 reads them through: seg_beg[8 nb1] | seg_end[8 nb1] | row_base[8 nb1 + 1] | bucket_start[nb1 + 1]
+	uint32_t *op_cursor, *op_flags, *op_seg; uint32_t op_cap;
 	unsigned long long *seg_tab;              // region-owned table segments: [regions][2^seg_shift] slots of id << 14 | high << 8 | count (KParams.seg)
 	unsigned long long *tab_first, *sub_last; // order stamps (NULL unless KParams.track)
 	unsigned long long batch_hi;              // batch number << 32
 };
 
 void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev);
+// one-pass stage A: K1 + level-1 scatter into the slabs of B.recs1 + the segment arrays of B.op_seg (no histogram pass); ev as run_stage_a
+void run_stage_a_onepass(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev);
 void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
                  const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev);
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(BT) void k_hist1(KParams P, const uint8_t *__restri
 	}
 	// statistics: k-mers, high-quality k-mers
 	for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
-	if ((threadIdx.x & 63) == 0) {
+	if ((threadIdx.x & 63) == 0 && !P.no_kstats) {
 		unsigned long long *sl = stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 		atomicAdd(&sl[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl[ST_HIGH], (unsigned long long)n_h);
 	}
@@ -338,9 +338,17 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t *cnt, int nb, uint3
 
 // pass B: K1 again; the tile's records are ordered by level-1 bucket in LDS and copied out run by run with
 // neighbouring lanes (coalesced stores), at rows1[tile][bucket] (absolute offsets after the scan).
-template <typename W, int RW, int TILE, int BT>
+// ONEPASS: no histogram pass at all (K1 runs ONCE per batch).  The output is not one contiguous run per bucket but 8 SLABS per bucket, one per
+// XCD (workgroups are dealt to the XCDs round-robin: blockIdx & 7), each of `cap` records: a tile reserves room for its bucket runs with one
+// returning atomicAdd per bucket on the slab's cursor -- 8 x 2^F1 cursors on cache lines of their own, so that the chains of same-address
+// atomics (~12 ns each) are 8 x 2^F1 wide -- and level 2 reads a bucket as its 8 segments (the machinery multi-GPU runs use for the sources'
+// blocks).  Uniform hashing fills a slab to its mean +- a fraction of a per cent; a batch of few, often repeated k-mers overflows one:
+// the kernel then raises `flags[0]`, k_seg_setup turns that batch and everything behind it into no-ops (sticky flags[1]) and the host
+// replays those batches through the two-pass partition (bfcg_ctx.hip: replay_poisoned).
+struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; };
+template <typename W, int RW, int TILE, int BT, bool ONEPASS = false>
 __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
-                                                 int64_t n_pos, const uint32_t *__restrict__ rows1, uint32_t *__restrict__ out)
+                                                 int64_t n_pos, const uint32_t *__restrict__ rows1, uint32_t *__restrict__ out, OnePass OP)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	constexpr int S = TILE / BT;
@@ -365,6 +373,7 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 	__syncthreads();
 	RecW<RW> w[S];
 	uint32_t br[S]; // bucket << 16 | rank inside (tile, bucket)
+	uint32_t n_k = 0, n_h = 0;
 #pragma unroll
 	for (int j = 0; j < S; ++j) {
 		const int r = j * BT + threadIdx.x;
@@ -375,6 +384,14 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 			const uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
 			Rec<RW>::pack(w[j], RG, (uint64_t)y0, (uint64_t)y1, idx, hi);
 			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+			if (ONEPASS) { ++n_k; n_h += hi; }
+		}
+	}
+	if (ONEPASS) { // the statistics k_hist1 keeps in the two-pass partition: k-mers, high-quality k-mers
+		for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
+		if ((threadIdx.x & 63) == 0 && n_k) {
+			unsigned long long *sl = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+			atomicAdd(&sl[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl[ST_HIGH], (unsigned long long)n_h);
 		}
 	}
 	__syncthreads();
@@ -382,7 +399,20 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 		const uint32_t tot = block_scan_excl<BT>(cnt, nb1, wsum1);
 		if (threadIdx.x == 0) s_total = tot;
 		__syncthreads();
-		for (int i = threadIdx.x; i < nb1; i += BT) gdelta[i] = rows1[tile * nb1 + i] - cnt[i]; // global record index = staged position + gdelta[bucket] (u32 modular)
+		if (!ONEPASS) {
+			for (int i = threadIdx.x; i < nb1; i += BT) gdelta[i] = rows1[tile * nb1 + i] - cnt[i]; // global record index = staged position + gdelta[bucket] (u32 modular)
+		} else {
+			const uint32_t xcd = blockIdx.x & 7u;
+			for (int i = threadIdx.x; i < nb1; i += BT) {
+				const uint32_t ex = cnt[i], c = (i + 1 < nb1 ? cnt[i + 1] : tot) - ex;
+				uint32_t base = 0;
+				if (c) {
+					base = atomicAdd(&OP.cursor[((size_t)xcd * nb1 + i) * 32], c);
+					if (base + c > OP.cap) { OP.flags[0] = 1; base = 0; } // the slab is full: this batch will be replayed; meanwhile write where it does no harm
+				}
+				gdelta[i] = ((uint32_t)i * 8u + xcd) * OP.cap + base - ex;
+			}
+		}
 	}
 	__syncthreads();
 #pragma unroll
@@ -550,6 +580,49 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
 		rec_store<RW>(out + dst * RW, rec);
 	}
+}
+
+// ONEPASS: the level-1 output as segments for level 2.  One workgroup.  seg (bucket b, XCD x) = slab (b * 8 + x) of `cap` records, filled
+// up to its cursor; row_base = first level-2 histogram row of every segment; bucket_start = the buckets' starts in the level-2 output.
+// A batch whose slabs overflowed (flags[0]) -- and, the flag being sticky (flags[1]), every batch behind it -- gets empty segments:
+// level 2, the bloom kernel and the table stage then change nothing, and the host replays those batches in order (two-pass partition).
+__global__ __launch_bounds__(1024) void k_seg_setup(KParams P, const uint32_t *__restrict__ cursor, uint32_t cap, uint32_t *flags, int tile2,
+                                                    uint32_t *__restrict__ seg_beg, uint32_t *__restrict__ seg_end, uint32_t *__restrict__ row_base,
+                                                    uint32_t *__restrict__ bucket_start)
+{
+	__shared__ uint32_t s_rows[1024], s_recs[1024];
+	__shared__ uint32_t s_poison;
+	const int nb1 = 1 << P.F1, t = threadIdx.x;
+	if (t == 0) { if (flags[0]) { flags[1] = 1; flags[0] = 0; } s_poison = flags[1]; }
+	__syncthreads();
+	const bool poison = s_poison != 0;
+	// thread t owns bucket t (nb1 <= 1024): its 8 segments
+	uint32_t len[8], rows = 0, recs = 0;
+#pragma unroll
+	for (int x = 0; x < 8; ++x) {
+		uint32_t l = 0;
+		if (t < nb1 && !poison) { l = cursor[((size_t)x * nb1 + t) * 32]; if (l > cap) l = cap; }
+		len[x] = l; rows += (l + tile2 - 1) / tile2; recs += l;
+	}
+	s_rows[t] = rows; s_recs[t] = recs;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) { // inclusive scans over the buckets
+		const uint32_t a = t >= o ? s_rows[t - o] : 0, b = t >= o ? s_recs[t - o] : 0;
+		__syncthreads();
+		s_rows[t] += a; s_recs[t] += b;
+		__syncthreads();
+	}
+	if (t < nb1) {
+		uint32_t r = s_rows[t] - rows;
+		bucket_start[t] = s_recs[t] - recs;
+#pragma unroll
+		for (int x = 0; x < 8; ++x) {
+			const uint32_t seg = (uint32_t)t * 8u + x, beg = seg * cap;
+			seg_beg[seg] = beg; seg_end[seg] = beg + len[x]; row_base[seg] = r;
+			r += (len[x] + tile2 - 1) / tile2;
+		}
+	}
+	if (t == nb1 - 1) { row_base[(size_t)nb1 * 8] = s_rows[t]; bucket_start[nb1] = s_recs[t]; }
 }
 
 __device__ __forceinline__ SegGeom seg_geom(const KParams &P) { SegGeom g; g.k = P.k; g.lo = P.seg_lo; g.hi = P.seg_hi; return g; }
@@ -1615,7 +1688,25 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, T2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1);
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr});
+	if (ev) hipEventRecord(ev[2], st);
+}
+
+// one-pass stage A (K1 once): cursors cleared, K1 + level-1 scatter into the slabs, the slabs described as segments for level 2
+template <typename W, int RW>
+static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
+{
+	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2;
+	const int nb1 = 1 << P.F1;
+	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
+	if (ev) hipEventRecord(ev[0], st);
+	hipMemsetAsync(B.op_cursor, 0, (size_t)8 * nb1 * 32 * sizeof(uint32_t), st);
+	if (ev) hipEventRecord(ev[1], st);
+	const unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8);
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st,
+	                   P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OnePass{B.op_cursor, B.op_cap, B.op_flags, B.stats});
+	uint32_t *sg = B.op_seg;
+	hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, st, P, B.op_cursor, B.op_cap, B.op_flags, T2, sg, sg + 8 * nb1, sg + 16 * nb1, sg + 24 * nb1 + 1);
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1696,6 +1787,9 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
 { DISPATCH_W(run_stage_a_t, P, B, seq, qual, n_pos, (uint32_t *)out1, st, ev); }
 
+void run_stage_a_onepass(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
+{ DISPATCH_W(run_stage_a_onepass_t, P, B, seq, qual, n_pos, (uint32_t *)out1, st, ev); }
+
 void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
                  const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev)
 { DISPATCH_W(run_stage_b_t, P, B, (const uint32_t *)in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, bucket_start, n_rec_bound, st, ev); }
@@ -1718,6 +1812,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	hipError_t e;
 	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

@@ -84,6 +84,7 @@ def test_c2_full_read_set(gpu_lib, batch_reads, layout):
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], batch_reads, table_layout=layout)
     assert g.table_info()["segments"] == (layout == 0)  # c2's geometry takes the region-owned table segments (46 identity bits)
     _check_against(g, e)
+    assert g.partition_info() == dict(one_pass=True, replayed_batches=0)  # K1 once per batch, no slab overflow on uniformly hashed k-mers
     g.close()
 
 
@@ -97,6 +98,7 @@ def test_c3_full_read_set(gpu_lib):
     assert ti["segments"] and ti["seg_growths"] >= 1, ti  # 48 identity bits; the segments grow with the 300 M keys
     st = _check_against(g, e)
     assert st["stream_batches"] > 0, "c3 is expected to run (mostly) without in-LDS aggregation"
+    assert g.partition_info() == dict(one_pass=True, replayed_batches=0)
     g.close()
 
 
@@ -133,3 +135,39 @@ def test_c5_parameters(gpu_lib):
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_000_000, filter_mode=1)
     _check_against(g, e)
     g.close()
+
+
+@pytest.mark.parametrize("fm", [0, 1])
+def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm):
+    """Input with few, often repeated k-mers (300 000 reads of a 400-base genome, -b30): the one-pass partition's slabs overflow, the batch
+    and the one behind it change nothing on the device, the library replays both through the two-pass partition -- results are the oracle's,
+    statistics counted once, and the rest of the run stays two-pass."""
+    rng = np.random.default_rng(77 + fm)
+    G, L, n = 400, 150, 300_000
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), G + L)
+    pos = rng.integers(0, G, n)
+    seq = genome[(pos[:, None] + np.arange(L)[None, :])].astype(np.uint8)
+    err = rng.random(seq.shape) < 0.01
+    seq[err] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(err.sum()))]
+    seq = seq.reshape(-1)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    k, b = 31, 30
+    oc = oracle.Counter(k, b, filter_mode=fm)
+    oc.count(seq, qual, off)
+    g = gpu_lib.GpuCounter(k, b, filter_mode=fm, max_batch_pos=(n // 3 + 1) * (L + 1) + 64)
+    for a in range(0, n, n // 3 + 1):
+        e = min(n, a + n // 3 + 1)
+        g.count_host(gen.to_stream(seq[a * L:e * L], L, 10), gen.to_stream(qual[a * L:e * L], L, 33))
+    st, ost = g.stats(), oc.stats()
+    pi = g.partition_info()
+    assert pi["replayed_batches"] >= 1 and not pi["one_pass"], pi
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    if fm:
+        assert np.array_equal(g.bloom_bytes(1), oc.bloom_bytes(True))
+    else:
+        sizes, slots = g.export_table().export_sorted()
+        osz, osl = oc.export()
+        assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.close(); oc.close()
