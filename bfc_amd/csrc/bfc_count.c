@@ -288,3 +288,36 @@ int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_t
 	ingest_close(&in);
 	return 0;
 }
+
+/* The parallel inflate alone (bfc_pgz.h; no GPU, no parser): the whole of `fn` in windows of `window` bytes.  out[0] text bytes,
+ * out[1] their CRC-32, out[2] pieces taken as the threads guessed them, out[3] pieces decoded again from the known position,
+ * out[4] rounds.  Returns 0, -1 if the file cannot be mapped or is not gzip, -2 if the stream cannot be decoded (bfc_count then reads
+ * it through gzread). */
+int bfc_pgz_digest(const char *fn, int n_threads, uint64_t chunk, uint64_t window, uint64_t out[5])
+{
+	struct stat st;
+	int fd = open(fn, O_RDONLY), rc = 0;
+	void *m;
+	pgz_t *g;
+	uint64_t pos = 0;
+	uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+	memset(out, 0, 5 * sizeof(uint64_t));
+	if (fd < 0) return -1;
+	if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) { close(fd); return -1; }
+	m = mmap(0, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (m == MAP_FAILED) return -1;
+	if (((const uint8_t*)m)[0] != 0x1f || ((const uint8_t*)m)[1] != 0x8b) { munmap(m, (size_t)st.st_size); return -1; }
+	g = pgz_open((const uint8_t*)m, (size_t)st.st_size, n_threads, (size_t)chunk);
+	for (;;) {
+		const uint8_t *p; uint64_t avail, o; int eof;
+		if (pgz_ensure(g, pos, window, &p, &avail, &eof) != 0) { rc = -2; break; }
+		for (o = pos; o < avail;) { const uint64_t step = avail - o < (1u << 30) ? avail - o : (1u << 30); crc = (uint32_t)crc32(crc, p + o, (uInt)step); o += step; }
+		pos = avail;
+		if (eof) break;
+	}
+	out[0] = pos; out[1] = crc; out[2] = g->n_spec; out[3] = g->n_redo; out[4] = g->n_rounds;
+	pgz_close(g);
+	munmap(m, (size_t)st.st_size);
+	return rc;
+}

@@ -16,6 +16,7 @@ typedef struct {
 	gzFile fp;
 	uint8_t *buf; int begin, end, eof;
 	uint64_t total;  /* bytes delivered by gzread so far */
+	int first_piece; /* size of the next gzread if it is not RD_PIECE */
 	uint8_t *line; size_t l_line, m_line;
 	int line_nl;     /* the line just read ended with '\n' (0: the input ended first) */
 	int pending;     /* a header line already read into `line`; hdr_at = index of its '>' / '@' */
@@ -23,14 +24,21 @@ typedef struct {
 } reader_t;
 
 #define RD_BUF (1 << 20)
+#define RD_PIECE 16384
 
 static inline int rd_fill(reader_t *r)
 {
 	if (r->eof) return 0;
-	r->begin = 0;
-	r->end = gzread(r->fp, r->buf, RD_BUF);
-	if (r->end < RD_BUF) r->eof = 1;
-	if (r->end < 0) r->end = 0;
+	r->begin = 0; r->end = 0;
+	/* gzread in kseq's own pieces (kseq.h:72-74,104-106: 16384 bytes a call, a short or failed read ends the input): what zlib hands out
+	 * before it reports a damaged gzip stream depends on the sizes it is asked for */
+	while (r->end + RD_PIECE <= RD_BUF) {
+		const int want = r->first_piece ? r->first_piece : RD_PIECE; /* behind a seek: up to kseq's next buffer boundary */
+		const int n = gzread(r->fp, r->buf + r->end, (unsigned)want);
+		r->first_piece = 0;
+		if (n > 0) r->end += n;
+		if (n < want) { r->eof = 1; break; }
+	}
 	r->total += (uint64_t)r->end;
 	return r->end;
 }
@@ -167,6 +175,7 @@ static inline int next_record(parser_t *ps)
  * does not chain) sends this batch and the rest of the file through the serial parser above, from the window start.  The threads then
  * copy their records into the batch at offsets known from the per-thread totals. */
 #include <pthread.h>
+#include "bfc_pgz.h"
 
 typedef struct { uint64_t hdr; uint32_t len, seq_delta; } fq_rec_t; /* '@' position in the file; bases (CR stripped); sequence line - '@' */
 
@@ -256,6 +265,8 @@ static void *fq_copy(void *arg)
 
 typedef struct {
 	const uint8_t *map; uint64_t size, pos; /* pos: next record boundary */
+	pgz_t *gz;             /* gzip input: `map` is the text the parallel inflate (bfc_pgz.h) holds from `pos` on, `size` unknown until its end */
+	const uint8_t *zmap; uint64_t zsize; /* the mapped .gz file */
 	int n_threads, active;
 	uint64_t min_slice;    /* bytes a thread's slice has at least (65536; tests lower it to chain walks inside small files) */
 	double bytes_per_base; /* of the batches so far: sizes the next window */
@@ -279,10 +290,17 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 	const uint64_t pos0 = f->pos;
 	batch_clear(b);
 	for (;;) {
-		const uint64_t wend = f->pos + win < f->size ? f->pos + win : f->size;
-		const int at_eof = wend == f->size;
+		uint64_t wend = f->pos + win < f->size ? f->pos + win : f->size;
+		int at_eof = wend == f->size;
 		int T = f->n_threads, i, n_used = 0, cut = 0, bad = 0;
 		uint64_t slice, cur = f->pos, bases = 0, npos = 0, nseq = 0;
+		if (f->gz) { /* inflate until the window is there (or the input ends) */
+			uint64_t avail; int eof;
+			if (pgz_ensure(f->gz, f->pos, win, &f->map, &avail, &eof) != 0) return 0; /* damaged gzip: gzread decides what the reference would see */
+			if (eof) f->size = avail;
+			wend = f->pos + win < avail ? f->pos + win : avail; at_eof = eof && wend == avail;
+			if (f->pos == 0 && wend > 0 && f->map[0] != '@') return 0;
+		}
 		if (wend - f->pos < (uint64_t)T * f->min_slice) T = 1;
 		slice = (wend - f->pos + T - 1) / T;
 		for (i = 0; i < T; ++i) {
@@ -408,7 +426,6 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 	in->workers = workers < 1 ? 1 : workers;
 	in->ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
 	if (in->ps.rd.fp == 0) return -1;
-	gzbuffer(in->ps.rd.fp, 1 << 18);
 	in->ps.rd.buf = (uint8_t*)malloc(RD_BUF);
 	if (n_threads > 0 && fn && strcmp(fn, "-")) { /* a regular, uncompressed file that starts like a FASTQ: map it */
 		struct stat st;
@@ -417,7 +434,17 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 			void *m = mmap(0, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
 			if (m != MAP_FAILED) {
 				const uint8_t *p = (const uint8_t*)m;
-				if (p[0] == '@' && !(p[0] == 0x1f && p[1] == 0x8b)) {
+				if (p[0] == 0x1f && p[1] == 0x8b && (uint64_t)st.st_size >= (getenv("BFC_INGEST_GZ_MIN") ? strtoull(getenv("BFC_INGEST_GZ_MIN"), 0, 10) : (uint64_t)1 << 20)) {
+					/* gzip: the same chained walks over text that several threads inflate (bfc_pgz.h) */
+					(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+					in->fast.zmap = p; in->fast.zsize = (uint64_t)st.st_size;
+					in->fast.n_threads = n_threads > FQ_MAX_THREADS ? FQ_MAX_THREADS : n_threads;
+					in->fast.gz = pgz_open(p, (size_t)st.st_size, in->fast.n_threads, getenv("BFC_INGEST_GZ_CHUNK") ? strtoull(getenv("BFC_INGEST_GZ_CHUNK"), 0, 10) : (size_t)2 << 20);
+					in->fast.map = 0; in->fast.size = ~(uint64_t)0; in->fast.pos = 0; in->fast.active = 1;
+					in->fast.min_slice = getenv("BFC_INGEST_MIN_SLICE") ? strtoull(getenv("BFC_INGEST_MIN_SLICE"), 0, 10) : 65536;
+					if (in->fast.min_slice < 16) in->fast.min_slice = 16;
+					in->fast.job = (fq_job_t*)calloc((size_t)in->fast.n_threads, sizeof(fq_job_t));
+				} else if (p[0] == '@') {
 					(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
 					in->fast.map = p; in->fast.size = (uint64_t)st.st_size; in->fast.pos = 0; in->fast.active = 1;
 					in->fast.n_threads = n_threads > FQ_MAX_THREADS ? FQ_MAX_THREADS : n_threads;
@@ -439,7 +466,9 @@ static inline void ingest_fill(ingest_t *in, batch_t *b)
 		if (fq_fill_batch(&in->fast, b, in->ps.chunk_size)) { if (b->n_seqs) ++in->fast_batches; done = 1; }
 		else {
 			in->fast.active = 0; /* not strict 4-line FASTQ from here on: the serial parser takes over at the last record boundary */
+			if (in->fast.gz) { pgz_close(in->fast.gz); in->fast.gz = 0; in->fast.map = 0; } /* (for gzip input zlib inflates up to there again) */
 			gzseek(in->ps.rd.fp, (z_off_t)in->fast.pos, SEEK_SET);
+			in->ps.rd.total = in->fast.pos; in->ps.rd.first_piece = RD_PIECE - (int)(in->fast.pos % RD_PIECE);
 		}
 	}
 	if (!done) { fill_batch(&in->ps, b); if (b->n_seqs) ++in->serial_batches; }
@@ -450,7 +479,9 @@ static inline void ingest_fill(ingest_t *in, batch_t *b)
 static inline void ingest_close(ingest_t *in)
 {
 	int i;
-	if (in->fast.map) munmap((void*)in->fast.map, (size_t)in->fast.size);
+	if (in->fast.gz) pgz_close(in->fast.gz);
+	if (in->fast.zmap) munmap((void*)in->fast.zmap, (size_t)in->fast.zsize);
+	else if (in->fast.map) munmap((void*)in->fast.map, (size_t)in->fast.size);
 	if (in->fast.job) { for (i = 0; i < in->fast.n_threads; ++i) free(in->fast.job[i].rec); free(in->fast.job); }
 	gzclose(in->ps.rd.fp);
 	free(in->ps.rd.buf); free(in->ps.rd.line); free(in->ps.seq); free(in->ps.qual); free(in->ps.hdr); free(in->ps.cmt);

@@ -209,6 +209,12 @@ bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (calle
  * [3]/[4] FNV-1a of all sequence / quality streams, [5] FNV-1a of the per-batch read counts, [6] batches parsed by the multi-threaded
  * fast path (uncompressed strict 4-line FASTQ; n_threads = 0 forces the serial parser).  Used to test that both parsers agree. */
 int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, uint64_t out[7]);
+/* gzip input (bseq.c:33-50 reads it through one gzread stream): bfc_count inflates a regular .gz file with n_threads threads -- guessed
+ * block starts, 16-bit symbols with markers for the unknown 32 KiB window, pieces chained only where one started exactly where its
+ * predecessor stopped, CRC-32 / ISIZE of every member checked (bfc_pgz.h); anything it cannot decode goes through gzread.  This runs that
+ * inflate alone over `fn` in windows of `window` bytes with compressed chunks of `chunk` bytes: out[0] text bytes, [1] their CRC-32,
+ * [2] pieces taken as guessed, [3] pieces decoded again from the chain position, [4] rounds.  0 / -1 not a mappable gzip file / -2 damaged. */
+int bfc_pgz_digest(const char *fn, int n_threads, uint64_t chunk, uint64_t window, uint64_t out[5]);
 
 /* Union of the per-GPU tables of an owner-computes run (disjoint key sets: the union is the reference's table); order stamps travel
  * along, so that bfc_ch_dump of the union is byte-identical to `bfc -t1 -d` across GPUs too.  NULL if k / l_pre differ. */
