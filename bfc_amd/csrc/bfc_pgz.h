@@ -198,7 +198,7 @@ static inline void pgz_fixed_tabs(pgz_tabs_t *t)
  * window is known, markers 0x8000|i when it is not) */
 typedef struct { uint64_t at; uint32_t crc, isize; } pgz_mend_t; /* a gzip member ended after `at` symbols of the piece */
 typedef struct {
-	uint16_t *sym; size_t n, cap; /* n counts the prefix */
+	uint16_t *sym; size_t n, cap, cap0; /* n counts the prefix; cap0: first allocation */
 	size_t floor;                 /* symbols before this index do not exist for back references (a gzip member started there) */
 	pgz_mend_t *mend; int n_mend, m_mend;
 	uint64_t start, end; int start_kind, end_kind; /* chain positions in bits */
@@ -209,9 +209,10 @@ typedef struct {
 static inline int pgz_piece_room(pgz_piece_t *pc, size_t more)
 {
 	if (pc->n + more > pc->cap) {
-		size_t nc = pc->cap ? pc->cap * 2 : (size_t)1 << 20;
+		size_t nc = pc->cap ? pc->cap * 2 : pc->cap0 > ((size_t)1 << 20) ? pc->cap0 : (size_t)1 << 20;
 		uint16_t *ns;
 		while (nc < pc->n + more) nc *= 2;
+		if (nc > ((size_t)1 << 31)) return -1; /* a piece of more than 2 G symbols: gzread's business */
 		if ((ns = (uint16_t*)realloc(pc->sym, nc * sizeof(uint16_t))) == 0) return -1;
 		pc->sym = ns; pc->cap = nc;
 	}
@@ -388,7 +389,7 @@ struct pgz_s {
 	uint8_t win[PGZ_WIN]; int win_len;     /* text before it (right-aligned) */
 	uint32_t run_crc; uint64_t run_len;    /* of the current member so far */
 	int eof, err;
-	uint8_t *text; uint64_t text_off, text_len, text_cap;
+	uint8_t *text; uint64_t text_off, text_len, text_cap, text_head; /* the text held is text[text_head, text_head + text_len), stream offset text_off */
 	pgz_job_t *job; pgz_job_t *redo;       /* redo: the one that decodes again what did not chain */
 	uint64_t n_spec, n_redo, n_rounds;     /* pieces taken as guessed / decoded again */
 };
@@ -464,7 +465,7 @@ static inline pgz_t *pgz_open(const uint8_t *z, size_t zlen, int n_threads, size
 	g->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
 	g->job = (pgz_job_t*)calloc((size_t)g->T + 1, sizeof(pgz_job_t));
 	g->redo = &g->job[g->T];
-	for (i = 0; i <= g->T; ++i) { g->job[i].g = g; g->job[i].idx = i; }
+	for (i = 0; i <= g->T; ++i) { g->job[i].g = g; g->job[i].idx = i; g->job[i].pc.cap0 = PGZ_WIN + g->chunk * 6; }
 	return g;
 }
 
@@ -496,12 +497,16 @@ static inline void pgz_next_window(const pgz_piece_t *pc, const uint8_t *win, in
 
 static inline int pgz_text_room(pgz_t *g, uint64_t more)
 {
-	if (g->text_len + more > g->text_cap) {
-		uint64_t nc = g->text_cap ? g->text_cap : (uint64_t)1 << 24;
-		uint8_t *nt;
-		while (nc < g->text_len + more) nc += nc < ((uint64_t)1 << 30) ? nc : (uint64_t)1 << 30;
-		if ((nt = (uint8_t*)realloc(g->text, nc)) == 0) return -1;
-		g->text = nt; g->text_cap = nc;
+	if (g->text_head + g->text_len + more > g->text_cap) {
+		if (g->text_head) { memmove(g->text, g->text + g->text_head, (size_t)g->text_len); g->text_head = 0; } /* what the parser has taken goes first */
+		if (g->text_len + more > g->text_cap) {
+			uint64_t nc = g->text_cap ? g->text_cap : (uint64_t)1 << 24;
+			uint8_t *nt;
+			while (nc < g->text_len + more) nc += nc < ((uint64_t)1 << 30) ? nc : (uint64_t)1 << 30;
+			nc += nc / 2; /* so that a window's worth of taken text can usually stay where it is */
+			if ((nt = (uint8_t*)realloc(g->text, nc)) == 0) return -1;
+			g->text = nt; g->text_cap = nc;
+		}
 	}
 	return 0;
 }
@@ -564,7 +569,7 @@ static inline int pgz_round(pgz_t *g)
 	}
 	if (pgz_text_room(g, total) != 0) { g->err = 1; return -1; }
 	at = g->text_len;
-	for (i = 0; i < T; ++i) if (g->job[i].take) { g->job[i].dst = g->text + at; at += g->job[i].pc.n - PGZ_WIN; }
+	for (i = 0; i < T; ++i) if (g->job[i].take) { g->job[i].dst = g->text + g->text_head + at; at += g->job[i].pc.n - PGZ_WIN; }
 	pgz_par(g, pgz_narrow_job, T);
 	for (i = 0; i < T; ++i) if (g->job[i].take && pgz_account(g, &g->job[i]) != 0) { g->err = 1; return -1; }
 	g->text_len = at;
@@ -583,12 +588,12 @@ static inline int pgz_ensure(pgz_t *g, uint64_t pos, uint64_t want, const uint8_
 	if (pos > g->text_off) {
 		const uint64_t d = pos - g->text_off;
 		if (d > g->text_len) return -1;
-		memmove(g->text, g->text + d, (size_t)(g->text_len - d));
-		g->text_len -= d; g->text_off = pos;
+		g->text_head += d; g->text_len -= d; g->text_off = pos;
+		if (g->text_len == 0) g->text_head = 0;
 	}
 	while (!g->eof && g->text_len < want) if (pgz_round(g) != 0) return -1;
 	if (g->err) return -1;
-	*p = g->text - g->text_off; *avail_end = g->text_off + g->text_len; *eof = g->eof;
+	*p = g->text + g->text_head - g->text_off; *avail_end = g->text_off + g->text_len; *eof = g->eof;
 	return 0;
 }
 

@@ -23,6 +23,12 @@ def test_ingest_under_asan():
     assert r.returncode == 0 and "problems: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_parallel_inflate_under_asan():
+    _build(os.path.join(ROOT, "build", "asan_pgz"), [os.path.join(ROOT, "scripts", "asan", "pgz_main.c")])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "asan", "run_pgz.py"), "26"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "problems: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_host_api_under_asan(tmp_path):
     exe = os.path.join(ROOT, "build", "asan_host")
     _build(exe, [os.path.join(ROOT, "scripts", "asan", "host_main.c"), os.path.join(ROOT, "bfc_amd", "csrc", "bfc_host.c")])
