@@ -296,7 +296,7 @@ class GpuCounter:
     def partition_info(self):
         out = (C.c_uint64 * 2)()
         self.L.bfcg_partition_info(self.ctx, out)
-        return dict(one_pass=bool(out[0]), replayed_batches=int(out[1]))
+        return dict(one_pass=bool(out[0] & 1), level2_one_pass=bool(out[0] & 2), replayed_batches=int(out[1]))
 
     def last_batch_ms(self):
         out = np.zeros(6, dtype=np.float32)

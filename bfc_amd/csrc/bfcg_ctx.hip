@@ -75,6 +75,7 @@ struct bfcg_ctx {
 	int onepass_ok, onepass;     // the buffers exist / the current run still uses the one-pass partition
 	uint32_t *op_cursor[2], *op_seg[2], *op_flags, *h_flags[2];
 	uint32_t op_cap; uint64_t op_min_pos;
+	uint32_t *cnt2; uint32_t cap2; uint64_t recs2_n; // one-pass level 2 (region slabs); records recs2 / stream_out hold
 	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
 	uint64_t n_replayed;
 	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
@@ -239,13 +240,22 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->op_cursor[b], sizeof(uint32_t) * 8 * nb1 * 32));
 			HIPCKN(hipMalloc(&c->op_seg[b], sizeof(uint32_t) * ((size_t)25 * nb1 + 8)));
-			HIPCKN(hipHostMalloc(&c->h_flags[b], 2 * sizeof(uint32_t)));
+			HIPCKN(hipHostMalloc(&c->h_flags[b], 4 * sizeof(uint32_t)));
 		}
-		HIPCKN(hipMalloc(&c->op_flags, 2 * sizeof(uint32_t)));
-		HIPCKN(hipMemset(c->op_flags, 0, 2 * sizeof(uint32_t)));
+		HIPCKN(hipMalloc(&c->op_flags, 4 * sizeof(uint32_t)));
+		HIPCKN(hipMemset(c->op_flags, 0, 4 * sizeof(uint32_t)));
 	}
 	B.recs1 = c->recs1[0];
-	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recv_cap * c->rw));
+	c->recs2_n = c->recv_cap;
+	if (c->onepass_ok) { // level 2 in one pass too: a slab per region, 9/8 of the mean of a full batch's positions + 64 records (k-mers are ~0.8 of the positions)
+		const char *e = getenv("BFCG_ONEPASS2");
+		const uint64_t cap2 = (B.max_kmers + B.max_kmers / 8) / (uint64_t)nfine + 64, n2 = cap2 * (uint64_t)nfine + bfcg_tile_of_rw(c->rw / 4);
+		if (!(e && atoi(e) == 0) && n2 < 0xffffffffULL) {
+			c->cap2 = (uint32_t)cap2; c->recs2_n = n2 > c->recv_cap ? n2 : c->recv_cap;
+			HIPCKN(hipMalloc(&c->cnt2, sizeof(uint32_t) * (size_t)nfine));
+		}
+	}
+	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recs2_n * c->rw));
 	c->seg_words = (size_t)4 * nb1 + 8;
 	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * 2 * c->seg_words)); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * 2 * c->seg_words)); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
@@ -258,7 +268,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.seg = 1; P.seg_shift = sh; c->seg_cap_shift = sh;
 		HIPCKN(set_seg_lds_attr());
 		HIPCKN(hipMalloc(&B.seg_tab, ((uint64_t)nfine << sh) * 8));
-		HIPCKN(hipMalloc(&c->stream_out, c->recv_cap * (uint64_t)c->rw));
+		HIPCKN(hipMalloc(&c->stream_out, c->recs2_n * (uint64_t)c->rw));
 	}
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
 	else if (!c->seg_ok) HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
@@ -301,7 +311,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->op_cursor[b]); (void)hipFree(c->op_seg[b]); if (c->h_flags[b]) (void)hipHostFree(c->h_flags[b]); }
-	(void)hipFree(c->op_flags);
+	(void)hipFree(c->op_flags); (void)hipFree(c->cnt2);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipHostFree(c->h_snap[0]); (void)hipHostFree(c->h_snap[1]); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -324,7 +334,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	// the statistics first: stage A of the next batch (stream stA) adds to them and only has to wait for that small memset; the
 	// filters and the table are touched by stage B alone, on this same stream, so zeroing them needs no host synchronisation
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
-	if (c->onepass_ok) HIPCK(hipMemsetAsync(c->op_flags, 0, 2 * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
+	if (c->onepass_ok) HIPCK(hipMemsetAsync(c->op_flags, 0, 4 * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
 	HIPCK(hipEventRecord(c->evCopy, c->st));
 	HIPCK(hipStreamWaitEvent(c->stA, c->evCopy, 0));
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
@@ -453,7 +463,7 @@ static int replay_poisoned(bfcg_ctx_t *c)
 	bfcg_ctx::opq_t q[4];
 	for (int i = 0; i < n; ++i) q[i] = c->opq[i];
 	c->n_opq = 0; c->onepass = 0;
-	HIPCK(hipMemset(c->op_flags, 0, 2 * sizeof(uint32_t)));
+	HIPCK(hipMemset(c->op_flags, 0, 4 * sizeof(uint32_t)));
 	if (fetch_stats(c) != 0) return -1;
 	c->n_batches -= (uint64_t)n; // the batches keep their places in the count (order stamps carry the batch number)
 	for (int i = 0; i < n; ++i) {
@@ -653,7 +663,7 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 
 // partition of the current run: out[0] 1 = one-pass level 1 (K1 once per batch) still in use, out[1] batches replayed through the two-pass partition
 // since the context was created (a slab overflowed: few, often repeated k-mers)
-extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)c->onepass; out[1] = c->n_replayed; return 0; }
+extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)(c->onepass ? 1 | (c->cap2 ? 2 : 0) : 0); out[1] = c->n_replayed; return 0; }
 
 extern "C" int bfcg_table_info(bfcg_ctx_t *c, int out[4])
 {
@@ -744,7 +754,7 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 static int use_stream(bfcg_ctx_t *c)
 {
 	if (c->stream_mode) {
-		if (!c->stream_out) HIPCK(hipMalloc(&c->stream_out, c->recv_cap * (uint64_t)c->rw));
+		if (!c->stream_out) HIPCK(hipMalloc(&c->stream_out, c->recs2_n * (uint64_t)c->rw));
 		++c->n_stream_batches;
 	}
 	return 0;
@@ -792,6 +802,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	const int op = c->onepass && !no_kstats && n_pos >= c->op_min_pos; // (a handful of tiles cannot fill 8 slabs per bucket evenly)
 	if (op) {
 		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags; Bt.op_cap = c->op_cap;
+		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2;
 		run_stage_a_onepass(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
 	} else run_stage_a(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
 	HIPCK(hipEventRecord(c->evA[b], sA));

@@ -513,11 +513,18 @@ __global__ __launch_bounds__(BFCG_MAXB) void k_scan2(KParams P, const uint32_t *
 // The tile is first ordered by fine bucket in LDS, then copied out: neighbouring lanes store neighbouring
 // records of one run, so the 16-byte stores coalesce into line-sized requests (registers->HBM scatter of single
 // records measured 2x WRITE_SIZE inflation and ~1.1 TB/s).
-template <typename W, int RW, int TILE, int BT>
+// ONEPASS2 (no k_hist2, no k_scan2): region f owns the slab out[f * cap2 .. (f + 1) * cap2); a tile's run for region f goes where an atomic on
+// cnt2[f] says.  Rows are dealt XCD-contiguously, so a region's counter is (nearly always) touched from one XCD only.  A slab that cannot take a
+// run raises flags[2]: k_bloom and the commit kernels of this batch then do nothing, k_seal2 makes the flag sticky and the host replays the batch.
+struct OnePass2 { uint32_t *cnt2; uint32_t cap2; uint32_t *flags; };
+
+__global__ void k_seal2(uint32_t *flags) { if (flags[2]) { flags[1] = 1; flags[2] = 0; } }
+
+template <typename W, int RW, int TILE, int BT, bool ONEPASS2 = false>
 __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
                                                  const uint32_t *__restrict__ seg_end, int n_seg, int segs_per_bucket,
                                                  const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ rows2,
-                                                 uint32_t *__restrict__ out)
+                                                 uint32_t *__restrict__ out, OnePass2 O2)
 {
 	const RecGeom RG = rec_geom(P);
 	constexpr int S = TILE / BT;
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	const uint32_t tile = (uint32_t)row - row_base[b1];
 	const uint32_t s = seg_beg[b1], e = seg_end[b1];
 	const uint32_t imp = (P.f_base >> P.F2) + (uint32_t)(b1 / segs_per_bucket);
-	const uint32_t *rowp = rows2 + (size_t)row * nb2;
+	const uint32_t *rowp = ONEPASS2 ? nullptr : rows2 + (size_t)row * nb2;
 	for (int i = threadIdx.x; i < nb2; i += BT) cnt[i] = 0;
 	__syncthreads();
 	RecW<RW> w[S];
@@ -554,9 +561,22 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	}
 	__syncthreads();
 	{ // bucket counters -> exclusive offsets inside the stage; gdelta = where the bucket's run goes in the output
-		block_scan_excl<BT>(cnt, nb2, wsum2);
+		const uint32_t tot = block_scan_excl<BT>(cnt, nb2, wsum2);
 		__syncthreads();
-		for (int i = threadIdx.x; i < nb2; i += BT) gdelta[i] = rowp[i] - cnt[i]; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
+		if (!ONEPASS2) {
+			for (int i = threadIdx.x; i < nb2; i += BT) gdelta[i] = rowp[i] - cnt[i]; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
+		} else {
+			const uint32_t f0 = (uint32_t)(b1 / segs_per_bucket) << P.F2;
+			for (int i = threadIdx.x; i < nb2; i += BT) {
+				const uint32_t ex = cnt[i], c = (i + 1 < nb2 ? cnt[i + 1] : tot) - ex;
+				uint32_t base = 0;
+				if (c) {
+					base = atomicAdd(&O2.cnt2[f0 + i], c);
+					if (base + c > O2.cap2) { O2.flags[2] = 1; base = 0; } // (the run then lands on records nobody will read: the buffer ends with a tile of slack)
+				}
+				gdelta[i] = (f0 + (uint32_t)i) * O2.cap2 + base - ex;
+			}
+		}
 	}
 	__syncthreads();
 #pragma unroll
@@ -760,7 +780,18 @@ struct BloomArgs {
 	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
 	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
 	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
+	const uint32_t *cnt2; uint32_t cap2; // one-pass level 2: region f's records are recs[f * cap2 .. + cnt2[f]) (cap2 = 0: start[] says where)
+	const uint32_t *flags;         // one-pass partition: [1] an earlier batch or this one overflowed a level-1 slab, [2] this one a region's slab
 };
+
+// where region f's records are
+__device__ __forceinline__ void region_list(const BloomArgs &A, uint32_t f, uint32_t &rs, uint32_t &n)
+{
+	if (A.cap2) { const uint32_t c = A.cnt2[f]; rs = f * A.cap2; n = c < A.cap2 ? c : A.cap2; }
+	else { rs = A.start[f]; n = A.start[f + 1] - rs; }
+}
+// A batch the one-pass partition gave up on must change nothing: the host replays it (and every batch behind it) through the two-pass one.
+__device__ __forceinline__ bool batch_poisoned(const BloomArgs &A) { return A.flags && (A.flags[1] | A.flags[2]); }
 
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
 template <typename W, bool TRACK>
@@ -917,7 +948,9 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_seen, s_agg_n, s_fs_used, s_pad[2];
 	const uint32_t f = blockIdx.x;
-	const uint32_t rs = A.start[f], n = A.start[f + 1] - rs;
+	if (batch_poisoned(A)) return;
+	uint32_t rs, n;
+	region_list(A, f, rs, n);
 	if (n == 0) { if (threadIdx.x == 0 && A.agg_cnt) A.agg_cnt[f] = 0; return; }
 	A.stats += (size_t)(f & (ST_SLOTS - 1)) * ST_N; // statistics are slotted: no chip-wide single-address atomics
 	const int region_blocks = 1 << P.R;                 // P.R already clamped to bf_shift-9
@@ -1267,6 +1300,7 @@ template <typename W, bool TRACK, bool WALK>
 __global__ __launch_bounds__(256) void k_commit(KParams P, BloomArgs A)
 {
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+	if (batch_poisoned(A)) return;
 	const uint64_t plane = (uint64_t)A.n_fine * P.ag_cap;
 	if (!WALK) {
 		const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
@@ -1298,10 +1332,13 @@ template <typename W, int RW>
 __global__ __launch_bounds__(256) void k_commit_stream(KParams P, BloomArgs A)
 {
 	A.stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+	if (batch_poisoned(A)) return;
 	const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	for (uint32_t f = wave * COMMIT_RPW; f < wave * COMMIT_RPW + COMMIT_RPW && f < A.n_fine; ++f) {
 		const uint32_t n = A.agg_cnt[f];
-		const uint64_t base = A.start[f];
+		uint32_t rs0, n0;
+		region_list(A, f, rs0, n0);
+		const uint64_t base = rs0;
 		for (uint32_t j = lane; j < n; j += 64) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
 			Rec<RW>::unpack(rec_load<RW>(A.stream_out + (base + j) * RW), rec_geom(P), (P.f_base + f) >> P.F2, y0, y1, idx, hi);
@@ -1361,11 +1398,14 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
 	__shared__ uint32_t s_new;
 	const uint32_t f = blockIdx.x;
+	if (batch_poisoned(A)) return;
 	const uint32_t n = A.agg_cnt[f];
 	if (n == 0) return;
 	const uint32_t slots = 1u << P.seg_shift, mask = slots - 1;
 	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift);
-	const unsigned long long *recs = reinterpret_cast<const unsigned long long *>(A.stream_out) + A.start[f];
+	uint32_t rs0, n0;
+	region_list(A, f, rs0, n0);
+	const unsigned long long *recs = reinterpret_cast<const unsigned long long *>(A.stream_out) + rs0;
 	const SegGeom G = seg_geom(P);
 	// few k-mers for a large segment: touch their lines only (this workgroup alone owns the segment, the atomics order its own lanes)
 	const bool direct = (uint64_t)n * 16 < slots;
@@ -1722,9 +1762,16 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		constexpr int T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
 		// rows of level 2 <= records/T2 + one ragged row per segment; surplus blocks exit at once
 		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
-		hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2);
-		hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
-		hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2, (uint32_t *)B.recs2);
+		if (B.cap2) { // one pass: region slabs and cursors
+			hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
+			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+			                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
+		} else {
+			hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2);
+			hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
+			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2,
+			                   (uint32_t *)B.recs2, OnePass2{nullptr, 0u, nullptr});
+		}
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
 	}
 	if (ev) hipEventRecord(ev[3], st);
@@ -1733,6 +1780,8 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_slices = B.pool_slices; A.seen_out = B.seen_out;
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine; A.stream_out = nullptr; A.seg_tab = nullptr;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
+	A.cnt2 = nullptr; A.cap2 = 0; A.flags = B.op_flags; // (op_flags: NULL unless this batch went through the one-pass partition)
+	if (P.F2 > 0 && B.cap2) { A.cnt2 = B.cnt2; A.cap2 = B.cap2; }
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
 		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
@@ -1748,6 +1797,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
 		else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)8 << P.seg_shift, st, P, A);
 		else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+		if (A.cap2) hipLaunchKernelGGL(k_seal2, dim3(1), dim3(1), 0, st, B.op_flags);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
 	} else if (B.stream && B.stream_out && !P.track && P.n_hashes == 4) { // low-multiplicity batches: no aggregation (ctx decides, see bfcg_ctx.hip)
@@ -1755,6 +1805,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
 		hipLaunchKernelGGL((k_commit_stream<W, RW>), dim3((unsigned)((nfine + 4 * COMMIT_RPW - 1) / (4 * COMMIT_RPW))), dim3(256), 0, st, P, A);
+		if (A.cap2) hipLaunchKernelGGL(k_seal2, dim3(1), dim3(1), 0, st, B.op_flags);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
 	} else if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
@@ -1776,6 +1827,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 			else hipLaunchKernelGGL((k_commit<W, false, false>), dim3(gs), dim3(256), 0, st, P, A);
 		}
 	}
+	if (A.cap2) hipLaunchKernelGGL(k_seal2, dim3(1), dim3(1), 0, st, B.op_flags);
 	if (ev) hipEventRecord(ev[5], st);
 }
 

@@ -183,8 +183,9 @@ int bfcg_progress(bfcg_ctx_t *c, uint64_t *calls, uint64_t *final, uint64_t *key
 /* how the count table is held right now: out[0] 1 = region-owned segments, 0 = the host's layout; out[1] log2 slots per segment;
  * out[2] log2 slots per sub-table; out[3] segment growths so far */
 int bfcg_table_info(bfcg_ctx_t *c, int out[4]);
-/* how the k-mers are partitioned: out[0] 1 = the one-pass level-1 partition (the k-mer hash is computed once per batch) is in use; out[1] batches
- * that had to be replayed through the two-pass partition so far (input with few, often repeated k-mers overflows a one-pass slab) */
+/* how the k-mers are partitioned: out[0] bit 0 = the one-pass level-1 partition (the k-mer hash is computed once per batch, no histogram pass) is in
+ * use, bit 1 = level 2 runs in one pass too (a slab per bloom region, no k_hist2); out[1] batches that had to be replayed through the two-pass
+ * partition so far (input with few, often repeated k-mers overflows a one-pass slab) */
 int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]);
 /* batches handled without aggregation (k-mers that hardly repeat inside a batch: seen k-mers are streamed to the table kernel) */
 uint64_t bfcg_stream_batches(bfcg_ctx_t *c);

@@ -84,7 +84,7 @@ def test_c2_full_read_set(gpu_lib, batch_reads, layout):
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], batch_reads, table_layout=layout)
     assert g.table_info()["segments"] == (layout == 0)  # c2's geometry takes the region-owned table segments (46 identity bits)
     _check_against(g, e)
-    assert g.partition_info() == dict(one_pass=True, replayed_batches=0)  # K1 once per batch, no slab overflow on uniformly hashed k-mers
+    assert g.partition_info() == dict(one_pass=True, level2_one_pass=True, replayed_batches=0)  # K1 once per batch, no histogram passes, no slab overflow on uniformly hashed k-mers
     g.close()
 
 
@@ -98,7 +98,7 @@ def test_c3_full_read_set(gpu_lib):
     assert ti["segments"] and ti["seg_growths"] >= 1, ti  # 48 identity bits; the segments grow with the 300 M keys
     st = _check_against(g, e)
     assert st["stream_batches"] > 0, "c3 is expected to run (mostly) without in-LDS aggregation"
-    assert g.partition_info() == dict(one_pass=True, replayed_batches=0)
+    assert g.partition_info() == dict(one_pass=True, level2_one_pass=True, replayed_batches=0)
     g.close()
 
 
@@ -138,26 +138,42 @@ def test_c5_parameters(gpu_lib):
 
 
 @pytest.mark.parametrize("fm", [0, 1])
-def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm):
-    """Input with few, often repeated k-mers (300 000 reads of a 400-base genome, -b30): the one-pass partition's slabs overflow, the batch
-    and the one behind it change nothing on the device, the library replays both through the two-pass partition -- results are the oracle's,
-    statistics counted once, and the rest of the run stays two-pass."""
-    rng = np.random.default_rng(77 + fm)
-    G, L, n = 400, 150, 300_000
-    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), G + L)
-    pos = rng.integers(0, G, n)
+@pytest.mark.parametrize("level", [1, 2])
+def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level):
+    """Input the one-pass partition cannot take, at -b30 (128 level-1 buckets x 8 slabs, 8192 regions):
+      level 1: 300 000 reads of a 400-base genome -- few, often repeated k-mers overflow the level-1 slabs;
+      level 2: 100 000 reads of a 50 Mbp genome plus 2 000 copies of one read -- every level-1 slab has room (a repeated k-mer adds 250 records
+               to slabs of 16 000), but the regions of the repeated k-mers get 2 000 records more than their slab of ~2 100 holds.
+    The batch and the one behind it change nothing on the device, the library replays both through the two-pass partition -- results are the
+    oracle's, statistics counted once -- and the rest of the run stays two-pass."""
+    rng = np.random.default_rng(77 + fm + 10 * level)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L = 150
+    if level == 1:
+        G, n = 400, 300_000
+        genome = rng.choice(acgt, G + L)
+        pos = rng.integers(0, G, n)
+    else:
+        G, n = 50_000_000, 102_000
+        genome = rng.choice(acgt, G + L)
+        pos = rng.integers(0, G, n)
+        pos[rng.choice(n, 2000, replace=False)] = 12345
     seq = genome[(pos[:, None] + np.arange(L)[None, :])].astype(np.uint8)
-    err = rng.random(seq.shape) < 0.01
-    seq[err] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(err.sum()))]
+    if level == 1:
+        err = rng.random(seq.shape) < 0.01
+        seq[err] = acgt[rng.integers(0, 4, int(err.sum()))]
     seq = seq.reshape(-1)
     qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
     off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     k, b = 31, 30
     oc = oracle.Counter(k, b, filter_mode=fm)
     oc.count(seq, qual, off)
-    g = gpu_lib.GpuCounter(k, b, filter_mode=fm, max_batch_pos=(n // 3 + 1) * (L + 1) + 64)
-    for a in range(0, n, n // 3 + 1):
-        e = min(n, a + n // 3 + 1)
+    nb = 3 if level == 1 else 1
+    per = n // nb + 1
+    g = gpu_lib.GpuCounter(k, b, filter_mode=fm, max_batch_pos=per * (L + 1) + 64)
+    assert g.partition_info() == dict(one_pass=True, level2_one_pass=True, replayed_batches=0)
+    for a in range(0, n, per):
+        e = min(n, a + per)
         g.count_host(gen.to_stream(seq[a * L:e * L], L, 10), gen.to_stream(qual[a * L:e * L], L, 33))
     st, ost = g.stats(), oc.stats()
     pi = g.partition_info()
