@@ -13,3 +13,4 @@ d=json.load(open('gpurun_out/r2_bench_final.json'))
 print(d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], 'verified', d.get('verified'), d['build_id'])
 print(d['secondary']['c2']['value'], d['secondary']['c2'].get('verified'), d['cpu_baseline']['value'])
 PY
+timeout 900 python scripts/gz_rate.py 50 6 4 2>&1 | tee gpurun_out/round2_gz_rate.txt | tail -8
