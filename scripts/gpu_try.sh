@@ -1,10 +1,24 @@
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 1500 python scripts/c4_run.py --batch-reads 16777216 > gpurun_out/r2b_c4_16m.log 2>&1; echo c4 rc=$?; tail -4 gpurun_out/r2b_c4_16m.log | cut -c1-600
-timeout 1500 python scripts/c4_run.py --k 51 --filter-mode 1 --trim 1 --batch-reads 8388608 > gpurun_out/r2b_c5_8m.log 2>&1; echo c5 rc=$?; tail -5 gpurun_out/r2b_c5_8m.log | cut -c1-600
-timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -4
-timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/try_bench.json 2>gpurun_out/try_bench.log; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/try_bench.json'))
-print(d['value'], d['ms_per_step'], d['config']['partition'], list(d['stages']), d['stages']['level2']['frac'], d['roofline'].get('traffic_note'))
+BFCG_DEBUG=0 timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x -k one_pass 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6
+python - <<'PY'
+# how often the forced one-pass draws were replayed
+import os, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+os.environ["BFCG_ONEPASS_MIN_TILES"] = "1"
+import numpy as np, bfc_amd
+import test_gpu_fuzz as T
+rep = 0; op = 0
+for seed in range(40):
+    prm, seq, qual, off, cuts, kw = T._draw(40000 + seed, scale=12, b_range=(26, 32))
+    n = len(off) - 1
+    g = bfc_amd.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"], max_batch_pos=len(seq) + n + 64, **kw)
+    p0 = g.partition_info()
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        o = off[a:e + 1] - off[a]
+        g.count_host(bfc_amd.to_stream(seq[int(off[a]):int(off[e])], o), bfc_amd.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None)
+    g.stats(); p1 = g.partition_info()
+    op += p0["one_pass"]; rep += p1["replayed_batches"] > 0
+    g.close()
+print("draws with the one-pass partition:", op, "of 40; with replayed batches:", rep)
 PY
+bash scripts/more_fuzz.sh 7 8 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -8

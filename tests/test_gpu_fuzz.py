@@ -91,6 +91,17 @@ def test_random_configuration_large_filters(gpu_lib, seed):
     _check(gpu_lib, *_draw(30000 + seed, scale=4, b_range=(28, 34)))
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_one_pass_partition(gpu_lib, seed, monkeypatch):
+    """the one-pass partition (bucket slabs + cursors) on draws it would normally leave to the two-pass one: with
+    BFCG_ONEPASS_MIN_TILES=1 every batch of a filter of 2^26 bits and more goes through it, however few records a slab expects -- slabs
+    overflow at level 1 or 2 in the middle of a run (low-complexity draws: coverage 40 of a tiny genome), the poisoned batch and the ones
+    enqueued behind it are replayed, the rest of the run falls back; any k, any number of hashes, both table layouts, filter mode, batch
+    cuts, several region sizes.  Bit for bit the oracle's filter(s), statistics and table."""
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    _check(gpu_lib, *_draw(40000 + seed, scale=12, b_range=(26, 32)))
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_medium_configuration(gpu_lib, seed):
     """the same draws at 40x the size (up to 60 000 reads, tens of millions of positions): many tiles per bucket, multi-chunk scans, full
