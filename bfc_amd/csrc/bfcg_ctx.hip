@@ -11,6 +11,7 @@
 #include <time.h>
 #include <atomic>
 #include <mutex>
+#include <vector>
 #include <thread>
 #include <vector>
 #include "bfc_gpu.h"
@@ -76,7 +77,8 @@ struct bfcg_ctx {
 	uint32_t *op_cursor[2], *op_seg[2], *op_flags, *h_flags[2];
 	uint32_t op_cap; uint64_t op_min_pos;
 	uint32_t *cnt2; uint32_t cap2; uint64_t recs2_n; // one-pass level 2 (region slabs); records recs2 / stream_out hold
-	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
+	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; const void *recv; int mg; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
+	int mg_op2_ok, mg_op2; uint32_t *mg_seg[4];  // a rank of a multi-GPU run: level 2 (its own stage B) in one pass; copies of the queued batches' segment sizes
 	uint64_t n_replayed;
 	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
 	int seg_no_grow;             // the next segment size does not fit (memory / LDS): grow only when a segment overflows or the load passes 85 %
@@ -236,24 +238,31 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	const uint64_t recs1_n = c->onepass_ok ? (uint64_t)c->op_cap * nb1 * 8 : B.max_kmers;
 	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], recs1_n * c->rw));
+	{ // a rank of a multi-GPU run partitions what it RECEIVES in one pass (level 2 is the owner's own stage B; level 1 feeds the exchange and stays two-pass)
+		const char *e = getenv("BFCG_ONEPASS");
+		c->mg_op2_ok = n_ranks > 1 && P.F2 > 0 && !(e && atoi(e) == 0);
+	}
 	if (c->onepass_ok) {
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->op_cursor[b], sizeof(uint32_t) * 8 * nb1 * 32));
 			HIPCKN(hipMalloc(&c->op_seg[b], sizeof(uint32_t) * ((size_t)25 * nb1 + 8)));
-			HIPCKN(hipHostMalloc(&c->h_flags[b], 4 * sizeof(uint32_t)));
 		}
+	}
+	if (c->onepass_ok || c->mg_op2_ok) {
+		for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_flags[b], 4 * sizeof(uint32_t)));
 		HIPCKN(hipMalloc(&c->op_flags, 4 * sizeof(uint32_t)));
 		HIPCKN(hipMemset(c->op_flags, 0, 4 * sizeof(uint32_t)));
 	}
+	if (c->mg_op2_ok) for (int i = 0; i < 4; ++i) c->mg_seg[i] = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_ranks * (size_t)(nb1 >> log2n));
 	B.recs1 = c->recs1[0];
 	c->recs2_n = c->recv_cap;
-	if (c->onepass_ok) { // level 2 in one pass too: a slab per region, 9/8 of the mean of a full batch's positions + 64 records (k-mers are ~0.8 of the positions)
+	if (c->onepass_ok || c->mg_op2_ok) { // level 2 in one pass: a slab per region, 9/8 of the mean of a full batch's positions + 64 records (k-mers are ~0.8 of the positions)
 		const char *e = getenv("BFCG_ONEPASS2");
 		const uint64_t cap2 = (B.max_kmers + B.max_kmers / 8) / (uint64_t)nfine + 64, n2 = cap2 * (uint64_t)nfine + bfcg_tile_of_rw(c->rw / 4);
 		if (!(e && atoi(e) == 0) && n2 < 0xffffffffULL) {
 			c->cap2 = (uint32_t)cap2; c->recs2_n = n2 > c->recv_cap ? n2 : c->recv_cap;
 			HIPCKN(hipMalloc(&c->cnt2, sizeof(uint32_t) * (size_t)nfine));
-		}
+		} else c->mg_op2_ok = 0;
 	}
 	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recs2_n * c->rw));
 	c->seg_words = (size_t)4 * nb1 + 8;
@@ -311,7 +320,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->op_cursor[b]); (void)hipFree(c->op_seg[b]); if (c->h_flags[b]) (void)hipHostFree(c->h_flags[b]); }
-	(void)hipFree(c->op_flags); (void)hipFree(c->cnt2);
+	(void)hipFree(c->op_flags); (void)hipFree(c->cnt2); for (int i = 0; i < 4; ++i) free(c->mg_seg[i]);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipHostFree(c->h_snap[0]); (void)hipHostFree(c->h_snap[1]); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
 	for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(c->evt[b][i]); (void)hipEventDestroy(c->evA[b]); (void)hipEventDestroy(c->evB[b]); }
@@ -322,6 +331,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 
 static int drain(bfcg_ctx_t *c);
 static int replay_poisoned(bfcg_ctx_t *c);
+extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats);
 
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -334,7 +344,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	// the statistics first: stage A of the next batch (stream stA) adds to them and only has to wait for that small memset; the
 	// filters and the table are touched by stage B alone, on this same stream, so zeroing them needs no host synchronisation
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
-	if (c->onepass_ok) HIPCK(hipMemsetAsync(c->op_flags, 0, 4 * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
+	if (c->op_flags) HIPCK(hipMemsetAsync(c->op_flags, 0, 4 * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
 	HIPCK(hipEventRecord(c->evCopy, c->st));
 	HIPCK(hipStreamWaitEvent(c->stA, c->evCopy, 0));
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
@@ -367,7 +377,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	c->keys_last = 0; c->grow[0] = c->grow[1] = 0;
 	c->crowded_last = 0; c->stream_mode = c->P.seg ? 1 : 0;
 	c->cold = 1; c->seen_last = c->pos_final = 0; c->seg_no_grow = 0;
-	c->onepass = c->onepass_ok; c->n_opq = 0;
+	c->onepass = c->onepass_ok; c->mg_op2 = c->mg_op2_ok; c->n_opq = 0;
 	c->call_no = c->final_call = 0; c->call_depth = 0; memset(c->call_keys, 0, sizeof(c->call_keys));
 	return 0;
 }
@@ -462,12 +472,18 @@ static int replay_poisoned(bfcg_ctx_t *c)
 	const int n = c->n_opq;
 	bfcg_ctx::opq_t q[4];
 	for (int i = 0; i < n; ++i) q[i] = c->opq[i];
-	c->n_opq = 0; c->onepass = 0;
+	c->n_opq = 0; c->onepass = 0; c->mg_op2 = 0;
 	HIPCK(hipMemset(c->op_flags, 0, 4 * sizeof(uint32_t)));
 	if (fetch_stats(c) != 0) return -1;
 	c->n_batches -= (uint64_t)n; // the batches keep their places in the count (order stamps carry the batch number)
+	std::vector<uint32_t> seg;
+	for (int i = 0; i < n; ++i) if (q[i].mg) --c->call_no; // (bfcg_mg_process_ev numbers its calls itself)
 	for (int i = 0; i < n; ++i) {
-		if (enqueue_batch(c, q[i].seq, q[i].qual, q[i].n_pos, 0, 1) != 0) return -1;
+		if (q[i].mg) { // a rank's stage B: what it received is still in its receive buffer (the exchange of the next batch has not begun: this thread starts it)
+			const size_t w = (size_t)c->n_ranks * (size_t)((1 << c->P.F1) >> c->log2n);
+			seg.assign(c->mg_seg[q[i].mg - 1], c->mg_seg[q[i].mg - 1] + w);
+			if (bfcg_mg_process_ev(c, q[i].recv, seg.data(), 0, 0) != 0) return -1;
+		} else if (enqueue_batch(c, q[i].seq, q[i].qual, q[i].n_pos, 0, 1) != 0) return -1;
 		if (drain(c) != 0) return -1;
 		++c->n_replayed;
 	}
@@ -663,7 +679,7 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 
 // partition of the current run: out[0] 1 = one-pass level 1 (K1 once per batch) still in use, out[1] batches replayed through the two-pass partition
 // since the context was created (a slab overflowed: few, often repeated k-mers)
-extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)(c->onepass ? 1 | (c->cap2 ? 2 : 0) : 0); out[1] = c->n_replayed; return 0; }
+extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)((c->onepass ? 1 : 0) | ((c->onepass || c->mg_op2) && c->cap2 ? 2 : 0)); out[1] = c->n_replayed; return 0; }
 
 extern "C" int bfcg_table_info(bfcg_ctx_t *c, int out[4])
 {
@@ -740,7 +756,19 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	if (use_stream(c) != 0) return -1;
 	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
-	run_stage_b(c->P, c->B, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	BatchBufs Bt = c->B;
+	const int op2 = c->mg_op2 && c->cap2 && off >= (uint64_t)8 << c->P.F >> c->log2n; // (a handful of records per region: two passes)
+	if (op2) { Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2; Bt.op_flags = c->op_flags; }
+	run_stage_b(c->P, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	if (op2) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
+		HIPCK(hipMemcpyAsync(c->h_flags[b], c->op_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
+		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
+		int free_i = 0;
+		for (;; ++free_i) { int used = 0; for (int i = 0; i < c->n_opq; ++i) used |= c->opq[i].mg == free_i + 1; if (!used) break; }
+		memcpy(c->mg_seg[free_i], seg_cnt, sizeof(uint32_t) * (size_t)N * nb_loc);
+		bfcg_ctx::opq_t &q = c->opq[c->n_opq++];
+		q.seq = q.qual = nullptr; q.n_pos = off; q.slot = b; q.recv = d_recv; q.mg = free_i + 1;
+	}
 	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
 	c->slot_call[b] = ++c->call_no; c->slot_pos[b] = off;
 	HIPCK(hipEventRecord(c->evB[b], c->st));
@@ -814,7 +842,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 		run_stage_b(Pt, Bt, Bt.recs1, sg, sg + 8 * nb1, 8 * nb1, 8, sg + 16 * nb1, sg + 24 * nb1 + 1, n_pos, c->st, c->evt[b]);
 		HIPCK(hipMemcpyAsync(c->h_flags[b], c->op_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
 		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
-		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; ++c->n_opq;
+		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; c->opq[c->n_opq].recv = nullptr; c->opq[c->n_opq].mg = 0; ++c->n_opq;
 	} else
 	run_stage_b(Pt, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
 	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));

@@ -130,3 +130,34 @@ def test_group_random_configurations(gpu_lib, seed):
             grp.count_host(gpu_lib.to_stream(seq[int(off[a]):int(off[e])], o), gpu_lib.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None)
     _compare(grp, oc, prm["fm"])
     grp.close(); oc.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+@pytest.mark.parametrize("fm", [0, 1])
+def test_group_level2_slab_overflow_is_replayed(gpu_lib, n_ranks, fm):
+    """A rank of a multi-GPU run partitions what it receives in one pass (a slab per bloom region).  100 000 reads of a 50 Mbp genome plus
+    3 000 copies of one read, -b30: the regions of the repeated k-mers get 3 000 records more than their slab holds on whichever rank owns
+    them.  That rank replays its own stage B from its receive buffer through the two-pass kernels -- no second exchange -- and the group's
+    result is the oracle's."""
+    rng = np.random.default_rng(500 + n_ranks + fm)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, G, n = 150, 50_000_000, 103_000
+    genome = rng.choice(acgt, G + L)
+    pos = rng.integers(0, G, n)
+    pos[rng.choice(n, 3000, replace=False)] = 4242
+    seq = genome[(pos[:, None] + np.arange(L)[None, :])].astype(np.uint8).reshape(-1)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    k, b = 31, 30
+    oc = _oracle(k, b, seq, qual, off, filter_mode=fm)
+    half = n // 2 + 1
+    grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=half * (L + 1) // n_ranks + 4096, filter_mode=fm)
+    before = [grp.ctx(i).partition_info() for i in range(n_ranks)]
+    assert all(p["level2_one_pass"] and not p["one_pass"] for p in before), before
+    for a in range(0, n, half):
+        e = min(n, a + half)
+        grp.count_host(gen.to_stream(seq[a * L:e * L], L, 10), gen.to_stream(qual[a * L:e * L], L, 33))
+    _compare(grp, oc, fm)
+    after = [grp.ctx(i).partition_info() for i in range(n_ranks)]
+    assert sum(p["replayed_batches"] for p in after) >= 1, after
+    grp.close(); oc.close()
