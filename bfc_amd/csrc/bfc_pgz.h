@@ -26,6 +26,30 @@
 #include <pthread.h>
 #include <zlib.h> /* crc32, crc32_combine */
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define PGZ_X86 1
+#else
+#define PGZ_X86 0
+#endif
+
+#include <sys/mman.h>
+
+/* the large buffers (symbols, text) on 2 MiB pages where the kernel gives them: a fresh piece buffer is otherwise a page fault per 4 KiB,
+ * taken by all threads at once */
+static inline void *pgz_big_realloc(void *old, size_t old_bytes, size_t new_bytes)
+{
+	void *p = 0;
+	const size_t al = (size_t)2 << 20;
+	if (new_bytes < al) return realloc(old, new_bytes);
+	if (posix_memalign(&p, al, (new_bytes + al - 1) & ~(al - 1)) != 0) return 0;
+#ifdef MADV_HUGEPAGE
+	if (!getenv("BFC_GPU_NO_THP")) (void)madvise(p, (new_bytes + al - 1) & ~(al - 1), MADV_HUGEPAGE);
+#endif
+	if (old) { memcpy(p, old, old_bytes < new_bytes ? old_bytes : new_bytes); free(old); }
+	return p;
+}
+
 #define PGZ_WIN 32768
 #define PGZ_LB 11 /* bits of the literal/length root table */
 #define PGZ_DB 9  /* bits of the distance root table */
@@ -213,14 +237,15 @@ static inline int pgz_piece_room(pgz_piece_t *pc, size_t more)
 		uint16_t *ns;
 		while (nc < pc->n + more) nc *= 2;
 		if (nc > ((size_t)1 << 31)) return -1; /* a piece of more than 2 G symbols: gzread's business */
-		if ((ns = (uint16_t*)realloc(pc->sym, nc * sizeof(uint16_t))) == 0) return -1;
+		if ((ns = (uint16_t*)pgz_big_realloc(pc->sym, pc->n * sizeof(uint16_t), nc * sizeof(uint16_t))) == 0) return -1;
 		pc->sym = ns; pc->cap = nc;
 	}
 	return 0;
 }
 
-/* the symbols of one Huffman-coded block; 0 at its end-of-block code, -1 on an invalid code / distance or the end of the input */
-static inline int pgz_codes(pgz_br_t *b, const pgz_tabs_t *t, pgz_piece_t *pc)
+/* the symbols of one Huffman-coded block; 0 at its end-of-block code, -1 on an invalid code / distance or the end of the input.
+ * This version checks for the end of the input after every symbol; pgz_codes() below runs ahead of it while 16 bytes of input are left. */
+static inline int pgz_codes_careful(pgz_br_t *b, const pgz_tabs_t *t, pgz_piece_t *pc)
 {
 	for (;;) {
 		uint16_t *out;
@@ -266,6 +291,70 @@ static inline int pgz_codes(pgz_br_t *b, const pgz_tabs_t *t, pgz_piece_t *pc)
 		}
 		pc->n = n;
 	}
+}
+
+/* the same while at least 16 bytes of input lie ahead (a refill then always delivers 56 valid bits: no end-of-input checks), bit buffer and
+ * cursors in registers, up to three literals per refill, matches copied 16 bytes at a time; the careful loop finishes the block */
+static inline int pgz_codes(pgz_br_t *b, const pgz_tabs_t *t, pgz_piece_t *pc)
+{
+	const pgz_ent_t *lt = t->lt, *dt = t->dt;
+	const uint32_t LM = (1u << PGZ_LB) - 1, DM = (1u << PGZ_DB) - 1;
+	while (b->end - b->p >= 32) {
+		uint64_t bb = b->bb; int bc = b->bc;
+		const uint8_t *p = b->p, *fast_end = b->end - 16;
+		uint16_t *out;
+		size_t n = pc->n, lim;
+		const size_t floor = pc->floor;
+		int done = 0; /* 1 end of block, -1 error */
+		if (pgz_piece_room(pc, 65536 + 300) != 0) return -1;
+		out = pc->sym; lim = pc->cap - 258 - 16;
+		while (n < lim && p <= fast_end) {
+			pgz_ent_t e;
+			uint64_t w;
+			memcpy(&w, p, 8); bb |= w << bc; p += (63 - bc) >> 3; bc |= 56;
+			e = lt[bb & LM];
+			if (e.op == PGZ_LIT) {
+				bb >>= e.bits; bc -= e.bits; out[n++] = e.val;
+				e = lt[bb & LM];
+				if (e.op == PGZ_LIT) {
+					bb >>= e.bits; bc -= e.bits; out[n++] = e.val;
+					e = lt[bb & LM];
+					if (e.op == PGZ_LIT) { bb >>= e.bits; bc -= e.bits; out[n++] = e.val; }
+				}
+				continue;
+			}
+			if (e.op == PGZ_LINK) { e = lt[e.val + ((bb >> PGZ_LB) & ((1u << e.xb) - 1))]; bb >>= PGZ_LB; bc -= PGZ_LB; }
+			bb >>= e.bits; bc -= e.bits;
+			if (e.op == PGZ_LIT) { out[n++] = e.val; continue; }
+			if (e.op == PGZ_BASE) {
+				const uint32_t len = e.val + (uint32_t)(bb & ((1u << e.xb) - 1));
+				uint32_t dist;
+				pgz_ent_t d;
+				bb >>= e.xb; bc -= e.xb;
+				d = dt[bb & DM];
+				if (d.op == PGZ_LINK) { d = dt[d.val + ((bb >> PGZ_DB) & ((1u << d.xb) - 1))]; bb >>= PGZ_DB; bc -= PGZ_DB; }
+				bb >>= d.bits; bc -= d.bits;
+				if (d.op != PGZ_BASE) { done = -1; break; }
+				dist = d.val + (uint32_t)(bb & ((1u << d.xb) - 1));
+				bb >>= d.xb; bc -= d.xb;
+				if (dist > n - floor) { done = -1; break; }
+				if (dist >= 8) { /* 16-byte pieces never overlap their own source; up to 7 symbols of slack behind the match are overwritten later */
+					const uint16_t *sp = out + (n - dist);
+					uint16_t *dp = out + n;
+					uint32_t k = 0;
+					do { memcpy(dp + k, sp + k, 16); k += 8; } while (k < len);
+				} else { const size_t src = n - dist; uint32_t k; for (k = 0; k < len; ++k) out[n + k] = out[src + k]; }
+				n += len;
+				continue;
+			}
+			done = e.op == PGZ_EOB ? 1 : -1;
+			break;
+		}
+		b->bb = bb; b->bc = bc; b->p = p; pc->n = n;
+		if (done) return done > 0 ? 0 : -1;
+		if (p > fast_end) break;
+	}
+	return pgz_codes_careful(b, t, pc);
 }
 
 /* one deflate block at b (its 3 header bits first); *final = BFINAL.  0 / -1 */
@@ -370,6 +459,63 @@ static inline int pgz_try_block(const uint8_t *z, size_t zlen, uint64_t pos, pgz
 	return pgz_dyn_header(&b, t) == 0;
 }
 
+#if PGZ_X86
+/* CRC-32 (the gzip polynomial) by carry-less multiplication: folds 64 bytes per step (Gopal et al., "Fast CRC Computation for Generic
+ * Polynomials Using PCLMULQDQ Instruction", Intel 2009; the constants are x^n mod P for the fold distances).  len: a multiple of 16, >= 64;
+ * crc in and out as zlib's crc32() passes it. */
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t pgz_crc32_clmul(uint32_t crc0, const uint8_t *buf, size_t len)
+{
+	const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596LL, 0x0154442bd4LL);
+	const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009eLL, 0x01751997d0LL);
+	const __m128i k5k0 = _mm_set_epi64x(0, 0x0163cd6124LL);
+	const __m128i poly = _mm_set_epi64x(0x01f7011641LL, 0x01db710641LL);
+	const __m128i m32 = _mm_setr_epi32(~0, 0, ~0, 0);
+	__m128i x0, x1, x2, x3, x4, x5, x6, x7, x8;
+	x1 = _mm_loadu_si128((const __m128i*)(buf + 0)); x2 = _mm_loadu_si128((const __m128i*)(buf + 16));
+	x3 = _mm_loadu_si128((const __m128i*)(buf + 32)); x4 = _mm_loadu_si128((const __m128i*)(buf + 48));
+	x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)~crc0));
+	x0 = k1k2; buf += 64; len -= 64;
+	while (len >= 64) {
+		x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00); x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+		x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11); x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+		x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), _mm_loadu_si128((const __m128i*)(buf + 0)));
+		x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), _mm_loadu_si128((const __m128i*)(buf + 16)));
+		x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), _mm_loadu_si128((const __m128i*)(buf + 32)));
+		x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), _mm_loadu_si128((const __m128i*)(buf + 48)));
+		buf += 64; len -= 64;
+	}
+	x0 = k3k4;
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+	while (len >= 16) {
+		x2 = _mm_loadu_si128((const __m128i*)buf);
+		x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+		buf += 16; len -= 16;
+	}
+	x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+	x1 = _mm_srli_si128(x1, 8); x1 = _mm_xor_si128(x1, x2);
+	x0 = k5k0;
+	x2 = _mm_srli_si128(x1, 4); x1 = _mm_and_si128(x1, m32); x1 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_xor_si128(x1, x2);
+	x0 = poly;
+	x2 = _mm_and_si128(x1, m32); x2 = _mm_clmulepi64_si128(x2, x0, 0x10); x2 = _mm_and_si128(x2, m32); x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+	x1 = _mm_xor_si128(x1, x2);
+	return ~(uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+/* crc32() of zlib, 6x faster where the CPU multiplies carry-less (checked against zlib's own in tests/test_pgz.py) */
+static inline uint32_t pgz_crc32(uint32_t crc, const uint8_t *buf, size_t len)
+{
+#if PGZ_X86
+	static int have = -1;
+	if (have < 0) have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("BFC_PGZ_NO_CLMUL");
+	if (have && len >= 64) { const size_t n = len & ~(size_t)15; crc = pgz_crc32_clmul(crc, buf, n); buf += n; len -= n; }
+#endif
+	while (len) { const size_t step = len < ((size_t)1 << 30) ? len : (size_t)1 << 30; crc = (uint32_t)crc32(crc, buf, (uInt)step); buf += step; len -= step; }
+	return crc;
+}
+
 typedef struct pgz_s pgz_t;
 typedef struct {
 	pgz_t *g; int idx;
@@ -433,14 +579,19 @@ static void *pgz_narrow_job(void *arg)
 	size_t i, a = 0;
 	int m;
 	if (!j->take) return 0;
-	for (i = 0; i < n; ++i) { const uint16_t v = s[i]; j->dst[i] = (v & 0x8000) ? j->win[v & 0x7fff] : (uint8_t)v; }
+	i = 0;
+#if PGZ_X86
+	for (; i + 16 <= n; i += 16) { /* 16 symbols at a time; markers are rare behind the first 32 KiB of most pieces, frequent in FASTQ headers */
+		const __m128i a = _mm_loadu_si128((const __m128i*)(s + i)), b = _mm_loadu_si128((const __m128i*)(s + i + 8));
+		if (_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xaaaa) { size_t k; for (k = i; k < i + 16; ++k) { const uint16_t v = s[k]; j->dst[k] = (v & 0x8000) ? j->win[v & 0x7fff] : (uint8_t)v; } }
+		else _mm_storeu_si128((__m128i*)(j->dst + i), _mm_packus_epi16(a, b));
+	}
+#endif
+	for (; i < n; ++i) { const uint16_t v = s[i]; j->dst[i] = (v & 0x8000) ? j->win[v & 0x7fff] : (uint8_t)v; }
 	if (j->m_seg < j->pc.n_mend + 1) { j->m_seg = j->pc.n_mend + 8; j->seg_crc = (uint32_t*)realloc(j->seg_crc, sizeof(uint32_t) * (size_t)j->m_seg); j->seg_len = (uint64_t*)realloc(j->seg_len, sizeof(uint64_t) * (size_t)j->m_seg); }
 	for (m = 0; m <= j->pc.n_mend; ++m) {
 		const size_t e = m < j->pc.n_mend ? (size_t)j->pc.mend[m].at : n;
-		uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-		size_t o = a;
-		while (o < e) { const size_t step = e - o < (1u << 30) ? e - o : (1u << 30); c = (uint32_t)crc32(c, j->dst + o, (uInt)step); o += step; }
-		j->seg_crc[m] = c; j->seg_len[m] = e - a; a = e;
+		j->seg_crc[m] = pgz_crc32((uint32_t)crc32(0L, Z_NULL, 0), j->dst + a, e - a); j->seg_len[m] = e - a; a = e;
 	}
 	return 0;
 }
@@ -504,7 +655,7 @@ static inline int pgz_text_room(pgz_t *g, uint64_t more)
 			uint8_t *nt;
 			while (nc < g->text_len + more) nc += nc < ((uint64_t)1 << 30) ? nc : (uint64_t)1 << 30;
 			nc += nc / 2; /* so that a window's worth of taken text can usually stay where it is */
-			if ((nt = (uint8_t*)realloc(g->text, nc)) == 0) return -1;
+			if ((nt = (uint8_t*)pgz_big_realloc(g->text, (size_t)g->text_len, (size_t)nc)) == 0) return -1; /* (text_head is 0 here) */
 			g->text = nt; g->text_cap = nc;
 		}
 	}
