@@ -139,13 +139,15 @@ def test_c5_parameters(gpu_lib):
 
 @pytest.mark.parametrize("fm", [0, 1])
 @pytest.mark.parametrize("level", [1, 2])
-def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level):
+@pytest.mark.parametrize("pipeline", ["1", "0"])  # two streams (batches up to 2^28 positions) / one stream (larger batches: c3, c4)
+def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level, pipeline, monkeypatch):
     """Input the one-pass partition cannot take, at -b30 (128 level-1 buckets x 8 slabs, 8192 regions):
       level 1: 300 000 reads of a 400-base genome -- few, often repeated k-mers overflow the level-1 slabs;
       level 2: 100 000 reads of a 50 Mbp genome plus 2 000 copies of one read -- every level-1 slab has room (a repeated k-mer adds 250 records
                to slabs of 16 000), but the regions of the repeated k-mers get 2 000 records more than their slab of ~2 100 holds.
     The batch and the one behind it change nothing on the device, the library replays both through the two-pass partition -- results are the
     oracle's, statistics counted once -- and the rest of the run stays two-pass."""
+    monkeypatch.setenv("BFCG_PIPELINE", pipeline)
     rng = np.random.default_rng(77 + fm + 10 * level)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     L = 150
