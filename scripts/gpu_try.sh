@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_gpu_baseline_shapes.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3
 for v in 0 1; do
-BFCG_ONEPASS=$v BFC_BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-verify 2>gpurun_out/try_dist$v.log | python -c "
+env $( [ $v = 0 ] && echo BFCG_NO_CHUNKS=1 || echo BFCG_X=1 ) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/try.log | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('ONEPASS=$v world-1 RCCL path:', d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d['config']['library_batches_per_step'], d['config']['exchange_plus_stages_s_per_step'])"
+d=json.loads(sys.stdin.readline()); print('chunks=$v', d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d.get('verified')); print(d['secondary']['c2']['value'], d['secondary']['c2'].get('verified'), d['secondary']['c2'].get('stage_ms_per_step'))"
 done
-tail -5 gpurun_out/try_dist1.log
