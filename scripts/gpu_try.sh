@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_baseline_shapes.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3
-for v in 0 1; do
-env $( [ $v = 0 ] && echo BFCG_NO_CHUNKS=1 || echo BFCG_X=1 ) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/try.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('chunks=$v', d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d.get('verified')); print(d['secondary']['c2']['value'], d['secondary']['c2'].get('verified'), d['secondary']['c2'].get('stage_ms_per_step'))"
-done
+timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_baseline_shapes.py -q -m gpu -x -k "gz or skewed" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -4
+bash scripts/more_fuzz.sh 11 12 13 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -9
+MORE_DROPIN=1 bash scripts/more_fuzz.sh 5 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3

@@ -188,4 +188,6 @@ def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level, pipeline,
         sizes, slots = g.export_table().export_sorted()
         osz, osl = oc.export()
         assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.reset()  # the next data set starts with the one-pass partition again
+    assert g.partition_info()["one_pass"]
     g.close(); oc.close()

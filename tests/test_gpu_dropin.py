@@ -97,6 +97,20 @@ def test_bfc_count_gz_fasta_and_no_mt_io(gpu_lib, g1_fq, tmp_path):
     t.close()
 
 
+def test_bfc_count_gz_inflated_by_several_threads(gpu_lib, g1_fq, tmp_path, monkeypatch):
+    """-t 4 on a gzip file: the ingest threads inflate the ONE deflate stream together (bfc_pgz.h; forced here for a file below 1 MiB and
+    with chunks of 20 KB, so that most pieces come from guessed block starts) and parse the text into batches; the table is `bfc -t1`'s."""
+    monkeypatch.setenv("BFC_INGEST_GZ_MIN", "0")
+    monkeypatch.setenv("BFC_INGEST_GZ_CHUNK", "20000")
+    gz = str(tmp_path / "g1.fq.gz")
+    with open(g1_fq, "rb") as f, gzip.open(gz, "wb", compresslevel=6) as g:
+        g.write(f.read())
+    for chunk in (100000000, 150000):
+        t = gpu_lib.bfc_count(gz, _opt(gpu_lib, k=31, bf_shift=26, n_threads=4, chunk_size=chunk))
+        assert t.count() == 99561 and oracle.l1_digest(*t.export_sorted()) == "237be10261b07ef0677f8136b0a327b6"
+        t.close()
+
+
 def test_bfc_count_filter_mode(gpu_lib, g1_fq):
     """-1 mode returns the bloom filter of k-mers seen twice (count.c:148-154) as a host bfc_bf_t."""
     b = gpu_lib.bfc_count(g1_fq, _opt(gpu_lib, k=51, bf_shift=26, filter_mode=1))
