@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_baseline_shapes.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3
-timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/try.log | python -c "
+for r in 7 9; do
+BFCG_R=$r timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary 2>gpurun_out/try_r$r.log | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d.get('verified')); print(d['secondary']['c2']['value'], d['secondary']['c2'].get('verified'), d['secondary']['c2'].get('stage_ms_per_step'))"
+d=json.loads(sys.stdin.readline()); print('R=$r', d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], d.get('verified'), d['config']['library_batches_per_step'], d['config']['slow_buckets'])" || tail -3 gpurun_out/try_r$r.log
+done
