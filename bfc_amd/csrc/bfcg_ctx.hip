@@ -904,6 +904,17 @@ static uint64_t find_cut(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *d_s
 
 // positions of a batch this context's regions take at full speed (with several ranks: of the global batch, divided by the ranks)
 extern "C" uint64_t bfcg_batch_limit(bfcg_ctx_t *c) { return split_limit(c); }
+// A rank of a multi-GPU run: how many times the cold limit its regions take at full speed right now.  Into a filter that is still filling up
+// every received k-mer takes an entry of its region's LDS list (1.0); later only the unseen ones do -- the share the last stage B showed
+// (of RECORDS here: bfcg_mg_process_ev counts what it received) -- and the aim is 60 % of the list capacity, at most 3 x the cold limit.
+extern "C" double bfcg_mg_warm_factor(bfcg_ctx_t *c)
+{
+	if (c->cold || getenv("BFCG_NO_WARM_BATCHES")) return 1.0;
+	double unseen = 1.0 - c->seen_per_pos;
+	if (unseen < 0.2) unseen = 0.2;
+	const double w = 0.6 / unseen;
+	return w < 1.0 ? 1.0 : w;
+}
 
 extern "C" int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos)
 {

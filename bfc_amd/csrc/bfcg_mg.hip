@@ -27,6 +27,7 @@
 
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 extern "C" void bfcg_set_error(const char *msg);
+extern "C" double bfcg_mg_warm_factor(bfcg_ctx_t *c);
 extern "C" int bfcg_resident_register(const void *bf, void *dev, int device, int n_shift);
 extern "C" void *bfcg_bloom_slice(bfcg_ctx_t *c, int which, uint64_t *bytes);
 
@@ -91,13 +92,16 @@ static int process_in_groups(bfcg_group_t *g, rank_t &R, const uint8_t *recv, co
 	std::vector<uint64_t> per_src((size_t)N, 0);
 	uint64_t total = 0;
 	for (int s = 0; s < N; ++s) { for (int k = 0; k < nb_loc; ++k) per_src[s] += seg_cnt[(size_t)s * nb_loc + k]; total += per_src[s]; }
-	if (g->prm.track_order || total <= g->kmer_limit || N == 1) return bfcg_mg_process_ev(R.ctx, recv, seg_cnt, wait, n_wait);
+	// (the limit follows the filter's fill, as a single GPU's batch cuts do: once most k-mers are seen again a region takes ~3 x as many per pass,
+	// and every pass streams the rank's share of the filter and of the table segments)
+	const uint64_t limit = (uint64_t)((double)g->kmer_limit * bfcg_mg_warm_factor(R.ctx));
+	if (g->prm.track_order || total <= limit || N == 1) return bfcg_mg_process_ev(R.ctx, recv, seg_cnt, wait, n_wait);
 	std::vector<uint32_t> seg((size_t)N * nb_loc);
 	uint64_t off = 0;
 	int s0 = 0, launched = 0;
 	while (s0 < N) {
 		uint64_t acc = per_src[s0]; int s1 = s0 + 1;
-		while (s1 < N && acc + per_src[s1] <= g->kmer_limit) acc += per_src[s1++];
+		while (s1 < N && acc + per_src[s1] <= limit) acc += per_src[s1++];
 		if (acc) {
 			memset(seg.data(), 0, seg.size() * sizeof(uint32_t));
 			memcpy(&seg[(size_t)s0 * nb_loc], &seg_cnt[(size_t)s0 * nb_loc], sizeof(uint32_t) * (size_t)(s1 - s0) * nb_loc);

@@ -161,3 +161,30 @@ def test_group_level2_slab_overflow_is_replayed(gpu_lib, n_ranks, fm):
     after = [grp.ctx(i).partition_info() for i in range(n_ranks)]
     assert sum(p["replayed_batches"] for p in after) >= 1, after
     grp.close(); oc.close()
+
+
+@pytest.mark.parametrize("fm", [0, 1])
+def test_group_overloaded_ranks_process_sources_in_groups(gpu_lib, g1, fm):
+    """-b24 over 4 ranks: 32 bloom regions per rank take ~80 000 k-mers per pass at full speed, a global batch brings each rank 200 000.  The
+    first batch (empty filter) is applied in groups of sources -- several stage B passes per rank, the result that of one batch because the
+    receive buffer is source-major and file order rank-major; the later ones (most k-mers seen again: a region takes three times as many) in
+    fewer passes.  No region on the slow path, and the oracle's filter(s), statistics and table."""
+    rs, (seq, qual, off) = g1
+    k, b, N = 31, 24, 4
+    oc = _oracle(k, b, seq, qual, off, filter_mode=fm)
+    n = rs.n_reads
+    per = n // 3 + 1
+    grp = gpu_lib.GpuGroup(k, b, [0] * N, max_batch_pos=per * (rs.L + 1) // N + 4096, filter_mode=fm)
+    launches = []
+    for a in range(0, n, per):
+        e = min(n, a + per)
+        grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
+        grp.sync()
+        launches.append([grp.ctx(i).stage_ms()[1] for i in range(N)])
+    first = launches[0]
+    later = [x - y for x, y in zip(launches[-1], launches[-2])]
+    assert all(v >= 2 for v in first), launches                     # the cold batch: several passes, each over some of the sources
+    assert all(l < f for l, f in zip(later, first)), launches       # a warm batch of the same size: fewer passes
+    assert grp.stats()["slow_buckets"] == 0
+    _compare(grp, oc, fm)
+    grp.close(); oc.close()
