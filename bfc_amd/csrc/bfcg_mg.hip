@@ -39,9 +39,10 @@ const uint64_t MSG_BYTES = 256ull << 20; // this image's RCCL truncates single m
 struct rank_t {
 	int rank, device;
 	bfcg_ctx_t *ctx;
-	hipStream_t xs;            // exchange stream
+	hipStream_t xs, cs;        // exchange stream; staging copies of host batches
 	hipEvent_t ev_x;           // this rank's part of the exchange is done (its receives with RCCL; its outgoing copies with peer copies)
-	uint8_t *send, *recv[2];
+	hipEvent_t ev_sent[2]; int sent_pending[2]; // the exchange that reads send buffer [t & 1] has drained (waited for before stage A writes it again)
+	uint8_t *send2[2], *recv[2]; // send buffers alternate, so that stage A of the next batch runs beside this batch's exchange
 	uint64_t send_cap, recv_cap; // bytes
 	uint32_t *counts;          // this rank's level-1 bucket sizes of the current batch (host)
 	uint32_t *d_counts;        // multi-process: all ranks' sizes, device side of the all-gather
@@ -69,6 +70,7 @@ struct bfcg_group {
 	char err[512];
 };
 
+static int drain_exchange(bfcg_group_t *g);
 static void grp_err(bfcg_group_t *g, const char *fmt, ...)
 {
 	pthread_mutex_lock(&g->mu);
@@ -127,19 +129,22 @@ static int rank_batch(bfcg_group_t *g, int i)
 	const uint64_t rb = (uint64_t)g->rec_bytes;
 	int ok = !g->failed;
 	GHIP(hipSetDevice(R.device));
-	// ---- stage A (the send buffer is free: the previous exchange of this rank was waited for below, before stage B was enqueued)
+	// ---- stage A into send buffer [t & 1]: the exchange two batches ago read it last
+	const int sb = (int)(g->t & 1);
+	uint8_t *const send = R.send2[sb];
+	if (R.sent_pending[sb]) { GHIP(hipEventSynchronize(R.ev_sent[sb])); R.sent_pending[sb] = 0; }
 	if (ok) {
 		const uint8_t *ds = R.in_seq, *dq = R.in_qual;
 		if (R.in_host && R.in_pos) {
 			if (R.in_pos > R.in_cap) { grp_err(g, "share of %llu positions exceeds the staging buffer", (unsigned long long)R.in_pos); ok = 0; }
 			else {
-				GHIP(hipMemcpyAsync(R.d_seq, R.in_seq, R.in_pos, hipMemcpyHostToDevice, R.xs));
-				if (R.in_qual) GHIP(hipMemcpyAsync(R.d_qual, R.in_qual, R.in_pos, hipMemcpyHostToDevice, R.xs));
-				GHIP(hipStreamSynchronize(R.xs));
+				GHIP(hipMemcpyAsync(R.d_seq, R.in_seq, R.in_pos, hipMemcpyHostToDevice, R.cs));
+				if (R.in_qual) GHIP(hipMemcpyAsync(R.d_qual, R.in_qual, R.in_pos, hipMemcpyHostToDevice, R.cs));
+				GHIP(hipStreamSynchronize(R.cs));
 				ds = R.d_seq; dq = R.in_qual ? R.d_qual : 0;
 			}
 		}
-		if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, R.send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+		if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
 	}
 	if (!ok) memset(R.counts, 0, sizeof(uint32_t) * (size_t)nb1);
 	memcpy(g->all_counts + (size_t)me * nb1, R.counts, sizeof(uint32_t) * (size_t)nb1);
@@ -172,13 +177,13 @@ static int rank_batch(bfcg_group_t *g, int i)
 	// ---- records
 	if (g->xp == XP_RCCL) {
 		if (ok) {
-			if (s_off[me + 1] > s_off[me]) GHIP(hipMemcpyAsync(recv + r_off[me] * rb, R.send + s_off[me] * rb, (s_off[me + 1] - s_off[me]) * rb, hipMemcpyDeviceToDevice, R.xs));
+			if (s_off[me + 1] > s_off[me]) GHIP(hipMemcpyAsync(recv + r_off[me] * rb, send + s_off[me] * rb, (s_off[me + 1] - s_off[me]) * rb, hipMemcpyDeviceToDevice, R.xs));
 			if (N > 1) GNCCL(ncclGroupStart());
 			for (int step = 1; step < N; ++step) { // ring-shifted peer order: every rank talks to a different peer at any time
 				const int to = (me + step) % N, from = (me - step + N) % N;
 				const uint64_t n_to = (s_off[to + 1] - s_off[to]) * rb, n_from = (r_off[from + 1] - r_off[from]) * rb;
 				for (uint64_t c0 = 0; c0 < (n_to > n_from ? n_to : n_from); c0 += MSG_BYTES) {
-					if (c0 < n_to) GNCCL(ncclSend(R.send + s_off[to] * rb + c0, (size_t)(n_to - c0 < MSG_BYTES ? n_to - c0 : MSG_BYTES), ncclUint8, to, R.comm, R.xs));
+					if (c0 < n_to) GNCCL(ncclSend(send + s_off[to] * rb + c0, (size_t)(n_to - c0 < MSG_BYTES ? n_to - c0 : MSG_BYTES), ncclUint8, to, R.comm, R.xs));
 					if (c0 < n_from) GNCCL(ncclRecv(recv + r_off[from] * rb + c0, (size_t)(n_from - c0 < MSG_BYTES ? n_from - c0 : MSG_BYTES), ncclUint8, from, R.comm, R.xs));
 				}
 			}
@@ -194,7 +199,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 				// my block in `to`'s buffer starts behind the blocks of the sources before me
 				uint64_t at = 0;
 				for (int p = 0; p < me; ++p) for (int k = 0; k < nb_loc; ++k) at += C[(size_t)p * nb1 + (size_t)to * nb_loc + k];
-				if (n_to) GHIP(hipMemcpyPeerAsync(T.recv[g->t & 1] + at * rb, T.device, R.send + s_off[to] * rb, R.device, n_to, R.xs));
+				if (n_to) GHIP(hipMemcpyPeerAsync(T.recv[g->t & 1] + at * rb, T.device, send + s_off[to] * rb, R.device, n_to, R.xs));
 			}
 			GHIP(hipEventRecord(R.ev_x, R.xs));
 		}
@@ -209,8 +214,11 @@ static int rank_batch(bfcg_group_t *g, int i)
 		else for (int j = 0; j < g->n_local; ++j) ev.push_back(g->r[j].ev_x);
 		if (process_in_groups(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
 	}
-	// the send buffer and (with peer copies) the other ranks' reads of all_counts: the next batch may start when my exchange has drained
-	(void)hipStreamSynchronize(R.xs);
+	// The exchange is left running: the next batch's stage A (other send buffer) proceeds beside it.  What the next batch may not do before
+	// this one is through is ordered elsewhere: its exchange follows this one on the stream xs; a receive buffer is written again two batches
+	// on, behind this barrier of the batch in between, which every rank reaches only after its bfcg_mg_process_ev has waited for THIS
+	// batch's stage B (finalise_previous); the other ranks have read all_counts before they come here.
+	if (ok) { GHIP(hipEventRecord(R.ev_sent[sb], R.xs)); R.sent_pending[sb] = 1; }
 	pthread_barrier_wait(&g->bar);
 	return g->failed ? -1 : 0;
 }
@@ -259,13 +267,16 @@ extern "C" void bfcg_group_destroy(bfcg_group_t *g)
 	if (!g) return;
 	pthread_mutex_lock(&g->mu); g->quit = 1; pthread_cond_broadcast(&g->cv); pthread_mutex_unlock(&g->mu);
 	for (auto &R : g->r) if (R.th) pthread_join(R.th, 0);
+	for (auto &R : g->r) { (void)hipSetDevice(R.device); if (R.xs) (void)hipStreamSynchronize(R.xs); } // every rank's exchange first: it writes into the others' buffers
 	for (auto &R : g->r) {
 		(void)hipSetDevice(R.device);
 		if (R.ctx) (void)bfcg_sync(R.ctx);
 		if (R.comm) (void)ncclCommDestroy(R.comm);
-		(void)hipFree(R.send); (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
+		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
 		if (R.ev_x) (void)hipEventDestroy(R.ev_x);
+		for (int b = 0; b < 2; ++b) if (R.ev_sent[b]) (void)hipEventDestroy(R.ev_sent[b]);
 		if (R.xs) (void)hipStreamDestroy(R.xs);
+		if (R.cs) (void)hipStreamDestroy(R.cs);
 		free(R.counts);
 		if (R.ctx) bfcg_destroy(R.ctx);
 	}
@@ -316,7 +327,10 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		hipError_t e = hipSetDevice(R.device);
 		if (e == hipSuccess) e = hipStreamCreateWithFlags(&R.xs, hipStreamNonBlocking);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_x, hipEventDisableTiming);
-		if (e == hipSuccess) e = hipMalloc(&R.send, R.send_cap = cap * (uint64_t)g->rec_bytes);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&R.cs, hipStreamNonBlocking);
+		for (int b = 0; b < 2; ++b) if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_sent[b], hipEventDisableTiming);
+		R.send_cap = cap * (uint64_t)g->rec_bytes;
+		for (int b = 0; b < 2; ++b) if (e == hipSuccess) e = hipMalloc(&R.send2[b], R.send_cap);
 		R.recv_cap = rcap * (uint64_t)g->rec_bytes;
 		if (e == hipSuccess) e = hipMalloc(&R.recv[0], R.recv_cap);
 		if (e == hipSuccess) e = hipMalloc(&R.recv[1], R.recv_cap);
@@ -351,13 +365,23 @@ extern "C" int bfcg_group_info(bfcg_group_t *g, int out[6])
 }
 extern "C" bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i) { return i >= 0 && i < g->n_local ? g->r[i].ctx : NULL; }
 
+static int drain_exchange(bfcg_group_t *g)
+{
+	for (auto &R : g->r) {
+		if (hipSetDevice(R.device) != hipSuccess || hipStreamSynchronize(R.xs) != hipSuccess) { bfcg_set_error("exchange stream failed"); return -1; }
+		R.sent_pending[0] = R.sent_pending[1] = 0;
+	}
+	return 0;
+}
 extern "C" int bfcg_group_reset(bfcg_group_t *g)
 {
+	if (drain_exchange(g) != 0) return -1;
 	for (auto &R : g->r) if (bfcg_reset(R.ctx) != 0) return -1;
 	return 0;
 }
 extern "C" int bfcg_group_sync(bfcg_group_t *g)
 {
+	if (drain_exchange(g) != 0) return -1;
 	for (auto &R : g->r) if (bfcg_sync(R.ctx) != 0) return -1;
 	return 0;
 }
@@ -391,6 +415,7 @@ extern "C" int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq
 // sums over the local ranks (a multi-process caller adds the processes' sums up); table geometry of rank `first`
 extern "C" int bfcg_group_stats(bfcg_group_t *g, uint64_t out[BFCG_ST_N])
 {
+	if (drain_exchange(g) != 0) return -1;
 	memset(out, 0, sizeof(uint64_t) * BFCG_ST_N);
 	for (auto &R : g->r) {
 		uint64_t st[BFCG_ST_N];
@@ -404,6 +429,7 @@ extern "C" int bfcg_group_stats(bfcg_group_t *g, uint64_t out[BFCG_ST_N])
 // THE count table of the run (all ranks local): the union of the ranks' disjoint tables
 extern "C" bfc_ch_t *bfcg_group_export_table(bfcg_group_t *g)
 {
+	if (drain_exchange(g) != 0) return NULL;
 	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_export_table needs every rank in this process (else: export per rank, bfc_ch_union)"); return NULL; }
 	std::vector<bfc_ch_t *> t;
 	bfc_ch_t *u = 0;
@@ -417,6 +443,7 @@ extern "C" bfc_ch_t *bfcg_group_export_table(bfcg_group_t *g)
 // THE bloom filter of the run (all ranks local): rank r owns the r-th 1/n_ranks of the bitmap
 extern "C" bfc_bf_t *bfcg_group_export_bloom(bfcg_group_t *g, int which)
 {
+	if (drain_exchange(g) != 0) return NULL;
 	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_export_bloom needs every rank in this process"); return NULL; }
 	bfc_bf_t *b = bfc_bf_alloc_raw(g->prm.bf_shift, g->prm.n_hashes);
 	if (!b) { bfcg_set_error("host allocation of the bloom filter failed"); return NULL; }
@@ -431,6 +458,7 @@ extern "C" bfc_bf_t *bfcg_group_export_bloom(bfcg_group_t *g, int which)
 // the reads over the same devices (bfc_trim.c) -- each of its contexts adopts the copy on its device instead of uploading 2^(b-3) bytes.
 extern "C" bfc_bf_t *bfcg_group_export_bloom_resident(bfcg_group_t *g, int which)
 {
+	if (drain_exchange(g) != 0) return NULL;
 	bfc_bf_t *b = bfcg_group_export_bloom(g, which);
 	if (!b) return NULL;
 	const uint64_t full = 1ULL << (g->prm.bf_shift - 3);
