@@ -268,6 +268,7 @@ typedef struct {
 	pgz_t *gz;             /* gzip input: `map` is the text the parallel inflate (bfc_pgz.h) holds from `pos` on, `size` unknown until its end */
 	const uint8_t *zmap; uint64_t zsize; /* the mapped .gz file */
 	int n_threads, active;
+	bfc_pool_t *pool;      /* n_threads - 1 workers, kept for the whole input */
 	uint64_t min_slice;    /* bytes a thread's slice has at least (65536; tests lower it to chain walks inside small files) */
 	double bytes_per_base; /* of the batches so far: sizes the next window */
 	fq_job_t *job;
@@ -275,11 +276,7 @@ typedef struct {
 
 static inline void fq_run(fq_fast_t *f, void *(*fn)(void*), int n)
 {
-	pthread_t tid[FQ_MAX_THREADS];
-	int i;
-	for (i = 1; i < n; ++i) pthread_create(&tid[i], 0, fn, &f->job[i]);
-	fn(&f->job[0]);
-	for (i = 1; i < n; ++i) pthread_join(tid[i], 0);
+	bfc_pool_run(f->pool, fn, f->job, sizeof(fq_job_t), n);
 }
 
 /* one batch out of the mapped file: 1 = done (b filled, f->pos advanced), 0 = not strict here: the caller falls back to the serial
@@ -444,6 +441,7 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 					in->fast.min_slice = getenv("BFC_INGEST_MIN_SLICE") ? strtoull(getenv("BFC_INGEST_MIN_SLICE"), 0, 10) : 65536;
 					if (in->fast.min_slice < 16) in->fast.min_slice = 16;
 					in->fast.job = (fq_job_t*)calloc((size_t)in->fast.n_threads, sizeof(fq_job_t));
+					in->fast.pool = bfc_pool_create(in->fast.n_threads); in->fast.gz->pool = in->fast.pool;
 				} else if (p[0] == '@') {
 					(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
 					in->fast.map = p; in->fast.size = (uint64_t)st.st_size; in->fast.pos = 0; in->fast.active = 1;
@@ -451,6 +449,7 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 					in->fast.min_slice = getenv("BFC_INGEST_MIN_SLICE") ? strtoull(getenv("BFC_INGEST_MIN_SLICE"), 0, 10) : 65536;
 					if (in->fast.min_slice < 16) in->fast.min_slice = 16;
 					in->fast.job = (fq_job_t*)calloc((size_t)in->fast.n_threads, sizeof(fq_job_t));
+					in->fast.pool = bfc_pool_create(in->fast.n_threads);
 				} else munmap(m, (size_t)st.st_size);
 			}
 		}
@@ -480,6 +479,7 @@ static inline void ingest_close(ingest_t *in)
 {
 	int i;
 	if (in->fast.gz) pgz_close(in->fast.gz);
+	bfc_pool_destroy(in->fast.pool);
 	if (in->fast.zmap) munmap((void*)in->fast.zmap, (size_t)in->fast.zsize);
 	else if (in->fast.map) munmap((void*)in->fast.map, (size_t)in->fast.size);
 	if (in->fast.job) { for (i = 0; i < in->fast.n_threads; ++i) free(in->fast.job[i].rec); free(in->fast.job); }

@@ -50,6 +50,83 @@ static inline void *pgz_big_realloc(void *old, size_t old_bytes, size_t new_byte
 	return p;
 }
 
+/* A small pool of worker threads for the ingest (the chained FASTQ walks, their copy phase, the inflate's two phases): a batch of 100 M bases
+ * is ~20 ms of work for 64 threads, and creating + joining 63 threads twice per batch was a third of that.  run(pool, fn, jobs, stride, n)
+ * runs fn(jobs + i * stride) for i < n, job 0 on the caller; one run at a time. */
+typedef struct bfc_pool_s {
+	pthread_t *th; int n_th, n_alloc;
+	pthread_mutex_t mu; pthread_cond_t cv_go, cv_done;
+	uint64_t gen; int quit, pending;
+	void *(*fn)(void*); char *jobs; size_t stride; int n_jobs;
+	struct bfc_pool_arg_s { struct bfc_pool_s *p; int idx; } *arg;
+} bfc_pool_t;
+
+static void *bfc_pool_worker(void *a)
+{
+	struct bfc_pool_arg_s *arg = (struct bfc_pool_arg_s*)a;
+	bfc_pool_t *p = arg->p;
+	const int idx = arg->idx;
+	uint64_t seen = 0;
+	for (;;) {
+		void *(*fn)(void*); char *job;
+		pthread_mutex_lock(&p->mu);
+		while (p->gen == seen && !p->quit) pthread_cond_wait(&p->cv_go, &p->mu);
+		if (p->quit) { pthread_mutex_unlock(&p->mu); return 0; }
+		seen = p->gen;
+		if (idx >= p->n_jobs) { pthread_mutex_unlock(&p->mu); continue; }
+		fn = p->fn; job = p->jobs + (size_t)idx * p->stride;
+		pthread_mutex_unlock(&p->mu);
+		fn(job);
+		pthread_mutex_lock(&p->mu);
+		if (--p->pending == 0) pthread_cond_signal(&p->cv_done);
+		pthread_mutex_unlock(&p->mu);
+	}
+}
+
+static inline bfc_pool_t *bfc_pool_create(int n_threads) /* n_threads - 1 workers; NULL for one thread or on failure (callers then run serially created threads) */
+{
+	bfc_pool_t *p;
+	int i;
+	if (n_threads < 2) return 0;
+	p = (bfc_pool_t*)calloc(1, sizeof(bfc_pool_t));
+	p->n_alloc = n_threads - 1;
+	p->th = (pthread_t*)calloc((size_t)p->n_alloc, sizeof(pthread_t));
+	p->arg = (struct bfc_pool_arg_s*)calloc((size_t)p->n_alloc, sizeof(*p->arg));
+	pthread_mutex_init(&p->mu, 0); pthread_cond_init(&p->cv_go, 0); pthread_cond_init(&p->cv_done, 0);
+	for (i = 0; i < p->n_alloc; ++i) {
+		p->arg[i].p = p; p->arg[i].idx = i + 1;
+		if (pthread_create(&p->th[i], 0, bfc_pool_worker, &p->arg[i]) != 0) break;
+		++p->n_th;
+	}
+	return p;
+}
+
+static inline void bfc_pool_destroy(bfc_pool_t *p)
+{
+	int i;
+	if (p == 0) return;
+	pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_go); pthread_mutex_unlock(&p->mu);
+	for (i = 0; i < p->n_th; ++i) pthread_join(p->th[i], 0);
+	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_go); pthread_cond_destroy(&p->cv_done);
+	free(p->th); free(p->arg); free(p);
+}
+
+static inline void bfc_pool_run(bfc_pool_t *p, void *(*fn)(void*), void *jobs, size_t stride, int n)
+{
+	int i, n_par = n;
+	if (p == 0 || n < 2) { for (i = 0; i < n; ++i) fn((char*)jobs + (size_t)i * stride); return; }
+	if (n_par > p->n_th + 1) n_par = p->n_th + 1; /* (fewer workers than jobs: the caller takes the rest) */
+	pthread_mutex_lock(&p->mu);
+	p->fn = fn; p->jobs = (char*)jobs; p->stride = stride; p->n_jobs = n_par; p->pending = n_par - 1; ++p->gen;
+	pthread_cond_broadcast(&p->cv_go);
+	pthread_mutex_unlock(&p->mu);
+	fn(jobs);
+	for (i = n_par; i < n; ++i) fn((char*)jobs + (size_t)i * stride);
+	pthread_mutex_lock(&p->mu);
+	while (p->pending) pthread_cond_wait(&p->cv_done, &p->mu);
+	pthread_mutex_unlock(&p->mu);
+}
+
 #define PGZ_WIN 32768
 #define PGZ_LB 11 /* bits of the literal/length root table */
 #define PGZ_DB 9  /* bits of the distance root table */
@@ -505,11 +582,17 @@ static uint32_t pgz_crc32_clmul(uint32_t crc0, const uint8_t *buf, size_t len)
 }
 #endif
 /* crc32() of zlib, 6x faster where the CPU multiplies carry-less (checked against zlib's own in tests/test_pgz.py) */
-static inline uint32_t pgz_crc32(uint32_t crc, const uint8_t *buf, size_t len)
+static inline int pgz_have_clmul(void) /* asked once per stream, before its threads run */
 {
 #if PGZ_X86
-	static int have = -1;
-	if (have < 0) have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("BFC_PGZ_NO_CLMUL");
+	return __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("BFC_PGZ_NO_CLMUL");
+#else
+	return 0;
+#endif
+}
+static inline uint32_t pgz_crc32(uint32_t crc, const uint8_t *buf, size_t len, int have)
+{
+#if PGZ_X86
 	if (have && len >= 64) { const size_t n = len & ~(size_t)15; crc = pgz_crc32_clmul(crc, buf, n); buf += n; len -= n; }
 #endif
 	while (len) { const size_t step = len < ((size_t)1 << 30) ? len : (size_t)1 << 30; crc = (uint32_t)crc32(crc, buf, (uInt)step); buf += step; len -= step; }
@@ -538,6 +621,8 @@ struct pgz_s {
 	uint8_t *text; uint64_t text_off, text_len, text_cap, text_head; /* the text held is text[text_head, text_head + text_len), stream offset text_off */
 	pgz_job_t *job; pgz_job_t *redo;       /* redo: the one that decodes again what did not chain */
 	uint64_t n_spec, n_redo, n_rounds;     /* pieces taken as guessed / decoded again */
+	bfc_pool_t *pool;                      /* the caller's worker threads (NULL: threads are created per phase) */
+	int clmul;                             /* CRC-32 by carry-less multiplication */
 };
 
 static void *pgz_decode_job(void *arg)
@@ -591,7 +676,7 @@ static void *pgz_narrow_job(void *arg)
 	if (j->m_seg < j->pc.n_mend + 1) { j->m_seg = j->pc.n_mend + 8; j->seg_crc = (uint32_t*)realloc(j->seg_crc, sizeof(uint32_t) * (size_t)j->m_seg); j->seg_len = (uint64_t*)realloc(j->seg_len, sizeof(uint64_t) * (size_t)j->m_seg); }
 	for (m = 0; m <= j->pc.n_mend; ++m) {
 		const size_t e = m < j->pc.n_mend ? (size_t)j->pc.mend[m].at : n;
-		j->seg_crc[m] = pgz_crc32((uint32_t)crc32(0L, Z_NULL, 0), j->dst + a, e - a); j->seg_len[m] = e - a; a = e;
+		j->seg_crc[m] = pgz_crc32((uint32_t)crc32(0L, Z_NULL, 0), j->dst + a, e - a, j->g->clmul); j->seg_len[m] = e - a; a = e;
 	}
 	return 0;
 }
@@ -600,6 +685,7 @@ static inline void pgz_par(pgz_t *g, void *(*fn)(void*), int n)
 {
 	pthread_t tid[PGZ_MAX_THREADS];
 	int i;
+	if (g->pool) { bfc_pool_run(g->pool, fn, g->job, sizeof(pgz_job_t), n); return; }
 	for (i = 1; i < n; ++i) pthread_create(&tid[i], 0, fn, &g->job[i]);
 	fn(&g->job[0]);
 	for (i = 1; i < n; ++i) pthread_join(tid[i], 0);
@@ -614,6 +700,7 @@ static inline pgz_t *pgz_open(const uint8_t *z, size_t zlen, int n_threads, size
 	g->chunk = chunk < 64 ? 64 : chunk;
 	g->cur = 0; g->cur_kind = PGZ_AT_MEMBER; g->win_len = 0;
 	g->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+	g->clmul = pgz_have_clmul();
 	g->job = (pgz_job_t*)calloc((size_t)g->T + 1, sizeof(pgz_job_t));
 	g->redo = &g->job[g->T];
 	for (i = 0; i <= g->T; ++i) { g->job[i].g = g; g->job[i].idx = i; g->job[i].pc.cap0 = PGZ_WIN + g->chunk * 6; }
