@@ -188,3 +188,31 @@ def test_group_overloaded_ranks_process_sources_in_groups(gpu_lib, g1, fm):
     assert grp.stats()["slow_buckets"] == 0
     _compare(grp, oc, fm)
     grp.close(); oc.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_group_c2_full_read_set(gpu_lib, n_ranks):
+    """The whole c2 read set (3.07 M reads, 367 M k-mers, k=31, -b33) through 2 / 4 emulated ranks in 4 global batches: the statistics, the bloom
+    filter (popcount + FNV-1a) and the table (distinct keys, both histograms, L1 digest) THE REFERENCE computed for these reads
+    (tests/golden/baseline.json) -- the multi-GPU path at the volumes of a real batch (tens of millions of records per rank and exchange)."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = {x["name"]: x for x in json.load(open(os.path.join(here, "golden", "baseline.json")))}["c2"]
+    rs = gen.ReadSet(**e["gen"])
+    per = 786_432
+    grp = gpu_lib.GpuGroup(e["k"], e["b"], [0] * n_ranks, max_batch_pos=per * (rs.L + 1) // n_ranks + 4096)
+    for r0 in range(0, rs.n_reads, per):
+        seq, qual, _ = rs.reads(r0, min(rs.n_reads, r0 + per))
+        grp.count_host(gen.to_stream(seq, rs.L, 10), gen.to_stream(qual, rs.L, 33))
+    st = grp.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"], st["n_keys"]) == (e["n_kmers"], e["n_high"], e["n_seen"], e["distinct"]), st
+    bf = grp.export_bloom(0)
+    assert gen.bitmap_checksums(bf.bytes()) == (e["bf_popcount"], int(e["bf_fnv1a64"], 16))
+    bf.close()
+    t = grp.export_table()
+    mode, cnt, high = t.hist()
+    assert int(mode) == e["hist_mode"] and np.array_equal(cnt, np.array(e["cnt"], dtype=np.uint64)) and np.array_equal(high, np.array(e["high"], dtype=np.uint64))
+    assert oracle.l1_digest(*t.export_sorted()) == e["l1_digest"]
+    t.close()
+    assert all(grp.ctx(i).partition_info()["level2_one_pass"] for i in range(n_ranks))
+    grp.close()
