@@ -92,7 +92,8 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 	if (ps.chunk_size > cap - cap / 32) ps.chunk_size = cap - cap / 32;
 	ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
 	if (ps.rd.fp == 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
-	gzbuffer(ps.rd.fp, 1 << 18);
+	/* (no gzbuffer: zlib is asked for kseq's own 16 KiB pieces through its default buffers, so that a damaged gzip file ends where it ends for
+	 * the reference -- rd_fill in bfc_ingest.h) */
 	ps.rd.buf = (uint8_t*)malloc(RD_BUF);
 	memset(&b, 0, sizeof(b));
 	b.cap = cap;

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python scripts/pcie_rate.py 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3 | tee gpurun_out/round2_pcie_rate.txt
+timeout 1200 python -m pytest tests/test_gpu_dropin.py -q -m gpu -x -k "damaged" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -8

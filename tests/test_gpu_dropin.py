@@ -308,6 +308,46 @@ def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
             assert pk(g.stderr.decode()) == pk(r.stderr.decode()) and (len(pk(r.stderr.decode())) > 1 or chunk != "50000"), (seed, chunk, t)
 
 
+@pytest.mark.usefixtures("dropin_bin", "gputrim_bin", "ref_bin")
+@pytest.mark.parametrize("seed", range(6))
+def test_binaries_equal_reference_on_damaged_gzip(tmp_path, seed):
+    """A truncated or corrupted .gz: zlib hands the reference text until it meets the damage, and where exactly that is depends on how it is asked
+    (kseq: 16 KiB a call).  The count pass (`bfc -E -d`, serial ingest and 4 threads with the parallel inflate forced on) dumps the reference's
+    bytes, and `bfc -1` (both passes on the GPU, the second reads the file again) prints the reference's trimmed reads."""
+    import gzip as gz_
+    rng = np.random.default_rng(300 + seed)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 30000)
+    recs = []
+    for r in range(4000):
+        l = int(rng.integers(60, 151)); p = int(rng.integers(0, 30000 - l))
+        q = rng.integers(33, 74, l).astype(np.uint8)
+        recs.append(b"@r%d\n" % r + genome[p:p + l].tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    z = bytearray(gz_.compress(b"".join(recs), 6))
+    what = seed % 3
+    if what == 0:
+        z = z[:int(rng.integers(len(z) // 2, len(z) - 1))]
+    elif what == 1:
+        z[int(rng.integers(len(z) // 2, len(z) - 8))] ^= 1 << int(rng.integers(0, 8))
+    else:
+        z[len(z) - 6] ^= 0x20   # the member's CRC-32
+    fn = str(tmp_path / "d.fq.gz")
+    open(fn, "wb").write(bytes(z))
+    env = dict(os.environ, BFC_GPU_EXACT_DUMP="1", BFC_INGEST_GZ_MIN="0", BFC_INGEST_GZ_CHUNK="15000")
+    ref_dump = str(tmp_path / "ref.hash")
+    r = subprocess.run([REFBIN, "-E", "-k", "21", "-b", "24", "-t", "1", "-L", "60000", "-d", ref_dump, fn], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    for t in ("1", "4"):
+        gpu_dump = str(tmp_path / ("gpu%s.hash" % t))
+        g = subprocess.run([DROPIN, "-E", "-k", "21", "-b", "24", "-t", t, "-L", "60000", "-d", gpu_dump, fn], capture_output=True, timeout=600, env=env)
+        assert g.returncode == 0, g.stderr.decode()[-800:]
+        assert open(gpu_dump, "rb").read() == open(ref_dump, "rb").read(), (seed, t)
+    args = ["-1", "-k", "21", "-b", "24", "-t", "2", "-L", "60000", fn]
+    r = subprocess.run([REFBIN] + args, capture_output=True, timeout=600)
+    g = subprocess.run([GPUTRIM] + args, capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0 and g.returncode == 0, (r.stderr.decode()[-500:], g.stderr.decode()[-500:])
+    assert g.stdout == r.stdout and len(r.stdout) > 50000, (seed, len(g.stdout), len(r.stdout))
+
+
 @pytest.mark.usefixtures("gputrim_bin", "ref_bin")
 @pytest.mark.parametrize("seed", range(8))
 def test_gpu_trim_equals_reference_binary_on_damaged_files(tmp_path, seed):
