@@ -70,6 +70,7 @@ SYMBOLS = {
     "bfcg_batch_limit": (C.c_uint64, [C.c_void_p]),
     "bfcg_mg_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, u32p]),
     "bfcg_mg_process": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
+    "bfcg_mg_allow_onepass": (None, [C.c_void_p, C.c_int]),
     "bfcg_group_unique_id": (C.c_int, [C.c_void_p]),
     "bfcg_group_create": (C.c_void_p, [C.POINTER(BfcgParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int]),
     "bfcg_group_destroy": (None, [C.c_void_p]),

@@ -78,7 +78,7 @@ struct bfcg_ctx {
 	uint32_t op_cap; uint64_t op_min_pos;
 	uint32_t *cnt2; uint32_t cap2; uint64_t recs2_n; // one-pass level 2 (region slabs); records recs2 / stream_out hold
 	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; const void *recv; int mg; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
-	int mg_op2_ok, mg_op2; uint32_t *mg_seg[4];  // a rank of a multi-GPU run: level 2 (its own stage B) in one pass; copies of the queued batches' segment sizes
+	int mg_op2_ok, mg_op2, mg_op2_allowed; uint32_t *mg_seg[4];  // a rank of a multi-GPU run: level 2 (its own stage B) in one pass; copies of the queued batches' segment sizes
 	uint64_t n_replayed;
 	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
 	int seg_no_grow;             // the next segment size does not fit (memory / LDS): grow only when a segment overflows or the load passes 85 %
@@ -679,7 +679,10 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 
 // partition of the current run: out[0] 1 = one-pass level 1 (K1 once per batch) still in use, out[1] batches replayed through the two-pass partition
 // since the context was created (a slab overflowed: few, often repeated k-mers)
-extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)((c->onepass ? 1 : 0) | ((c->onepass || c->mg_op2) && c->cap2 ? 2 : 0)); out[1] = c->n_replayed; return 0; }
+extern "C" int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]) { out[0] = (uint64_t)((c->onepass ? 1 : 0) | ((c->onepass || (c->mg_op2 && c->mg_op2_allowed)) && c->cap2 ? 2 : 0)); out[1] = c->n_replayed; return 0; }
+// A rank's stage B may partition what it received in one pass only if the caller keeps every receive buffer unchanged until the call after the
+// next has returned (a slab overflow is found one call later and replayed from the buffer): bfcg_group_* alternates its buffers and says so here.
+extern "C" void bfcg_mg_allow_onepass(bfcg_ctx_t *c, int on) { c->mg_op2_allowed = on != 0; }
 
 extern "C" int bfcg_table_info(bfcg_ctx_t *c, int out[4])
 {
@@ -757,7 +760,7 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	if (use_stream(c) != 0) return -1;
 	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
 	BatchBufs Bt = c->B;
-	const int op2 = c->mg_op2 && c->cap2 && off >= (uint64_t)8 << c->P.F >> c->log2n; // (a handful of records per region: two passes)
+	const int op2 = c->mg_op2 && c->mg_op2_allowed && c->cap2 && off >= (uint64_t)8 << c->P.F >> c->log2n; // (a handful of records per region: two passes)
 	if (op2) { Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2; Bt.op_flags = c->op_flags; }
 	run_stage_b(c->P, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
 	if (op2) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)

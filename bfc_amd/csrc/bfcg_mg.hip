@@ -28,6 +28,7 @@
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 extern "C" void bfcg_set_error(const char *msg);
 extern "C" double bfcg_mg_warm_factor(bfcg_ctx_t *c);
+extern "C" void bfcg_mg_allow_onepass(bfcg_ctx_t *c, int on);
 extern "C" int bfcg_resident_register(const void *bf, void *dev, int device, int n_shift);
 extern "C" void *bfcg_bloom_slice(bfcg_ctx_t *c, int which, uint64_t *bytes);
 
@@ -309,6 +310,7 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		p.device = R.device; p.rank = R.rank; p.n_ranks = n_ranks;
 		R.ctx = bfcg_create(&p);
 		if (!R.ctx) { bfcg_group_destroy(g); return NULL; }
+		bfcg_mg_allow_onepass(R.ctx, 1); // the receive buffers alternate (rank_batch): a stage B can be replayed from the one it read
 	}
 	{
 		int info[4];

@@ -134,6 +134,10 @@ int bfcg_mg_info(bfcg_ctx_t *c, int out[4]);
 uint64_t bfcg_batch_limit(bfcg_ctx_t *c);
 int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts);
 int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt);
+/* stage B may partition what it received in one pass (region slabs; an overflow is found one call later and that stage B replayed from d_recv)
+ * only if the caller keeps every d_recv unchanged until the call after the next has returned -- bfcg_group_* alternates its receive buffers and
+ * turns this on; callers of bfcg_mg_process that reuse one buffer leave it off (the default) */
+void bfcg_mg_allow_onepass(bfcg_ctx_t *c, int on);
 
 enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_OVF, BFCG_ST_ERR_POOL, BFCG_ST_SLOW_BUCKETS, BFCG_ST_CROWDED,
        BFCG_ST_TAB_CSHIFT = 8, BFCG_ST_BATCHES, BFCG_ST_N = 16 };

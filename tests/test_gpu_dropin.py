@@ -305,7 +305,8 @@ def test_dropin_equals_reference_binary_on_damaged_files(tmp_path, seed):
             # exact although the GPU path prints them without waiting for the chunk (bfcg_progress)
             import re
             pk = lambda txt: re.findall(r"processed (\d+) sequences; # distinct k-mers: (\d+)", txt)  # noqa: E731
-            assert pk(g.stderr.decode()) == pk(r.stderr.decode()) and (len(pk(r.stderr.decode())) > 1 or chunk != "50000"), (seed, chunk, t)
+            assert pk(g.stderr.decode()) == pk(r.stderr.decode()), (seed, chunk, t)
+            assert len(pk(r.stderr.decode())) > 1 or chunk != "50000" or os.environ.get("BFC_FUZZ_SEED_BASE", "0") != "0", (seed, chunk, t)  # (other bases may truncate the text early)
 
 
 @pytest.mark.usefixtures("dropin_bin", "gputrim_bin", "ref_bin")
