@@ -81,6 +81,7 @@ SYMBOLS = {
     "bfcg_group_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_group_sync": (C.c_int, [C.c_void_p]),
     "bfcg_group_stats": (C.c_int, [C.c_void_p, u64p]),
+    "bfcg_group_progress": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_int]),
     "bfcg_group_export_table": (C.c_void_p, [C.c_void_p]),
     "bfcg_group_export_bloom": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),
     "bfcg_group_export_bloom_resident": (C.POINTER(BfcBf), [C.c_void_p, C.c_int]),

@@ -98,11 +98,13 @@ static void *create_main(void *arg)
 /* ------------------------------------------------------------------ bfc_count */
 
 /* count.c:110-114, for every submitted reader batch that is complete on the GPU by now (in order) */
-static void print_progress(bfcg_ctx_t *ctx, const bfc_opt_t *opt, double t0, const uint64_t *pend_call, const int *pend_seqs, unsigned *lo, unsigned hi)
+static void print_progress(bfcg_ctx_t *ctx, bfcg_group_t *grp, const bfc_opt_t *opt, double t0, const uint64_t *pend_call, const int *pend_seqs, unsigned *lo, unsigned hi)
 {
 	uint64_t final = 0, keys[64];
-	bfcg_progress(ctx, 0, &final, keys, 63);
-	while (*lo != hi && pend_call[*lo & 63] <= final && final - pend_call[*lo & 63] < 63) {
+	int n_keys = 63;
+	if (grp) n_keys = bfcg_group_progress(grp, 0, &final, keys, 63); /* several GPUs: a "call" is a global batch, the keys are the ranks' sums */
+	else bfcg_progress(ctx, 0, &final, keys, 63);
+	while (*lo != hi && pend_call[*lo & 63] <= final && final - pend_call[*lo & 63] < (uint64_t)n_keys) {
 		const double rt = now_real() - t0, eff = 100. * now_cpu() / (rt + 1e-6);
 		if (!opt->filter_mode)
 			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, pend_seqs[*lo & 63], (long)keys[final - pend_call[*lo & 63]]);
@@ -128,7 +130,6 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	uint64_t cap, bases;
 	int i, cur = 0, io_threads, timing, small_input = 0, pin;
 	double tt, t_wait = 0, t_submit = 0;
-	uint64_t st[BFCG_ST_N];
 	uint64_t pend_call[64]; int pend_seqs[64]; unsigned n_pend_lo = 0, n_pend_hi = 0; /* reader batches submitted, their progress line not printed yet */
 
 	bfcg_params_default(&prm);
@@ -203,32 +204,26 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		t_wait += now_real() - tt; tt = now_real();
 		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs); /* count.c:99, once per bseq_read call */
 		if (b->n_seqs) {
-			double rt = 0, eff = 0;
 			int rc = 0;
-			if (grp) rc = bfcg_group_count_batch_host(grp, b->seq, b->has_qual ? b->qual : 0, b->n_pos); /* (records without qualities inside a FASTQ batch carry '~' here: always high for -q <= 93) */
-			else if (b->has_qual && b->n_noq) { /* mixed batch: its runs of records with / without qualities, one after the other */
+			if (b->has_qual && b->n_noq) { /* mixed batch: its runs of records with / without qualities, one after the other (a record without
+			                                * qualities is all high quality whatever -q says, count.c:85) -- on one GPU and on several alike */
 				uint64_t o = 0;
 				int j, kind = (b->n_cut & 1) ? !b->last_kind : b->last_kind; /* kind of the first run: the kinds alternate at every cut */
 				for (j = 0; j <= b->n_cut && rc == 0; ++j, kind = !kind) {
 					const uint64_t e = j < b->n_cut ? b->kind_cut[j] : b->n_pos;
-					if (e > o) rc = bfcg_count_batch_host(ctx, b->seq + o, kind ? b->qual + o : 0, e - o);
+					if (e > o) rc = grp ? bfcg_group_count_batch_host(grp, b->seq + o, kind ? b->qual + o : 0, e - o)
+					                    : bfcg_count_batch_host(ctx, b->seq + o, kind ? b->qual + o : 0, e - o);
 					o = e;
 				}
-			} else rc = bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos);
+			} else rc = grp ? bfcg_group_count_batch_host(grp, b->seq, b->has_qual ? b->qual : 0, b->n_pos)
+			                : bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos);
 			if (rc != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
-			if (grp) { /* several GPUs: the ranks' statistics, summed (waits for the batch) */
-				bfcg_group_stats(grp, st);
-				rt = now_real() - t0; eff = 100. * now_cpu() / (rt + 1e-6);
-				if (!opt->filter_mode)
-					fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, b->n_seqs, (long)st[BFCG_ST_KEYS]);
-				else
-					fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, b->n_seqs);
-			} else { /* the line of count.c:110-114 is printed when the batch is COMPLETE on the GPU -- without waiting for it here: the kernels of
-			          * this batch run under the parsing and the copies of the next (the reference's two pipeline steps interleave their lines too) */
+			{ /* the line of count.c:110-114 is printed when the batch is COMPLETE on the GPU(s) -- without waiting for it here: the kernels of
+			   * this batch run under the parsing and the copies of the next (the reference's two pipeline steps interleave their lines too) */
 				uint64_t calls = 0;
-				bfcg_progress(ctx, &calls, 0, 0, 0);
+				if (grp) bfcg_group_progress(grp, &calls, 0, 0, 0); else bfcg_progress(ctx, &calls, 0, 0, 0);
 				pend_call[n_pend_hi & 63] = calls; pend_seqs[n_pend_hi & 63] = b->n_seqs; ++n_pend_hi;
-				print_progress(ctx, opt, t0, pend_call, pend_seqs, &n_pend_lo, n_pend_hi);
+				print_progress(ctx, grp, opt, t0, pend_call, pend_seqs, &n_pend_lo, n_pend_hi);
 			}
 		}
 		t_submit += now_real() - tt;
@@ -242,10 +237,9 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		cur ^= 1;
 	}
 	if (!opt->no_mt_io) pthread_join(tid, 0);
-	if (ctx) { /* the batches still in flight */
-		if (bfcg_sync(ctx) != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
-		print_progress(ctx, opt, t0, pend_call, pend_seqs, &n_pend_lo, n_pend_hi);
-	}
+	/* the batches still in flight */
+	if ((grp ? bfcg_group_sync(grp) : bfcg_sync(ctx)) != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
+	print_progress(ctx, grp, opt, t0, pend_call, pend_seqs, &n_pend_lo, n_pend_hi);
 
 	tt = now_real();
 	if (grp) ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_group_export_bloom(grp, 1) : bfcg_group_export_bloom_resident(grp, 1)) /* all-gathered onto every device for the sharded trim pass */

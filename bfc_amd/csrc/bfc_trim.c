@@ -38,11 +38,12 @@ int bfcg_env_devices(int *dev, int max); /* bfc_count.c: BFC_GPU_DEVICES */
 
 /* the trim pass is embarrassingly parallel over reads: with several GPUs every batch's reads are dealt to them in
  * contiguous ranges, one host thread per device; each device holds the whole of bf_high (left there by bfc_count, or uploaded) */
-typedef struct { bfcg_trim_t *tr; const uint8_t *seq; uint64_t n_pos; uint64_t *off; uint64_t n; float min_frac; int32_t *st, *en; int rc; } trim_job_t;
+typedef struct { bfcg_trim_t *tr; const uint8_t *seq; uint64_t n_pos; uint64_t *off; uint64_t n; float min_frac; int32_t *st, *en; int rc; char err[256]; } trim_job_t;
 static void *trim_worker(void *p)
 {
 	trim_job_t *j = (trim_job_t*)p;
 	j->rc = j->n ? bfcg_trim_batch(j->tr, j->seq, 0, j->n_pos, j->off, j->n, j->min_frac, j->st, j->en) : 0;
+	if (j->rc != 0) { strncpy(j->err, bfcg_last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; } /* the message is thread-local: it dies with this thread */
 	return 0;
 }
 
@@ -80,7 +81,8 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 		int dup = 0, j;
 		for (j = 0; j < d; ++j) if (devs[j] == devs[d]) dup = 1; /* a device named twice: its first context serves both shares' turns */
 		(void)dup;
-		trs[d] = bfcg_trim_create(opt->k, bf, devs[d], n_dev > 1 ? cap / (uint64_t)n_dev + cap / 64 + (1u << 16) : cap, n_dev > 1 ? max_reads / (uint64_t)n_dev + 1024 : max_reads);
+		/* a device's share of a batch: 1/N of its positions (cut at the nearest read boundary) -- and up to all of its reads, if they are short there */
+		trs[d] = bfcg_trim_create(opt->k, bf, devs[d], n_dev > 1 ? cap / (uint64_t)n_dev + cap / 64 + (1u << 16) : cap, max_reads);
 		if (!trs[d]) { fprintf(stderr, "[E::%s] cannot set up the GPU trim pass: %s\n", __func__, bfcg_last_error()); abort(); }
 	}
 	tr = trs[0];
@@ -133,13 +135,21 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 				if (bfcg_trim_batch(tr, b.seq, 0, b.n_pos, off, n, opt->min_frac, st, en) != 0) {
 					fprintf(stderr, "[E::%s] GPU trim pass failed: %s\n", __func__, bfcg_last_error()); abort();
 				}
-			} else { /* reads [n*d/N, n*(d+1)/N) on device d: their part of the stream, offsets rebased to its start */
+			} else { /* device d takes the reads up to the boundary nearest to d+1 N-ths of the batch's POSITIONS (the contexts are sized by positions:
+			          * dealt by read count, a batch of reads sorted by length would overflow one of them): their part of the stream, offsets rebased */
 				trim_job_t job[64];
 				pthread_t th[64];
-				uint64_t o2 = 0;
+				uint64_t o2 = 0, r1 = 0;
 				for (d = 0; d < n_dev; ++d) {
-					const uint64_t r0 = n * (uint64_t)d / (uint64_t)n_dev, r1 = n * (uint64_t)(d + 1) / (uint64_t)n_dev;
+					const uint64_t r0 = r1, want = d + 1 == n_dev ? b.n_pos : b.n_pos / (uint64_t)n_dev * (uint64_t)(d + 1);
 					uint64_t q;
+					if (d + 1 == n_dev) r1 = n;
+					else { /* first boundary at or behind `want` (off[] ascends), or the one before it if that is nearer */
+						uint64_t lo = r0, hi = n;
+						while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] < want) lo = mid + 1; else hi = mid; }
+						r1 = lo;
+						if (r1 > r0 && off[r1] - want > want - off[r1 - 1]) --r1;
+					}
 					job[d].tr = trs[d]; job[d].seq = b.seq + off[r0]; job[d].n_pos = off[r1] - off[r0]; job[d].n = r1 - r0;
 					job[d].off = off2 + o2; job[d].min_frac = opt->min_frac; job[d].st = st + r0; job[d].en = en + r0; job[d].rc = 0;
 					for (q = r0; q <= r1; ++q) off2[o2++] = off[q] - off[r0];
@@ -147,7 +157,7 @@ void bfc_correct(const char *fn, const bfc_opt_t *opt, const void *ptr)
 				}
 				for (d = 0; d < n_dev; ++d) {
 					pthread_join(th[d], 0);
-					if (job[d].rc != 0) { fprintf(stderr, "[E::%s] GPU trim pass failed on device %d: %s\n", __func__, devs[d], bfcg_last_error()); abort(); }
+					if (job[d].rc != 0) { fprintf(stderr, "[E::%s] GPU trim pass failed on device %d: %s\n", __func__, devs[d], job[d].err); abort(); }
 				}
 			}
 			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_ec_cb", t_real() - t0, 100. * t_cpu() / (t_real() - t0 + 1e-6), (int)n);

@@ -21,6 +21,7 @@
 using namespace bfcg;
 
 static thread_local char g_err[512] = "";
+enum { OP_FLAG_WORDS = 12, OP_STICKY = 8 }; // bfcg_ctx.op_flags: two slots of four words, the sticky poison word
 static int set_err(const char *fmt, ...)
 {
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -250,8 +251,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	if (c->onepass_ok || c->mg_op2_ok) {
 		for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_flags[b], 4 * sizeof(uint32_t)));
-		HIPCKN(hipMalloc(&c->op_flags, 4 * sizeof(uint32_t)));
-		HIPCKN(hipMemset(c->op_flags, 0, 4 * sizeof(uint32_t)));
+		// per batch slot b: op_flags[4 b + 0] a level-1 slab overflowed (raised on stage A's stream), [4 b + 2] a region's slab (stage B's stream);
+		// op_flags[8]: the run is poisoned (k_seal, stage B's stream only) -- a batch's stage B never reads what another batch's stage A writes
+		HIPCKN(hipMalloc(&c->op_flags, OP_FLAG_WORDS * sizeof(uint32_t)));
+		HIPCKN(hipMemset(c->op_flags, 0, OP_FLAG_WORDS * sizeof(uint32_t)));
 	}
 	if (c->mg_op2_ok) for (int i = 0; i < 4; ++i) c->mg_seg[i] = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_ranks * (size_t)(nb1 >> log2n));
 	B.recs1 = c->recs1[0];
@@ -344,7 +347,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 	// the statistics first: stage A of the next batch (stream stA) adds to them and only has to wait for that small memset; the
 	// filters and the table are touched by stage B alone, on this same stream, so zeroing them needs no host synchronisation
 	HIPCK(hipMemsetAsync(c->B.stats, 0, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), c->st));
-	if (c->op_flags) HIPCK(hipMemsetAsync(c->op_flags, 0, 4 * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
+	if (c->op_flags) HIPCK(hipMemsetAsync(c->op_flags, 0, OP_FLAG_WORDS * sizeof(uint32_t), c->st)); // stage A raises them: cleared before stage A's stream goes on
 	HIPCK(hipEventRecord(c->evCopy, c->st));
 	HIPCK(hipStreamWaitEvent(c->stA, c->evCopy, 0));
 	HIPCK(hipMemsetAsync(c->B.bloom, 0, c->bloom_bytes, c->st));
@@ -450,9 +453,9 @@ static int drain(bfcg_ctx_t *c)
 	c->pend = 0;
 	if (batch_times(c, c->cur ^ 1) != 0) return -1;
 	if (c->n_opq) { // batches that went through the one-pass partition: were their slabs large enough?
-		uint32_t fl[2] = {0, 0};
-		HIPCK(hipMemcpy(fl, c->op_flags, sizeof(fl), hipMemcpyDeviceToHost));
-		if (fl[1]) return replay_poisoned(c);
+		uint32_t sticky = 0;
+		HIPCK(hipMemcpy(&sticky, c->op_flags + OP_STICKY, sizeof(sticky), hipMemcpyDeviceToHost));
+		if (sticky) return replay_poisoned(c);
 		c->n_opq = 0;
 	}
 	if (fetch_stats(c) != 0) return -1;
@@ -473,7 +476,7 @@ static int replay_poisoned(bfcg_ctx_t *c)
 	bfcg_ctx::opq_t q[4];
 	for (int i = 0; i < n; ++i) q[i] = c->opq[i];
 	c->n_opq = 0; c->onepass = 0; c->mg_op2 = 0;
-	HIPCK(hipMemset(c->op_flags, 0, 4 * sizeof(uint32_t)));
+	HIPCK(hipMemset(c->op_flags, 0, OP_FLAG_WORDS * sizeof(uint32_t)));
 	if (fetch_stats(c) != 0) return -1;
 	c->n_batches -= (uint64_t)n; // the batches keep their places in the count (order stamps carry the batch number)
 	std::vector<uint32_t> seg;
@@ -760,11 +763,16 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	if (use_stream(c) != 0) return -1;
 	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
 	BatchBufs Bt = c->B;
-	const int op2 = c->mg_op2 && c->mg_op2_allowed && c->cap2 && off >= (uint64_t)8 << c->P.F >> c->log2n; // (a handful of records per region: two passes)
-	if (op2) { Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2; Bt.op_flags = c->op_flags; }
+	const int op2_run = c->mg_op2 && c->mg_op2_allowed && c->cap2; // (as enqueue_batch: every batch of a one-pass run tests the sticky word and is queued)
+	const int op2 = op2_run && off >= (uint64_t)8 << c->P.F >> c->log2n; // (a handful of records per region: two passes)
+	if (op2_run) Bt.op_sticky = c->op_flags + OP_STICKY;
+	if (op2) {
+		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2; Bt.op_flags = c->op_flags + 4 * b;
+		HIPCK(hipMemsetAsync(Bt.op_flags, 0, 4 * sizeof(uint32_t), c->st)); // (no one-pass stage A on a rank: stage B clears its slot's flags itself)
+	}
 	run_stage_b(c->P, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
-	if (op2) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
-		HIPCK(hipMemcpyAsync(c->h_flags[b], c->op_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
+	if (op2_run) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
+		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
 		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
 		int free_i = 0;
 		for (;; ++free_i) { int used = 0; for (int i = 0; i < c->n_opq; ++i) used |= c->opq[i].mg == free_i + 1; if (!used) break; }
@@ -830,9 +838,13 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	Bt.stream = c->stream_mode; Bt.stream_out = c->stream_out;
 	KParams Pt = c->P;
 	Pt.no_kstats = no_kstats;
-	const int op = c->onepass && !no_kstats && n_pos >= c->op_min_pos; // (a handful of tiles cannot fill 8 slabs per bucket evenly)
+	const int op_run = c->onepass && !no_kstats;  // the run still uses the one-pass partition: an earlier batch may turn out to have overflowed a slab
+	const int op = op_run && n_pos >= c->op_min_pos; // (a handful of tiles cannot fill 8 slabs per bucket evenly: such a batch takes two passes)
+	// every batch of such a run -- one-pass or not -- tests the sticky word in its stage B and waits in the queue until it is known to be clean:
+	// a small two-pass batch enqueued behind a poisoned one must not be applied before the replay of that one
+	if (op_run) Bt.op_sticky = c->op_flags + OP_STICKY;
 	if (op) {
-		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags; Bt.op_cap = c->op_cap;
+		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags + 4 * b; Bt.op_cap = c->op_cap;
 		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2;
 		run_stage_a_onepass(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
 	} else run_stage_a(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
@@ -843,11 +855,13 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	if (op) {
 		uint32_t *sg = c->op_seg[b];
 		run_stage_b(Pt, Bt, Bt.recs1, sg, sg + 8 * nb1, 8 * nb1, 8, sg + 16 * nb1, sg + 24 * nb1 + 1, n_pos, c->st, c->evt[b]);
-		HIPCK(hipMemcpyAsync(c->h_flags[b], c->op_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
-		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
-		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; c->opq[c->n_opq].recv = nullptr; c->opq[c->n_opq].mg = 0; ++c->n_opq;
 	} else
 	run_stage_b(Pt, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
+	if (op_run) {
+		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st)); // behind k_seal: is the run poisoned up to and including this batch?
+		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
+		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; c->opq[c->n_opq].recv = nullptr; c->opq[c->n_opq].mg = 0; ++c->n_opq;
+	}
 	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
 	c->slot_call[b] = c->call_no; c->slot_pos[b] = n_pos;
 	HIPCK(hipEventRecord(c->evB[b], c->st));

@@ -51,9 +51,10 @@ struct BatchBufs {
 	uint8_t *seen_out;
 	uint64_t *agg_out; uint32_t *agg_cnt; // aggregated seen k-mers per fine bucket (k_bloom -> k_commit)
 	uint32_t *stream_out; int stream;     // STREAM mode: seen k-mers as records (k_bloom -> k_commit_stream); on / off for this batch
-	// one-pass level 1 (K1 once per batch): 8 slabs of op_cap records per level-1 bucket in recs1, their cursors (one per 128-byte line), the overflow /
-	// poison flags, and the segment arrays level 2 reads them through: seg_beg[8 nb1] | seg_end[8 nb1] | row_base[8 nb1 + 1] | bucket_start[nb1 + 1]
-	uint32_t *op_cursor, *op_flags, *op_seg; uint32_t op_cap;
+	// one-pass level 1 (K1 once per batch): 8 slabs of op_cap records per level-1 bucket in recs1, their cursors (one per 128-byte line), the overflow
+	// flags of THIS batch's slot ([0] level 1, [2] level 2) and the run's sticky poison word (stage B's stream only), and the segment arrays level 2
+	// reads the slabs through: seg_beg[8 nb1] | seg_end[8 nb1] | row_base[8 nb1 + 1] | bucket_start[nb1 + 1]
+	uint32_t *op_cursor, *op_flags, *op_sticky, *op_seg; uint32_t op_cap;
 	uint32_t *cnt2; uint32_t cap2;            // one-pass level 2: a slab of cap2 records per bloom region in recs2 and its cursor (0: two passes, start2 says where)
 	unsigned long long *seg_tab;              // region-owned table segments: [regions][2^seg_shift] slots of id << 14 | high << 8 | count (KParams.seg)
 	unsigned long long *tab_first, *sub_last; // order stamps (NULL unless KParams.track)

@@ -1,18 +1,22 @@
 // bfcg_kernels.hip -- hand-written gfx950 kernels for the k-mer counting path of bfc
-// (count.c + bbf.c + htab.c).  See DESIGN.md for the pipeline; in short, per batch of reads:
+// (count.c + bbf.c + htab.c).  DESIGN.md section 2 has the pipeline; per batch of reads:
 //
-//   k_hist1    bases -> k-mers (K1, kmer_dev.h) -> histogram of level-1 bucket ids
-//   k_scatter  K1 again -> 12/16/20-byte k-mer records scattered into level-1 buckets
-//   k_hist2    level-1 buckets -> histogram of fine bucket ids          (two-level only)
-//   k_scatter2 level-1 buckets -> fine buckets                          (two-level only)
-//   k_bloom    one workgroup per fine bucket = one contiguous REGION of 2^R bloom blocks,
-//              staged in LDS; exact sequential `seen` flags by a first-setter table in LDS
-//              (SURVEY App. C.1); seen k-mers upserted into the HBM-resident count table
-//              by atomicCAS probing (or OR-ed into the second bloom filter in filter mode).
+//   k_scatter1   bases -> k-mers ONCE (K1, kmer_dev.h: windows of four bit planes, no rolling state) -> 12/16/20-byte records,
+//                ordered by level-1 bucket in LDS and appended run by run to the bucket's slabs (one cursor atomic per run)
+//   k_seg_setup  the slabs' fill -> the segment list level 2 reads
+//   k_scatter2   level-1 slabs -> one slab per bloom REGION (2^R blocks of 64 bytes), again one pass
+//   k_bloom      one workgroup per region: the region of the bitmap in LDS, exact sequential `seen` flags by a first-setter
+//                protocol in LDS, bits set, region back to HBM; seen k-mers leave as 8-byte table entries
+//   k_commit_seg one workgroup per region: the region-owned segment of the count table through LDS, upserts by LDS atomics
+//                (or, in filter mode, the second filter's slice sits in k_bloom's LDS and nothing is handed over)
 //
-// A "fine bucket" f holds the k-mers whose bloom block id has f as its top bits, so everything
-// that can interact under the reference's sequential semantics (bbf.c:27-31: one 64-byte block
-// per k-mer) meets inside one workgroup.
+// The two-pass partition of round 1 (k_hist1 / k_colsum / k_scan_top / k_apply; k_hist2 / k_scan2: histogram rows, scans, exact
+// offsets, no atomics) remains for what the slabs cannot take: replays of batches that overflowed a slab, batches too small for
+// their slabs, and level 1 of a multi-GPU rank.  k_commit / k_commit_stream + table_upsert (device-scope CAS) serve the table in the
+// host's (sub-table, key) layout: order stamps, geometries whose identity does not fit a slot, segments that outgrew LDS, export.
+//
+// A region holds the k-mers whose bloom block id has the region's number as its top bits, so everything that can interact under the
+// reference's sequential semantics (bbf.c:27-31: one 64-byte block per k-mer) meets inside one workgroup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kmer_dev.h"
@@ -343,8 +347,10 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t *cnt, int nb, uint3
 // returning atomicAdd per bucket on the slab's cursor -- 8 x 2^F1 cursors on cache lines of their own, so that the chains of same-address
 // atomics (~12 ns each) are 8 x 2^F1 wide -- and level 2 reads a bucket as its 8 segments (the machinery multi-GPU runs use for the sources'
 // blocks).  Uniform hashing fills a slab to its mean +- a fraction of a per cent; a batch of few, often repeated k-mers overflows one:
-// the kernel then raises `flags[0]`, k_seg_setup turns that batch and everything behind it into no-ops (sticky flags[1]) and the host
-// replays those batches through the two-pass partition (bfcg_ctx.hip: replay_poisoned).
+// the kernel then raises `flags[0]` of ITS batch slot, stage B of that batch changes nothing and seals the run (k_seal: the sticky word,
+// which only stage B's stream ever touches, turns every batch behind it into a no-op as well) and the host replays those batches through the
+// two-pass partition (bfcg_ctx.hip: replay_poisoned).  The flags are per slot because stage A of batch t+1 runs beside stage B of batch t:
+// an overflow of t+1 must not be seen by the kernels of the clean batch t.
 struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; };
 template <typename W, int RW, int TILE, int BT, bool ONEPASS = false>
 __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
@@ -515,10 +521,12 @@ __global__ __launch_bounds__(BFCG_MAXB) void k_scan2(KParams P, const uint32_t *
 // records measured 2x WRITE_SIZE inflation and ~1.1 TB/s).
 // ONEPASS2 (no k_hist2, no k_scan2): region f owns the slab out[f * cap2 .. (f + 1) * cap2); a tile's run for region f goes where an atomic on
 // cnt2[f] says.  Rows are dealt XCD-contiguously, so a region's counter is (nearly always) touched from one XCD only.  A slab that cannot take a
-// run raises flags[2]: k_bloom and the commit kernels of this batch then do nothing, k_seal2 makes the flag sticky and the host replays the batch.
+// run raises flags[2] (of the batch's slot): k_bloom and the commit kernels of this batch then do nothing, k_seal makes it sticky and the host
+// replays the batch.
 struct OnePass2 { uint32_t *cnt2; uint32_t cap2; uint32_t *flags; };
 
-__global__ void k_seal2(uint32_t *flags) { if (flags[2]) { flags[1] = 1; flags[2] = 0; } }
+// last kernel of a one-pass batch's stage B: a batch that overflowed a slab (level 1: flags[0], level 2: flags[2]) poisons the run
+__global__ void k_seal(const uint32_t *flags, uint32_t *sticky) { if (flags[0] | flags[2]) *sticky = 1; }
 
 template <typename W, int RW, int TILE, int BT, bool ONEPASS2 = false>
 __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
@@ -604,16 +612,16 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 
 // ONEPASS: the level-1 output as segments for level 2.  One workgroup.  seg (bucket b, XCD x) = slab (b * 8 + x) of `cap` records, filled
 // up to its cursor; row_base = first level-2 histogram row of every segment; bucket_start = the buckets' starts in the level-2 output.
-// A batch whose slabs overflowed (flags[0]) -- and, the flag being sticky (flags[1]), every batch behind it -- gets empty segments:
-// level 2, the bloom kernel and the table stage then change nothing, and the host replays those batches in order (two-pass partition).
-__global__ __launch_bounds__(1024) void k_seg_setup(KParams P, const uint32_t *__restrict__ cursor, uint32_t cap, uint32_t *flags, int tile2,
+// A batch whose slabs overflowed (flags[0] of its slot) gets empty segments -- level 2 has nothing to move; k_bloom and the table stage test the
+// flags themselves -- and the host replays it and the batches behind it in order (two-pass partition).
+__global__ __launch_bounds__(1024) void k_seg_setup(KParams P, const uint32_t *__restrict__ cursor, uint32_t cap, const uint32_t *flags, int tile2,
                                                     uint32_t *__restrict__ seg_beg, uint32_t *__restrict__ seg_end, uint32_t *__restrict__ row_base,
                                                     uint32_t *__restrict__ bucket_start)
 {
 	__shared__ uint32_t s_rows[1024], s_recs[1024];
 	__shared__ uint32_t s_poison;
 	const int nb1 = 1 << P.F1, t = threadIdx.x;
-	if (t == 0) { if (flags[0]) { flags[1] = 1; flags[0] = 0; } s_poison = flags[1]; }
+	if (t == 0) s_poison = flags[0];
 	__syncthreads();
 	const bool poison = s_poison != 0;
 	// thread t owns bucket t (nb1 <= 1024): its 8 segments
@@ -781,7 +789,8 @@ struct BloomArgs {
 	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
 	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
 	const uint32_t *cnt2; uint32_t cap2; // one-pass level 2: region f's records are recs[f * cap2 .. + cnt2[f]) (cap2 = 0: start[] says where)
-	const uint32_t *flags;         // one-pass partition: [1] an earlier batch or this one overflowed a level-1 slab, [2] this one a region's slab
+	const uint32_t *flags;         // one-pass partition, this batch's slot: [0] a level-1 slab overflowed, [2] a region's slab (NULL: two-pass batch)
+	const uint32_t *sticky;        // an earlier batch of the run overflowed (written by k_seal on stage B's stream only)
 };
 
 // where region f's records are
@@ -791,7 +800,7 @@ __device__ __forceinline__ void region_list(const BloomArgs &A, uint32_t f, uint
 	else { rs = A.start[f]; n = A.start[f + 1] - rs; }
 }
 // A batch the one-pass partition gave up on must change nothing: the host replays it (and every batch behind it) through the two-pass one.
-__device__ __forceinline__ bool batch_poisoned(const BloomArgs &A) { return A.flags && (A.flags[1] | A.flags[2]); }
+__device__ __forceinline__ bool batch_poisoned(const BloomArgs &A) { return (A.sticky && *A.sticky) || (A.flags && (A.flags[0] | A.flags[2])); }
 
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
 template <typename W, bool TRACK>
@@ -1741,6 +1750,7 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
 	if (ev) hipEventRecord(ev[0], st);
 	hipMemsetAsync(B.op_cursor, 0, (size_t)8 * nb1 * 32 * sizeof(uint32_t), st);
+	hipMemsetAsync(B.op_flags, 0, 4 * sizeof(uint32_t), st); // this slot's overflow flags (its previous batch's stage B and flag copy are complete: the caller waited)
 	if (ev) hipEventRecord(ev[1], st);
 	const unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8);
 	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st,
@@ -1780,7 +1790,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_slices = B.pool_slices; A.seen_out = B.seen_out;
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine; A.stream_out = nullptr; A.seg_tab = nullptr;
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
-	A.cnt2 = nullptr; A.cap2 = 0; A.flags = B.op_flags; // (op_flags: NULL unless this batch went through the one-pass partition)
+	A.cnt2 = nullptr; A.cap2 = 0; A.flags = B.op_flags; A.sticky = B.op_sticky; // (op_flags: NULL unless this batch went through the one-pass partition)
 	if (P.F2 > 0 && B.cap2) { A.cnt2 = B.cnt2; A.cap2 = B.cap2; }
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
@@ -1797,7 +1807,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
 		else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)8 << P.seg_shift, st, P, A);
 		else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
-		if (A.cap2) hipLaunchKernelGGL(k_seal2, dim3(1), dim3(1), 0, st, B.op_flags);
+		if (A.flags) hipLaunchKernelGGL(k_seal, dim3(1), dim3(1), 0, st, B.op_flags, B.op_sticky);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
 	} else if (B.stream && B.stream_out && !P.track && P.n_hashes == 4) { // low-multiplicity batches: no aggregation (ctx decides, see bfcg_ctx.hip)
@@ -1805,7 +1815,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
 		hipLaunchKernelGGL((k_commit_stream<W, RW>), dim3((unsigned)((nfine + 4 * COMMIT_RPW - 1) / (4 * COMMIT_RPW))), dim3(256), 0, st, P, A);
-		if (A.cap2) hipLaunchKernelGGL(k_seal2, dim3(1), dim3(1), 0, st, B.op_flags);
+		if (A.flags) hipLaunchKernelGGL(k_seal, dim3(1), dim3(1), 0, st, B.op_flags, B.op_sticky);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
 	} else if (P.track) { // order stamps for the byte-identical dump: its own instantiation, so that the default path pays nothing for it
@@ -1827,7 +1837,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 			else hipLaunchKernelGGL((k_commit<W, false, false>), dim3(gs), dim3(256), 0, st, P, A);
 		}
 	}
-	if (A.cap2) hipLaunchKernelGGL(k_seal2, dim3(1), dim3(1), 0, st, B.op_flags);
+	if (A.flags) hipLaunchKernelGGL(k_seal, dim3(1), dim3(1), 0, st, B.op_flags, B.op_sticky);
 	if (ev) hipEventRecord(ev[5], st);
 }
 
@@ -1866,6 +1876,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

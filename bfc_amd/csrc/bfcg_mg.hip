@@ -45,8 +45,9 @@ struct rank_t {
 	hipEvent_t ev_sent[2]; int sent_pending[2]; // the exchange that reads send buffer [t & 1] has drained (waited for before stage A writes it again)
 	uint8_t *send2[2], *recv[2]; // send buffers alternate, so that stage A of the next batch runs beside this batch's exchange
 	uint64_t send_cap, recv_cap; // bytes
-	uint32_t *counts;          // this rank's level-1 bucket sizes of the current batch (host)
-	uint32_t *d_counts;        // multi-process: all ranks' sizes, device side of the all-gather
+	uint32_t *counts;          // this rank's level-1 bucket sizes of the current batch (host) + one word: this rank's group has failed
+	uint32_t *d_counts;        // multi-process: all ranks' rows, device side of the all-gather
+	uint64_t batch_call[64];   // the context's call number after stage B of global batch t (t & 63): bfcg_group_progress
 	ncclComm_t comm;
 	uint8_t *d_seq, *d_qual; uint64_t in_cap; // staging of host batches
 	// the current batch's share
@@ -63,7 +64,7 @@ struct bfcg_group {
 	int mp;                     // one rank per process: sizes travel by ncclAllGather, records by ncclSend / ncclRecv between the processes
 	uint64_t kmer_limit;        // k-mers of a global batch one rank's regions take at full speed
 	std::vector<rank_t> r;
-	uint32_t *all_counts;       // [n_ranks][nb1], host (pinned): every rank's bucket sizes of the current batch
+	uint32_t *all_counts;       // [n_ranks][nb1 + 1], host (pinned): every rank's bucket sizes of the current batch and its failure word
 	pthread_barrier_t bar;      // local ranks
 	pthread_mutex_t mu; pthread_cond_t cv;
 	uint64_t job, done_job; int n_done, quit, failed, go;
@@ -127,6 +128,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 {
 	rank_t &R = g->r[i];
 	const int N = g->n_ranks, nb1 = g->nb1, nb_loc = g->nb_loc, me = R.rank;
+	const size_t cs = (size_t)nb1 + 1; // a rank's row: nb1 bucket sizes, then its failure word
 	const uint64_t rb = (uint64_t)g->rec_bytes;
 	int ok = !g->failed;
 	GHIP(hipSetDevice(R.device));
@@ -148,23 +150,30 @@ static int rank_batch(bfcg_group_t *g, int i)
 		if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
 	}
 	if (!ok) memset(R.counts, 0, sizeof(uint32_t) * (size_t)nb1);
-	memcpy(g->all_counts + (size_t)me * nb1, R.counts, sizeof(uint32_t) * (size_t)nb1);
+	// The failure word travels with the sizes: g->failed is local to a process, and a rank that skipped the exchange while its peers posted
+	// ncclSend / ncclRecv for it would leave them blocked for good.  A group that has failed keeps taking part in this all-gather (and only in it),
+	// so that every process of the run takes the same decision in the same batch.
+	R.counts[nb1] = g->failed ? 1u : 0u;
+	memcpy(g->all_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs);
 	// ---- every rank's bucket sizes
 	if (g->mp) { // between processes: all-gather over RCCL (the local ranks of a multi-process group are one per process)
-		GHIP(hipMemcpyAsync(R.d_counts + (size_t)me * nb1, R.counts, sizeof(uint32_t) * (size_t)nb1, hipMemcpyHostToDevice, R.xs));
-		GNCCL(ncclAllGather(R.d_counts + (size_t)me * nb1, R.d_counts, (size_t)nb1, ncclUint32, R.comm, R.xs));
-		GHIP(hipMemcpyAsync(g->all_counts, R.d_counts, sizeof(uint32_t) * (size_t)N * nb1, hipMemcpyDeviceToHost, R.xs));
-		GHIP(hipStreamSynchronize(R.xs));
+		ncclResult_t ne = ncclSuccess;
+		hipError_t he = hipMemcpyAsync(R.d_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs, hipMemcpyHostToDevice, R.xs);
+		if (he == hipSuccess) ne = ncclAllGather(R.d_counts + (size_t)me * cs, R.d_counts, cs, ncclUint32, R.comm, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipMemcpyAsync(g->all_counts, R.d_counts, sizeof(uint32_t) * (size_t)N * cs, hipMemcpyDeviceToHost, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipStreamSynchronize(R.xs);
+		if (he != hipSuccess || ne != ncclSuccess) grp_err(g, "all-gather of the bucket sizes failed: %s", he != hipSuccess ? hipGetErrorString(he) : ncclGetErrorString(ne));
+		else for (int p = 0; p < N; ++p) if (p != me && g->all_counts[(size_t)p * cs + nb1]) grp_err(g, "rank %d of the run has failed: this batch is not exchanged", p);
 	}
 	pthread_barrier_wait(&g->bar); // all local ranks have published their sizes
-	if (i == 0) g->go = !g->failed; // one decision for all local ranks: a group that failed so far skips the exchange on every rank
+	if (i == 0) g->go = !g->failed; // one decision for all local ranks -- and, the failure words being all-gathered, for all processes
 	pthread_barrier_wait(&g->bar);
 	const uint32_t *C = g->all_counts;
 	// what I send to rank p: my buckets [p*nb_loc, (p+1)*nb_loc); what I get from rank p: its buckets [me*nb_loc, ...), stored source-major
 	std::vector<uint64_t> s_off((size_t)N + 1, 0), r_off((size_t)N + 1, 0);
 	for (int p = 0; p < N; ++p) {
 		uint64_t s = 0, q = 0;
-		for (int k = 0; k < nb_loc; ++k) { s += C[(size_t)me * nb1 + (size_t)p * nb_loc + k]; q += C[(size_t)p * nb1 + (size_t)me * nb_loc + k]; }
+		for (int k = 0; k < nb_loc; ++k) { s += C[(size_t)me * cs + (size_t)p * nb_loc + k]; q += C[(size_t)p * cs + (size_t)me * nb_loc + k]; }
 		s_off[p + 1] = s_off[p] + s; r_off[p + 1] = r_off[p] + q;
 	}
 	uint8_t *recv = R.recv[g->t & 1];
@@ -172,7 +181,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 	// every rank can compute every rank's receive size: an overflow anywhere stops the exchange everywhere
 	for (int p = 0; p < N && ok; ++p) {
 		uint64_t q = 0;
-		for (int s2 = 0; s2 < N; ++s2) for (int k = 0; k < nb_loc; ++k) q += C[(size_t)s2 * nb1 + (size_t)p * nb_loc + k];
+		for (int s2 = 0; s2 < N; ++s2) for (int k = 0; k < nb_loc; ++k) q += C[(size_t)s2 * cs + (size_t)p * nb_loc + k];
 		if (q * rb > R.recv_cap) { grp_err(g, "rank %d receives %llu records of one global batch, its buffer holds %llu: smaller shares or a larger filter", p, (unsigned long long)q, (unsigned long long)(R.recv_cap / rb)); ok = 0; }
 	}
 	// ---- records
@@ -199,7 +208,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 				const uint64_t n_to = (s_off[to + 1] - s_off[to]) * rb;
 				// my block in `to`'s buffer starts behind the blocks of the sources before me
 				uint64_t at = 0;
-				for (int p = 0; p < me; ++p) for (int k = 0; k < nb_loc; ++k) at += C[(size_t)p * nb1 + (size_t)to * nb_loc + k];
+				for (int p = 0; p < me; ++p) for (int k = 0; k < nb_loc; ++k) at += C[(size_t)p * cs + (size_t)to * nb_loc + k];
 				if (n_to) GHIP(hipMemcpyPeerAsync(T.recv[g->t & 1] + at * rb, T.device, send + s_off[to] * rb, R.device, n_to, R.xs));
 			}
 			GHIP(hipEventRecord(R.ev_x, R.xs));
@@ -209,12 +218,13 @@ static int rank_batch(bfcg_group_t *g, int i)
 	// ---- stage B behind the exchange
 	if (ok && !g->failed) {
 		std::vector<uint32_t> seg((size_t)N * nb_loc);
-		for (int s = 0; s < N; ++s) memcpy(&seg[(size_t)s * nb_loc], &C[(size_t)s * nb1 + (size_t)me * nb_loc], sizeof(uint32_t) * (size_t)nb_loc);
+		for (int s = 0; s < N; ++s) memcpy(&seg[(size_t)s * nb_loc], &C[(size_t)s * cs + (size_t)me * nb_loc], sizeof(uint32_t) * (size_t)nb_loc);
 		std::vector<hipEvent_t> ev;
 		if (g->xp == XP_RCCL) ev.push_back(R.ev_x);
 		else for (int j = 0; j < g->n_local; ++j) ev.push_back(g->r[j].ev_x);
 		if (process_in_groups(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
 	}
+	{ uint64_t calls = 0; bfcg_progress(R.ctx, &calls, 0, 0, 0); R.batch_call[g->t & 63] = calls; } // this global batch is complete on this rank once that call is
 	// The exchange is left running: the next batch's stage A (other send buffer) proceeds beside it.  What the next batch may not do before
 	// this one is through is ordered elsewhere: its exchange follows this one on the stream xs; a receive buffer is written again two batches
 	// on, behind this barrier of the batch in between, which every rank reaches only after its bfcg_mg_process_ev has waited for THIS
@@ -272,7 +282,7 @@ extern "C" void bfcg_group_destroy(bfcg_group_t *g)
 	for (auto &R : g->r) {
 		(void)hipSetDevice(R.device);
 		if (R.ctx) (void)bfcg_sync(R.ctx);
-		if (R.comm) (void)ncclCommDestroy(R.comm);
+		if (R.comm) { if (g->failed && g->mp) (void)ncclCommAbort(R.comm); else (void)ncclCommDestroy(R.comm); } // (peers of a failed run may never post what a clean destroy waits for)
 		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
 		if (R.ev_x) (void)hipEventDestroy(R.ev_x);
 		for (int b = 0; b < 2; ++b) if (R.ev_sent[b]) (void)hipEventDestroy(R.ev_sent[b]);
@@ -318,7 +328,7 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		g->nb1 = info[0]; g->nb_loc = info[1]; g->rec_bytes = info[2];
 		g->kmer_limit = (uint64_t)((double)bfcg_batch_limit(g->r[0].ctx) / 0.95);
 	}
-	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * g->nb1, hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
+	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * (g->nb1 + 1), hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
 	const uint64_t cap = prm->max_batch_pos, rcap = n_ranks > 1 ? cap + cap / 4 + (1u << 20) : cap; // = the contexts' level-2 capacity
 	std::vector<ncclComm_t> comms((size_t)n_local, (ncclComm_t)0);
 	if (g->xp == XP_RCCL && !g->mp && n_ranks > 1) {
@@ -336,11 +346,11 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		R.recv_cap = rcap * (uint64_t)g->rec_bytes;
 		if (e == hipSuccess) e = hipMalloc(&R.recv[0], R.recv_cap);
 		if (e == hipSuccess) e = hipMalloc(&R.recv[1], R.recv_cap);
-		if (e == hipSuccess) e = hipMalloc(&R.d_counts, sizeof(uint32_t) * (size_t)n_ranks * g->nb1);
+		if (e == hipSuccess) e = hipMalloc(&R.d_counts, sizeof(uint32_t) * (size_t)n_ranks * (g->nb1 + 1));
 		R.in_cap = cap;
 		if (e == hipSuccess) e = hipMalloc(&R.d_seq, cap);
 		if (e == hipSuccess) e = hipMalloc(&R.d_qual, cap);
-		R.counts = (uint32_t *)calloc((size_t)g->nb1, sizeof(uint32_t));
+		R.counts = (uint32_t *)calloc((size_t)g->nb1 + 1, sizeof(uint32_t));
 		if (e != hipSuccess) { bfcg_set_error(hipGetErrorString(e)); bfcg_group_destroy(g); return NULL; }
 		if (g->xp == XP_PEER) for (int j = 0; j < n_local; ++j) if (devices[j] != R.device) (void)hipDeviceEnablePeerAccess(devices[j], 0);
 		if (g->xp == XP_RCCL && (n_ranks > 1 || g->mp)) {
@@ -381,11 +391,62 @@ extern "C" int bfcg_group_reset(bfcg_group_t *g)
 	for (auto &R : g->r) if (bfcg_reset(R.ctx) != 0) return -1;
 	return 0;
 }
+// one rank per process: every process learns whether any of them has failed (one word per rank, all-gathered; the rank threads are idle)
+static int mp_agree(bfcg_group_t *g, int local_rc)
+{
+	if (!g->mp) return local_rc;
+	rank_t &R = g->r[0];
+	uint32_t w = (local_rc != 0 || g->failed) ? 1u : 0u;
+	std::vector<uint32_t> all((size_t)g->n_ranks, 0);
+	hipError_t he = hipSetDevice(R.device);
+	ncclResult_t ne = ncclSuccess;
+	// (d_counts is free between batches; in place: word `rank` is this rank's contribution)
+	if (he == hipSuccess) he = hipMemcpyAsync(R.d_counts + R.rank, &w, sizeof(w), hipMemcpyHostToDevice, R.xs);
+	if (he == hipSuccess) ne = ncclAllGather(R.d_counts + R.rank, R.d_counts, 1, ncclUint32, R.comm, R.xs);
+	if (he == hipSuccess && ne == ncclSuccess) he = hipMemcpyAsync(all.data(), R.d_counts, sizeof(uint32_t) * (size_t)g->n_ranks, hipMemcpyDeviceToHost, R.xs);
+	if (he == hipSuccess && ne == ncclSuccess) he = hipStreamSynchronize(R.xs);
+	if (he != hipSuccess || ne != ncclSuccess) { bfcg_set_error("all-gather of the ranks' status failed"); return -1; }
+	for (int p = 0; p < g->n_ranks; ++p) if (all[(size_t)p] && local_rc == 0 && !g->failed) { grp_err(g, "rank %d of the run has failed", p); bfcg_set_error(g->err); return -1; }
+	return local_rc != 0 || g->failed ? -1 : 0;
+}
 extern "C" int bfcg_group_sync(bfcg_group_t *g)
 {
-	if (drain_exchange(g) != 0) return -1;
-	for (auto &R : g->r) if (bfcg_sync(R.ctx) != 0) return -1;
-	return 0;
+	int rc = 0;
+	if (drain_exchange(g) != 0) rc = -1;
+	for (auto &R : g->r) if (rc == 0 && bfcg_sync(R.ctx) != 0) rc = -1;
+	return mp_agree(g, rc);
+}
+
+// Progress without draining (as bfcg_progress): batches = global batches submitted so far, final = the last one that is complete on every local
+// rank, keys_of[j], j < n: distinct keys (summed over the local ranks) after global batch final - j.  Returns how many entries of keys_of are
+// valid.  bfc_count prints the lines of count.c:110-114 from this.
+extern "C" int bfcg_group_progress(bfcg_group_t *g, uint64_t *batches, uint64_t *final, uint64_t *keys_of, int n)
+{
+	const int NL = g->n_local;
+	std::vector<uint64_t> fin((size_t)NL, 0), keys((size_t)NL * 63, 0);
+	for (int i = 0; i < NL; ++i) bfcg_progress(g->r[i].ctx, 0, &fin[(size_t)i], &keys[(size_t)i * 63], 63);
+	const uint64_t lo = g->t > 63 ? g->t - 63 : 0; // batch_call[] remembers the last 64 batches (a rank runs at most two batches ahead of its stage B)
+	uint64_t T = g->t;                               // batches are numbered from 1: batch T sits at index (T - 1) & 63
+	for (; T > lo; --T) {
+		bool all = true;
+		for (int i = 0; i < NL && all; ++i) all = g->r[i].batch_call[(T - 1) & 63] <= fin[(size_t)i];
+		if (all) break;
+	}
+	if (batches) *batches = g->t;
+	if (final) *final = T;
+	int j = 0;
+	for (; j < n && T - (uint64_t)j > lo; ++j) {
+		uint64_t sum = 0;
+		bool have = true;
+		for (int i = 0; i < NL && have; ++i) {
+			const uint64_t call = g->r[i].batch_call[(T - (uint64_t)j - 1) & 63], back = fin[(size_t)i] - call;
+			have = call >= 1 && back < 63 && back < fin[(size_t)i];
+			if (have) sum += keys[(size_t)i * 63 + back];
+		}
+		if (!have) break;
+		keys_of[j] = sum;
+	}
+	return j;
 }
 
 extern "C" int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos)

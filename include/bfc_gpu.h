@@ -165,6 +165,9 @@ int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, con
 int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos);
 int bfcg_group_sync(bfcg_group_t *g);
 int bfcg_group_stats(bfcg_group_t *g, uint64_t out[BFCG_ST_N]);   /* sums over the local ranks */
+/* progress without draining (as bfcg_progress, below): *batches = global batches submitted, *final = the last one complete on every local rank,
+ * keys_of[j], j < n: distinct keys (local ranks summed) after global batch *final - j; returns the number of valid entries */
+int bfcg_group_progress(bfcg_group_t *g, uint64_t *batches, uint64_t *final, uint64_t *keys_of, int n);
 bfc_ch_t *bfcg_group_export_table(bfcg_group_t *g);              /* all ranks local: THE table (union of the ranks' disjoint tables) */
 bfc_bf_t *bfcg_group_export_bloom(bfcg_group_t *g, int which);   /* all ranks local: THE filter (the ranks' slices in rank order) */
 /* the same, and every local device keeps a full copy of the filter in HBM (all-gathered from the slices by peer copies) for the sharded

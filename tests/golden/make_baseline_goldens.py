@@ -30,6 +30,9 @@ OUT = os.environ.get("BASELINE_OUT") or os.path.join(HERE, "baseline.json")
 
 # name: generator arguments, k, bf_shift (as `-s` / the default give), filter_mode
 CASES = {
+    # c1 (BASELINE.json configs[0]): the reference's own CPU-runnable plumbing case, `bfc -t1 -E -k31` with the default -b33; its entry also holds
+    # the md5 of the reference BINARY's `-d` dump of the FASTQ file bfcgen writes for it (count.c:127-157, htab.c:129-149)
+    "c1": dict(gen=dict(seed=1, G=4_600_000, cov=1.0), k=31, b=33, fm=0, binary_dump=True),
     "c2": dict(gen=dict(seed=2, G=4_600_000, cov=100.0), k=31, b=33, fm=0),
     "c3": dict(gen=dict(seed=3, G=248_000_000, cov=30.0), k=33, b=35, fm=0),     # `-s 250m -k33` => -b35
     # c5's parameters (`-s 3g -k51 -1`: -b37, two 16 GiB filters, 20-byte records, 10+10 scatter levels) on a read set a CPU finishes
@@ -65,6 +68,19 @@ def run(name):
             kk, l_pre, sizes, slots = oracle.parse_dump(tf.name)
         e.update(l_pre=l_pre, l1_digest=oracle.l1_digest(sizes, slots))
     c.close()
+    if cs.get("binary_dump"):  # the unmodified reference binary on the file itself: `bfc-ref -t1 -E -k K -b B -d dump reads.fq`
+        import subprocess
+        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        fq, dump = os.path.join(d, name + ".fq"), os.path.join(d, name + ".hash")
+        rs.fastq(fq)
+        r = subprocess.run([os.path.join(oracle.REF_DIR, "bfc-ref"), "-t", "1", "-E", "-k", str(cs["k"]), "-b", str(cs["b"]), "-d", dump, fq], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        e.update(fastq_md5=oracle.md5_file(fq), ref_dump_md5=oracle.md5_file(dump), ref_cmd="bfc-ref -t 1 -E -k %d -b %d -d dump %s.fq" % (cs["k"], cs["b"], name))
+        k2, l2, sz2, sl2 = oracle.parse_dump(dump)
+        assert oracle.l1_digest(sz2, sl2) == e["l1_digest"], "harness and binary disagree"  # harness == binary
+        for f in (fq, dump):
+            os.unlink(f)
+        os.rmdir(d)
     e["ref_seconds"] = round(time.time() - t0, 1)
     print(e, file=sys.stderr, flush=True)
     return e

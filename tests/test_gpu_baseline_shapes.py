@@ -224,3 +224,60 @@ def test_c3_shape_has_no_batch_size_cliff(gpu_lib):
     for call, r in res.items():
         assert r[5] <= max(n // call, 3) + 1, (call, r[5])
     assert t[1_048_576] <= 5 * t[8_388_608], t   # (a sanity bound only: stage times between events include whatever the host delays)
+
+
+def test_c1_read_set_device_api(gpu_lib):
+    """Config c1 (BASELINE.json configs[0]: 1x coverage, k=31, the default -b33) through the device API: equals the reference's answers."""
+    e = BASE["c1"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], rs.n_reads)
+    _check_against(g, e)
+    g.close()
+
+
+@pytest.mark.parametrize("fm", [0, 1])
+def test_clean_batch_followed_by_an_overflowing_one(gpu_lib, monkeypatch, fm):
+    """Stage A of batch t+1 runs beside stage B of batch t (two streams).  A level-1 slab overflow in t+1 must not touch the clean batch t: the
+    overflow flags are per batch slot, and only stage B's own stream makes the poison sticky (round 2 kept ONE flag word: k_bloom / k_commit_seg of
+    batch t saw the flag raised by t+1's stage A, returned early, and the replay then applied t twice).  Behind the poisoned batch comes a batch too
+    small for the one-pass partition: it is enqueued before the host knows about the overflow and must wait for the replay all the same.
+    Device-resident inputs, no host synchronisation between the calls."""
+    monkeypatch.setenv("BFCG_PIPELINE", "1")
+    rng = np.random.default_rng(4242 + fm)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, k, b = 150, 31, 30
+    n1, n2, n3 = 500_000, 150_000, 1_500
+    genome = rng.choice(acgt, 40_000_000 + L)
+    small = rng.choice(acgt, 400 + L)
+    p1 = rng.integers(0, 40_000_000, n1); p2 = rng.integers(0, 400, n2); p3 = rng.integers(0, 40_000_000, n3)
+    seq = np.concatenate([genome[p1[:, None] + np.arange(L)[None, :]], small[p2[:, None] + np.arange(L)[None, :]], genome[p3[:, None] + np.arange(L)[None, :]]]).astype(np.uint8).reshape(-1)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    n = n1 + n2 + n3
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = oracle.Counter(k, b, filter_mode=fm)
+    oc.count(seq, qual, off)
+    stride = L + 1
+    g = gpu_lib.GpuCounter(k, b, filter_mode=fm, max_batch_pos=n1 * stride + 64)
+    s, q = gen.to_stream(seq, L, 10), gen.to_stream(qual, L, 33)
+    d_s, d_q = g.dev_alloc(len(s)), g.dev_alloc(len(q))
+    g.h2d(d_s, s); g.h2d(d_q, q)
+    for rep in range(2):  # (the second data set starts with the one-pass partition again)
+        assert g.partition_info()["one_pass"]
+        o = 0
+        for cnt in (n1, n2, n3):
+            g.count_dev(d_s + o * stride, d_q + o * stride, cnt * stride)
+            o += cnt
+        st, ost = g.stats(), oc.stats()
+        pi = g.partition_info()
+        assert pi["replayed_batches"] >= 2 * (rep + 1) and not pi["one_pass"], pi  # the overflowing batch and the small one behind it; not the clean first one
+        assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+        assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+        if fm:
+            assert np.array_equal(g.bloom_bytes(1), oc.bloom_bytes(True))
+        else:
+            sizes, slots = g.export_table().export_sorted()
+            osz, osl = oc.export()
+            assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+        g.reset()
+    g.dev_free(d_s); g.dev_free(d_q)
+    g.close(); oc.close()

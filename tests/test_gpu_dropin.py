@@ -453,3 +453,88 @@ def test_dropin_on_several_gpus(g1_fq, tmp_path, devices):
         r = subprocess.run([GPUTRIM, "-1", "-k", "51", "-b", "26", "-t", "2"] + extra + [g1_fq], capture_output=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr.decode()[-1500:]
         assert hashlib.md5(r.stdout).hexdigest() == "f751f7b1aa28fd74b23194bc7f70158c"                     # `bfc -1`
+
+
+@needs_dropin
+@pytest.mark.usefixtures("ref_bin")
+def test_config_c1_dump_equals_reference_binary(tmp_path):
+    """BASELINE.json configs[0] end to end: bfcgen's c1 FASTQ (E. coli-sized genome at 1x: 30 666 reads) through the reference's unmodified
+    main() on this library, `-E -k31 -d` with the default 1 GiB filter -- the dump is byte-identical to `bfc-ref -t1 -E -k31 -d` run here AND to
+    the md5 the build container recorded from the reference (tests/golden/baseline.json[c1]; count.c:127-157, htab.c:129-149)."""
+    import json
+    e = {x["name"]: x for x in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baseline.json")))}["c1"]
+    fq = str(tmp_path / "c1.fq")
+    gen.ReadSet(**e["gen"]).fastq(fq)
+    assert oracle.md5_file(fq) == e["fastq_md5"]
+    ref_dump, gpu_dump = str(tmp_path / "ref.hash"), str(tmp_path / "gpu.hash")
+    r = subprocess.run([REFBIN, "-t", "1", "-E", "-k", "31", "-d", ref_dump, fq], capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    assert oracle.md5_file(ref_dump) == e["ref_dump_md5"]
+    for t in ("1", "8"):
+        g = subprocess.run([DROPIN, "-t", t, "-E", "-k", "31", "-d", gpu_dump, fq], capture_output=True, timeout=900, env=dict(os.environ, BFC_GPU_EXACT_DUMP="1"))
+        assert g.returncode == 0, g.stderr.decode()[-800:]
+        assert oracle.md5_file(gpu_dump) == e["ref_dump_md5"], t
+        assert b"# distinct k-mers: %d" % e["distinct"] in g.stderr
+    # and without order stamps: the same table (L1), laid out by this library
+    g = subprocess.run([DROPIN, "-t", "8", "-E", "-k", "31", "-d", gpu_dump, fq], capture_output=True, timeout=900)
+    assert g.returncode == 0
+    k, l_pre, sizes, slots = oracle.parse_dump(gpu_dump)
+    assert (k, l_pre) == (31, 20) and oracle.l1_digest(sizes, slots) == e["l1_digest"]
+
+
+@needs_dropin
+@pytest.mark.usefixtures("ref_bin")
+@pytest.mark.parametrize("devices", ["", "0,0", "0,0,0,0"])
+def test_mixed_fasta_fastq_at_q94(tmp_path, devices):
+    """A file that mixes FASTQ and FASTA records, counted with -q 94: no FASTQ base is high quality any more (33 + 94 = 127 > '~'), every base of
+    a FASTA record still is (qual == NULL, count.c:85).  On one GPU and on several (ranks emulated on the one device) a mixed batch is submitted as
+    its homogeneous runs, so the dump equals the reference binary's byte for byte."""
+    from test_ingest import _fastq
+    rng = np.random.default_rng(94)
+    fa = b"".join(b">fa%d\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 120))) for i in range(400))
+    data = _fastq(rng, 1500, 60, 160) + fa + _fastq(rng, 800, 60, 160) + fa[: len(fa) // 2] + _fastq(rng, 700, 60, 160)
+    fn = str(tmp_path / "mixed.fq")
+    open(fn, "wb").write(data)
+    env = dict(os.environ, BFC_GPU_EXACT_DUMP="1")
+    if devices:
+        env["BFC_GPU_DEVICES"] = devices
+    for chunk in ("100000000", "60000"):
+        ref_dump, gpu_dump = str(tmp_path / "ref.hash"), str(tmp_path / "gpu.hash")
+        r = subprocess.run([REFBIN, "-E", "-k", "21", "-b", "26", "-q", "94", "-t", "1", "-L", chunk, "-d", ref_dump, fn], capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        g = subprocess.run([DROPIN, "-E", "-k", "21", "-b", "26", "-q", "94", "-t", "4", "-L", chunk, "-d", gpu_dump, fn], capture_output=True, timeout=600, env=env)
+        assert g.returncode == 0, g.stderr.decode()[-800:]
+        assert open(gpu_dump, "rb").read() == open(ref_dump, "rb").read(), (devices, chunk)
+        import re
+        pk = lambda txt: re.findall(r"processed (\d+) sequences; # distinct k-mers: (\d+)", txt)  # noqa: E731
+        assert pk(g.stderr.decode()) == pk(r.stderr.decode()), (devices, chunk)  # exact per chunk, printed without draining (bfcg_progress / bfcg_group_progress)
+        k, l_pre, sizes, slots = oracle.parse_dump(ref_dump)
+        high = (slots >> np.uint64(8)) & np.uint64(0x3f)
+        assert 0 < int((high > 0).sum()) < len(slots)  # only the FASTA records' k-mers have high-quality occurrences
+
+
+@pytest.mark.usefixtures("gputrim_bin", "ref_bin")
+def test_trim_pass_on_several_gpus_with_reads_sorted_by_length(tmp_path):
+    """`bfc -1` on two devices, reads sorted by length (2 000 down to 60 bases): the trim pass deals a batch to the devices by POSITIONS (cut at
+    the nearest read boundary) -- dealt by read count, the first device's share would exceed the context it was sized for -- and prints the
+    reference's bytes (correct.c:478-497,557-569,595-611)."""
+    rng = np.random.default_rng(7)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = rng.choice(acgt, 60_000)
+    lens = np.linspace(2000, 60, 1100).astype(int)
+    recs = []
+    for i, l in enumerate(lens):
+        p = int(rng.integers(0, len(genome) - l))
+        s = genome[p:p + l].copy()
+        e = rng.random(l) < 0.01
+        s[e] = acgt[rng.integers(0, 4, int(e.sum()))]
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, s.tobytes(), rng.integers(40, 74, l).astype(np.uint8).tobytes()))
+    fn = str(tmp_path / "sorted.fq")
+    open(fn, "wb").write(b"".join(recs))
+    r = subprocess.run([REFBIN, "-1", "-k", "21", "-b", "24", "-t", "1", fn], capture_output=True, timeout=600)
+    assert r.returncode == 0 and len(r.stdout) > 100_000, r.stderr.decode()[-500:]
+    for devices in ("0", "0,0", "0,0,0,0"):
+        g = subprocess.run([GPUTRIM, "-1", "-k", "21", "-b", "24", "-t", "2", fn], capture_output=True, timeout=600,
+                           env=dict(os.environ, BFC_GPU_DEVICES=devices, BFC_GPU_BATCH="200000"))
+        assert g.returncode == 0, (devices, g.stderr.decode()[-800:])
+        assert g.stdout == r.stdout, devices

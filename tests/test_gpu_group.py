@@ -216,3 +216,29 @@ def test_group_c2_full_read_set(gpu_lib, n_ranks):
     t.close()
     assert all(grp.ctx(i).partition_info()["level2_one_pass"] for i in range(n_ranks))
     grp.close()
+
+
+def test_group_c4_geometry_on_4_ranks(gpu_lib):
+    """c4's parameters (`-s 3g`: k=33, -b37 -- a 16 GiB filter, 2^20 bloom regions, 10 + 10 scatter levels, 12-byte records) on 4 emulated ranks,
+    each owning 4 GiB of the filter and a quarter of the table segments: the 20 Mbp x 30 read set (4 M reads, 472 M k-mers) in 3 global batches
+    must give what THE REFERENCE computed for it with these parameters (tests/golden/baseline.json[c4s])."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = {x["name"]: x for x in json.load(open(os.path.join(here, "golden", "baseline.json")))}["c4s"]
+    rs = gen.ReadSet(**e["gen"])
+    n_ranks, per = 4, 1_400_000
+    grp = gpu_lib.GpuGroup(e["k"], e["b"], [0] * n_ranks, max_batch_pos=per * (rs.L + 1) // n_ranks + 65536)
+    for r0 in range(0, rs.n_reads, per):
+        seq, qual, _ = rs.reads(r0, min(rs.n_reads, r0 + per))
+        grp.count_host(gen.to_stream(seq, rs.L, 10), gen.to_stream(qual, rs.L, 33))
+    st = grp.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"], st["n_keys"]) == (e["n_kmers"], e["n_high"], e["n_seen"], e["distinct"]), st
+    bf = grp.export_bloom(0)
+    assert gen.bitmap_checksums(bf.bytes()) == (e["bf_popcount"], int(e["bf_fnv1a64"], 16))
+    bf.close()
+    t = grp.export_table()
+    mode, cnt, high = t.hist()
+    assert int(mode) == e["hist_mode"] and np.array_equal(cnt, np.array(e["cnt"], dtype=np.uint64)) and np.array_equal(high, np.array(e["high"], dtype=np.uint64))
+    assert oracle.l1_digest(*t.export_sorted()) == e["l1_digest"]
+    t.close()
+    grp.close()

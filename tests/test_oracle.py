@@ -223,3 +223,31 @@ def test_quality_threshold_on_every_byte_value(q):
     if -40 <= q <= 0:
         assert 0 < o.stats()["n_high"] < o.stats()["n_kmers"]
     o.close(); r.close()
+
+
+def test_config_c1_oracle_equals_reference_golden(tmp_path):
+    """BASELINE.json configs[0] (E. coli-sized genome at 1x, k=31, the default -b33: the reference's own CPU-runnable plumbing case): the C
+    restatement over the c1 read set equals what the reference's functions gave for it (tests/golden/baseline.json[c1], generated by
+    make_baseline_goldens.py from count.c:127-157 at -t1) -- totals, filter checksums, both histograms, L1 digest -- and its byte-exact dump has
+    the md5 of the reference BINARY's `bfc -t1 -E -d` on bfcgen's FASTQ of the same reads (htab.c:129-149)."""
+    base = {e["name"]: e for e in json.load(open(os.path.join(HERE, "golden", "baseline.json")))}
+    e = base["c1"]
+    rs = gen.ReadSet(**e["gen"])
+    assert rs.n_reads == e["n_reads"]
+    fq = str(tmp_path / "c1.fq")
+    rs.fastq(fq)
+    assert oracle.md5_file(fq) == e["fastq_md5"]
+    seq, qual, off = rs.reads()
+    c = oracle.Counter(e["k"], e["b"])
+    c.count(seq, qual, off)
+    st = c.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (e["n_kmers"], e["n_high"], e["n_seen"])
+    pop, fnv = c.bloom_checksums()
+    assert (pop, "%016x" % fnv) == (e["bf_popcount"], e["bf_fnv1a64"])
+    mode, cnt, high = c.table_hist()
+    assert c.table_count() == e["distinct"] and int(mode) == e["hist_mode"]
+    assert [int(v) for v in cnt] == e["cnt"] and [int(v) for v in high] == e["high"]
+    dump = str(tmp_path / "c1.hash")
+    c.dump(dump)
+    assert oracle.md5_file(dump) == e["ref_dump_md5"]
+    c.close()
