@@ -269,7 +269,8 @@ def test_clean_batch_followed_by_an_overflowing_one(gpu_lib, monkeypatch, fm):
             o += cnt
         st, ost = g.stats(), oc.stats()
         pi = g.partition_info()
-        assert pi["replayed_batches"] >= 2 * (rep + 1) and not pi["one_pass"], pi  # the overflowing batch and the small one behind it; not the clean first one
+        # the overflowing batch -- and, where nothing drains the pipeline in between (no table to grow in filter mode), the small batch enqueued behind it
+        assert pi["replayed_batches"] >= (2 if fm else 1) * (rep + 1) and not pi["one_pass"], pi
         assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
         assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
         if fm:
