@@ -214,8 +214,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	HIPCKN(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
 	{
-		const uint64_t tile = (uint64_t)bfcg_tile_of_rw(c->rw / 4);
-		const uint64_t tiles1 = (prm->max_batch_pos + tile - 1) / tile, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
+		const uint64_t tile = (uint64_t)bfcg_tile_of_rw(c->rw / 4), tile1 = (uint64_t)bfcg_tile1_of_rw(c->rw / 4);
+		const uint64_t tiles1 = (prm->max_batch_pos + tile1 - 1) / tile1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
 		const uint64_t rows2 = c->recv_cap / tile + (uint64_t)nb1 * 8 + 1; // one ragged row per segment at most (one-pass level 1: 8 segments per bucket)
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->rows1[b], sizeof(uint32_t) * tiles1 * nb1));
@@ -245,7 +245,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	if (c->onepass_ok) {
 		for (int b = 0; b < 2; ++b) {
-			HIPCKN(hipMalloc(&c->op_cursor[b], sizeof(uint32_t) * 8 * nb1 * 32));
+			HIPCKN(hipMalloc(&c->op_cursor[b], sizeof(uint32_t) * (8 * nb1 * 32 + 32))); // (+ the tile counter of k_scatter1)
 			HIPCKN(hipMalloc(&c->op_seg[b], sizeof(uint32_t) * ((size_t)25 * nb1 + 8)));
 		}
 	}
@@ -304,7 +304,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
 		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
 	}
-	for (int b = 0; b < 2; ++b) { HIPCKN(hipMalloc(&c->d_seq2[b], prm->max_batch_pos)); HIPCKN(hipMalloc(&c->d_qual2[b], prm->max_batch_pos)); }
+	for (int b = 0; b < 2; ++b) { HIPCKN(hipMalloc(&c->d_seq2[b], prm->max_batch_pos)); HIPCKN(hipMalloc(&c->d_qual2[b], prm->max_batch_pos + 64)); }
 	c->d_seq = c->d_seq2[0]; c->d_qual = c->d_qual2[0];
 	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 2)));
 	for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_snap[b], sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1)));
@@ -336,6 +336,7 @@ static int drain(bfcg_ctx_t *c);
 static int replay_poisoned(bfcg_ctx_t *c);
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats);
+static int same_block_offset(bfcg_ctx_t *c, int b, const uint8_t *d_seq, const uint8_t **d_qual, uint64_t n_pos, hipStream_t s);
 
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
@@ -714,6 +715,7 @@ extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_
 	}
 	BatchBufs Bt = c->B;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1;
+	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, c->stA) != 0) return -1;
 	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
 	HIPCK(hipGetLastError());
 	uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (nb1 + 1));
@@ -822,6 +824,18 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 	return 0;
 }
 
+// k_scatter1 reads both streams as aligned 16-byte blocks and wants them at the SAME offset inside a block (any offset: sub-batches start
+// where a read ends).  Streams that differ there -- pointers a caller cut differently -- get their qualities copied to the slot's staging
+// buffer at the sequence's offset.
+static int same_block_offset(bfcg_ctx_t *c, int b, const uint8_t *d_seq, const uint8_t **d_qual, uint64_t n_pos, hipStream_t s)
+{
+	if (!*d_qual || ((((uintptr_t)d_seq) ^ ((uintptr_t)*d_qual)) & 15) == 0) return 0;
+	uint8_t *dst = c->d_qual2[b] + (((uintptr_t)d_seq) & 15);
+	HIPCK(hipMemcpyAsync(dst, *d_qual, n_pos, hipMemcpyDeviceToDevice, s));
+	*d_qual = dst;
+	return 0;
+}
+
 // One batch, software-pipelined over two streams: stage A of this batch (ALU-bound K1) is enqueued on stA and runs
 // under stage B of the previous batch (LDS/latency-bound) on st.  The call returns once the PREVIOUS batch is
 // finalised (statistics read, table maintained); bfcg_sync / bfcg_stats / exports drain the pipeline.
@@ -838,6 +852,8 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	Bt.stream = c->stream_mode; Bt.stream_out = c->stream_out;
 	KParams Pt = c->P;
 	Pt.no_kstats = no_kstats;
+	const uint8_t *const d_qual_given = d_qual; // (what a replay starts from again)
+	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, sA) != 0) return -1;
 	const int op_run = c->onepass && !no_kstats;  // the run still uses the one-pass partition: an earlier batch may turn out to have overflowed a slab
 	const int op = op_run && n_pos >= c->op_min_pos; // (a handful of tiles cannot fill 8 slabs per bucket evenly: such a batch takes two passes)
 	// every batch of such a run -- one-pass or not -- tests the sticky word in its stage B and waits in the queue until it is known to be clean:
@@ -860,7 +876,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	if (op_run) {
 		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st)); // behind k_seal: is the run poisoned up to and including this batch?
 		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
-		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; c->opq[c->n_opq].recv = nullptr; c->opq[c->n_opq].mg = 0; ++c->n_opq;
+		c->opq[c->n_opq].seq = d_seq; c->opq[c->n_opq].qual = d_qual_given; c->opq[c->n_opq].n_pos = n_pos; c->opq[c->n_opq].slot = b; c->opq[c->n_opq].recv = nullptr; c->opq[c->n_opq].mg = 0; ++c->n_opq;
 	}
 	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
 	c->slot_call[b] = c->call_no; c->slot_pos[b] = n_pos;

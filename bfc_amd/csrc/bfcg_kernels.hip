@@ -19,6 +19,8 @@
 // reference's sequential semantics (bbf.c:27-31: one 64-byte block per k-mer) meets inside one workgroup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
 #include "kmer_dev.h"
 #include "bfcg_internal.h"
 
@@ -62,6 +64,41 @@ __device__ __forceinline__ void quals16(uint32_t w, int sh, int q, uint32_t &mq)
 	for (int b = 0; b < 4; ++b) mq |= (uint32_t)((int)(int8_t)((w >> (8 * b)) & 0xffu) - 33 >= q) << (sh + b);
 }
 
+// The same for four bases at a time, bytes side by side in one register (no extraction, no compares): after folding case (& 0xDF) a byte
+// is A C G T iff bit 7 = 0, bit 6 = 1, bit 3 = 0 and (bit 4, bits 2..0) is one of (0,001) (0,011) (0,111) (1,100); the code's low bit is
+// bit 1 ^ bit 2, its high bit is bit 2.  Every quantity is computed in bit 0 of each byte; a multiplication gathers the four bits into a nibble.
+__device__ __forceinline__ uint32_t gather4(uint32_t m) { return (m * 0x01020408u) >> 24; } // m has bits 0, 8, 16, 24 only -> bits 0..3
+__device__ __forceinline__ void bases4x(uint32_t w, int sh, uint32_t &m0, uint32_t &m1, uint32_t &mn)
+{
+	const uint32_t u = w & 0xDFDFDFDFu, s1 = u >> 1, s2 = u >> 2, s3 = u >> 3, s4 = u >> 4, s6 = u >> 6, s7 = u >> 7, one = 0x01010101u;
+	const uint32_t t1 = u & (s1 | ~s2);          // bits 2..0 in {001, 011, 111}
+	const uint32_t t2 = s2 & ~s1 & ~u;           // bits 2..0 = 100
+	const uint32_t ok = (s4 & t2) | (~s4 & t1);
+	const uint32_t bad = (s7 | ~s6 | s3 | ~ok) & one;
+	m0 |= gather4((s1 ^ s2) & one) << sh; m1 |= gather4(s2 & one) << sh; mn |= gather4(bad) << sh;
+}
+// count.c:85 on four signed chars at once, for a threshold T = q + 33 in 1..127 (bytes above 0x7f are negative: never high quality):
+// (b & 0x7f) + (128 - T) carries into bit 7 iff (b & 0x7f) >= T
+__device__ __forceinline__ void quals4x(uint32_t w, int sh, uint32_t add, uint32_t &mq)
+{ mq |= gather4(((((w & 0x7F7F7F7Fu) + add) & ~w) >> 7) & 0x01010101u) << sh; }
+
+// 16 positions from `pos` on at the ragged ends of a batch (positions outside it read as separators), byte by byte
+// (a real call, results by value: met by two tiles of a batch, and inlined its 16 byte loads would cost every tile's path registers)
+__device__ __noinline__ uint4 ragged16(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos, int64_t pos, int q)
+{
+	uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
+#pragma unroll 1
+	for (int b = 0; b < 16; ++b) {
+		const int64_t pb = pos + b;
+		const bool in = pb >= 0 && pb < n_pos;
+		uint32_t w = in ? seq[pb] : (uint32_t)'\n', t0m = 0, t1m = 0, tnm = 0;
+		bases16(w | 0x0a0a0a00u, 0, t0m, t1m, tnm);
+		m0 |= (t0m & 1u) << b; m1 |= (t1m & 1u) << b; mn |= (tnm & 1u) << b;
+		mq |= (uint32_t)(qual ? (in && ((int)(int8_t)qual[pb] - 33 >= q)) : 1) << b;
+	}
+	return make_uint4(m0, m1, mn, mq);
+}
+
 template <int TILE, int BT>
 __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                              int64_t n_pos, int64_t t0, int q, uint32_t *planes)
@@ -76,21 +113,16 @@ __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, co
 			uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
 			if (pos >= 0 && pos + 16 <= n_pos) {
 				uint4 s = *reinterpret_cast<const uint4 *>(seq + pos);
-				bases16(s.x, 0, m0, m1, mn); bases16(s.y, 4, m0, m1, mn); bases16(s.z, 8, m0, m1, mn); bases16(s.w, 12, m0, m1, mn);
+				bases4x(s.x, 0, m0, m1, mn); bases4x(s.y, 4, m0, m1, mn); bases4x(s.z, 8, m0, m1, mn); bases4x(s.w, 12, m0, m1, mn);
 				if (qual) {
 					uint4 v = *reinterpret_cast<const uint4 *>(qual + pos);
-					quals16(v.x, 0, q, mq); quals16(v.y, 4, q, mq); quals16(v.z, 8, q, mq); quals16(v.w, 12, q, mq);
+					const int T = q + 33;
+					if (T >= 1 && T <= 127) {
+						const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
+						quals4x(v.x, 0, add, mq); quals4x(v.y, 4, add, mq); quals4x(v.z, 8, add, mq); quals4x(v.w, 12, add, mq);
+					} else { quals16(v.x, 0, q, mq); quals16(v.y, 4, q, mq); quals16(v.z, 8, q, mq); quals16(v.w, 12, q, mq); }
 				} else mq = 0xffffu;
-			} else { // ragged ends of the batch
-				for (int b = 0; b < 16; ++b) {
-					const int64_t pb = pos + b;
-					const bool in = pb >= 0 && pb < n_pos;
-					uint32_t w = in ? seq[pb] : (uint32_t)'\n', t0m = 0, t1m = 0, tnm = 0;
-					bases16(w | 0x0a0a0a00u, 0, t0m, t1m, tnm);
-					m0 |= (t0m & 1u) << b; m1 |= (t1m & 1u) << b; mn |= (tnm & 1u) << b;
-					mq |= (uint32_t)(qual ? (in && ((int)(int8_t)qual[pb] - 33 >= q)) : 1) << b;
-				}
-			}
+			} else { const uint4 r = ragged16(seq, qual, n_pos, pos, q); m0 = r.x; m1 = r.y; mn = r.z; mq = r.w; } // ragged ends of the batch
 			p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
 			p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
 		}
@@ -116,10 +148,38 @@ __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, co
 	if (threadIdx.x < 8) planes[(threadIdx.x >> 1) * PW + PW - 2 + (threadIdx.x & 1)] = 0;
 }
 
+// k-mer ending at tile-relative position r (0 <= r < TILE), 32 < k < 64, on 32-bit halves (kmer_dev.h); KC > 0: k at compile time.
+// Returns false if there is none.
+template <int TILE, int KC>
+__device__ __forceinline__ bool kmer_at2(const uint32_t *planes, int r, int k_, U2 &y0, U2 &y1, bool &is_high)
+{
+	constexpr int PW = (TILE + 64) / 32 + 2;
+	const int k = KC ? KC : k_, bit = r + 65 - k, wi = bit >> 5, s = bit & 31;
+	const uint32_t mh = (1u << (k - 32)) - 1u;
+	const uint32_t *p = planes + wi;
+	{
+		const uint32_t a = p[2 * PW], b = p[2 * PW + 1], c = p[2 * PW + 2];
+		if ((__builtin_amdgcn_alignbit(b, a, s) | (__builtin_amdgcn_alignbit(c, b, s) & mh)) != 0) return false; // a base that is not ACGT in the window (count.c:83,86-87)
+	}
+	const uint32_t l0 = p[0], l1 = p[1], l2 = p[2], h0 = p[PW], h1 = p[PW + 1], h2 = p[PW + 2], q0 = p[3 * PW], q1 = p[3 * PW + 1], q2 = p[3 * PW + 2];
+	is_high = (__builtin_amdgcn_alignbit(q1, q0, s) & (__builtin_amdgcn_alignbit(q2, q1, s) | ~mh)) == 0xffffffffu; // count.c:85-86
+	kmer_hash_from_windows2<KC>(k, __builtin_amdgcn_alignbit(l1, l0, s), __builtin_amdgcn_alignbit(l2, l1, s),
+	                            __builtin_amdgcn_alignbit(h1, h0, s), __builtin_amdgcn_alignbit(h2, h1, s), y0, y1);
+	return true;
+}
+
 // k-mer ending at tile-relative position r (0 <= r < TILE).  Returns false if there is none.
 template <typename W, int TILE>
 __device__ __forceinline__ bool kmer_at(const uint32_t *planes, int r, int k, W m, W &y0, W &y1, bool &is_high)
 {
+	if constexpr (sizeof(W) == 8) {
+		if (k > 32) { // (W = 64 bits serves k > 32 only; the generic code below remains for completeness)
+			U2 a, b;
+			if (!kmer_at2<TILE, 0>(planes, r, k, a, b, is_high)) return false;
+			y0 = u2_join(a); y1 = u2_join(b);
+			return true;
+		}
+	}
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	int bit = r + 65 - k;
 	if (window<W>(planes + 2 * PW, bit, m) != 0) return false;
@@ -243,9 +303,8 @@ __global__ __launch_bounds__(BT) void k_hist1(KParams P, const uint8_t *__restri
 		for (int i = threadIdx.x; i < nb1; i += BT) hist[i] = 0;
 		build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
 		__syncthreads();
-#pragma unroll 4
-		for (int j = 0; j < TILE / BT; ++j) {
-			int r = j * BT + threadIdx.x;
+#pragma unroll 2
+		for (int r = threadIdx.x; r < TILE; r += BT) {
 			W y0, y1; bool hi;
 			if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
 				uint32_t f = fine_id<W>(P, y0, y1);
@@ -352,46 +411,237 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t *cnt, int nb, uint3
 // two-pass partition (bfcg_ctx.hip: replay_poisoned).  The flags are per slot because stage A of batch t+1 runs beside stage B of batch t:
 // an overflow of t+1 must not be seen by the kernels of the clean batch t.
 struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; };
-template <typename W, int RW, int TILE, int BT, bool ONEPASS = false>
-__global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+
+// A 12-byte record from halves without 64-bit shifts (same bits as Rec<3>::pack): possible when the kept part of y0 fits one word
+// (0 < a = k - rec_n < 32), the dropped field ends below bit 32, and y1 reaches into the second word (a + k >= 32)
+struct Pack3 { int ok, a, lo, n, sh_flag; uint32_t lowmask; };
+__device__ __forceinline__ Pack3 pack3_geom(const KParams &P)
+{
+	Pack3 g; g.a = P.k - P.rec_n; g.lo = P.rec_lo; g.n = P.rec_n; g.sh_flag = g.a + P.k - 32; g.lowmask = P.rec_n ? (1u << (P.rec_lo & 31)) - 1u : 0xffffffffu;
+	g.ok = g.a >= 1 && g.a <= 31 && g.a + P.k >= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n <= 31);
+	return g;
+}
+__device__ __forceinline__ void pack3_fast(RecW<3> &r, const Pack3 g, const U2 y0, const U2 y1, uint32_t idx, bool hi)
+{
+	const uint32_t y0d = g.n ? (y0.lo & g.lowmask) | (__builtin_amdgcn_alignbit(y0.hi, y0.lo, g.lo + g.n) << g.lo) : y0.lo;
+	r.d[0] = y0d | (y1.lo << g.a);
+	r.d[1] = __builtin_amdgcn_alignbit(y1.hi, y1.lo, 32 - g.a) | ((uint32_t)hi << g.sh_flag);
+	r.d[2] = idx;
+}
+
+// KC > 0: k is known at compile time (instantiated for the reference's default k = 33: bfc.c:17, and what `-s 3g` sets).
+// FAST: the caller has checked that the bucket is a bit field of y0's low word (k >= bf_shift - 9) and that 12-byte records can be packed
+// from halves (scatter1_fast): the generic 64-bit code is not even compiled in.
+//
+// A workgroup walks its tiles (the grid is as many workgroups as the chip holds at once, dealt to the XCDs like the tiles: xcd_tile) and is
+// software-pipelined against the latencies a tile meets (a workgroup that lives for one tile spends a quarter of its life waiting for its
+// bases): the NEXT tile's bases and qualities are requested a round ahead, and the returning atomics that reserve the runs' places in the
+// slabs are waited for only after the records are staged.  Loads, atomics and stores share one in-order counter (vmcnt) on this chip, so the
+// order inside a round matters: whatever is waited for was issued BEFORE the previous round's stores or long after them.
+// What the kernel costs on config c3 (scripts/s1_ablate.py, per step): ~26 ms the skeleton (planes, LDS ranks, scan, staging, five
+// barriers), + ~12 ms hashing, + ~7 ms the cursors' atomics, + ~11 ms the stores (runs of ~6 records: partial lines).
+template <typename W, int RW, int TILE, int BT, bool ONEPASS = false, int KC = 0, bool FAST = false>
+__global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                                  int64_t n_pos, const uint32_t *__restrict__ rows1, uint32_t *__restrict__ out, OnePass OP)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	constexpr int S = TILE / BT;
+	static_assert(S * BT == TILE, "TILE = threads x k-mers per thread");
+	constexpr int NC16 = (TILE + 64) / 16, NCH = NC16 + 1; // 16-byte blocks of a tile's planes (one more when the streams start inside a block)
+	static_assert(NCH <= BT, "one 16-byte block per thread");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
 	uint32_t *stage = reinterpret_cast<uint32_t *>(smem1);                                   // TILE * RW dwords
-	// bucket of each staged record: kept (2 bytes per record) where the record itself no longer says it (RecGeom: the bucket's bits of y0 are
-	// not stored); otherwise it is recomputed from the staged record -- the 8 KiB would cost 20-byte records their second resident workgroup
-	const bool KEEP_BK = P.rec_n > 0 && RW != 5;
+	// The bucket of a staged record.  Where the file index is a dword of its own (12- and 20-byte records) the stage holds  bucket << 13 | r
+	// in its place -- r = the position inside the tile; the copy-out puts the index back -- ; 16-byte records keep the bucket in 2 more bytes
+	// where their y0 no longer says it (RecGeom), else it is recomputed.
+	constexpr bool IDX_BK = RW != 4;
+	constexpr int IDX_DW = RW - 1;
+	static_assert(TILE <= 8192, "13 bits for the position inside a tile");
+	const bool KEEP_BK = !IDX_BK && P.rec_n > 0;
 	const RecGeom RG = rec_geom(P);
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem1 + (size_t)TILE * RW * 4);
-	__shared__ uint32_t planes[4 * PW];
+	__shared__ uint32_t planes[2 * 4 * PW]; // two sets: the next tile's planes are made while this tile's records wait in the stage
 	__shared__ uint32_t s_total;
 	const int nb1 = 1 << P.F1;
 	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *gdelta = cnt + nb1; // 2 x nb1 counters behind the stage
 	__shared__ uint32_t wsum1[BT / WAVE];
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
-	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
-	if (tile >= n_tiles) return;
-	for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0;
-	build_planes<TILE, BT>(seq, qual, n_pos, tile * TILE, P.q, planes);
-	__syncthreads();
-	RecW<RW> w[S];
-	uint32_t br[S]; // bucket << 16 | rank inside (tile, bucket)
+	// the bloom block id is the low bf_shift-9 bits of the hash, and for k >= bf_shift-9 those are y0's (kmer.h:87): the level-1 bucket is a
+	// bit field of y0's low word then
+	const bool blk_in_y0 = FAST || P.k >= P.bf_shift - 9;
+	const int b1_shift = P.R + P.F2;
+	Pack3 PK = pack3_geom(P);
+	if (FAST) PK.ok = 1;
 	uint32_t n_k = 0, n_h = 0;
-#pragma unroll
-	for (int j = 0; j < S; ++j) {
-		const int r = j * BT + threadIdx.x;
-		W y0, y1; bool hi;
-		br[j] = 0xffffffffu;
-		if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
-			const uint32_t b = fine_id<W>(P, y0, y1) >> P.F2;
-			const uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
-			Rec<RW>::pack(w[j], RG, (uint64_t)y0, (uint64_t)y1, idx, hi);
-			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
-			if (ONEPASS) { ++n_k; n_h += hi; }
+
+	// The streams are read as aligned 16-byte blocks whatever their own alignment (the library cuts sub-batches where a read ends): both
+	// pointers sit at the same offset `mis` inside a block (the host sees to it), position p is byte p + mis of the block stream that starts
+	// at seq - mis, and the planes are built in THOSE coordinates: plane bit j = block-stream byte tile * TILE - 64 + j, a window starts
+	// `mis` bits later.  Bytes of a block that lie outside the batch are turned into separators in the registers: no byte loops.
+	const int mis = (int)((uintptr_t)seq & 15);
+	const uint8_t *const sb = seq - mis, *const qb = qual ? qual - mis : nullptr;
+	const int64_t v_end = n_pos + mis, v_last = (v_end - 1) & ~(int64_t)15; // valid block-stream bytes [mis, v_end); the last block that holds one
+	uint4 pf_s = make_uint4(0, 0, 0, 0), pf_q = make_uint4(0, 0, 0, 0);
+	// (the loads are unconditional, from an address clamped into the batch: their targets are the very registers the next round reads,
+	// with no copy in between that would have to wait for them)
+	const int pf_c = (int)threadIdx.x < NCH ? (int)threadIdx.x : NCH - 1;
+	auto prefetch = [&](int64_t t) {
+		const int64_t v = t * TILE - 64 + (int64_t)pf_c * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
+		pf_s = *reinterpret_cast<const uint4 *>(sb + at);
+		if (qual) pf_q = *reinterpret_cast<const uint4 *>(qb + at);
+	};
+	// bit planes of block-stream bytes [t * TILE - 64, (t + 1) * TILE + 16) into `pl`, from the prefetched 16 bases + 16 qualities of every thread
+	auto make_planes = [&](int64_t t, uint32_t *pl) {
+		const int c = threadIdx.x;
+		if (c < NCH) {
+			const int64_t v = t * TILE - 64 + (int64_t)c * 16;
+			uint4 s4 = pf_s, q4 = pf_q;
+			if (v < mis || v + 16 > v_end) { // a block at the ragged ends of the batch: bytes outside it read as separators (qualities: 0)
+				const int lo = v >= mis ? 0 : mis - v >= 16 ? 16 : (int)(mis - v), hi = v_end - v >= 16 ? 16 : v_end - v <= 0 ? 0 : (int)(v_end - v);
+				const uint32_t bm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u; // bit i: byte i belongs to the batch
+				auto keep = [&](int d) { return (((bm >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu; };
+				const uint32_t k0 = keep(0), k1 = keep(1), k2 = keep(2), k3 = keep(3);
+				s4.x = (s4.x & k0) | (0x0a0a0a0au & ~k0); s4.y = (s4.y & k1) | (0x0a0a0a0au & ~k1); s4.z = (s4.z & k2) | (0x0a0a0a0au & ~k2); s4.w = (s4.w & k3) | (0x0a0a0a0au & ~k3);
+				q4.x &= k0; q4.y &= k1; q4.z &= k2; q4.w &= k3;
+			}
+			uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
+			bases4x(s4.x, 0, m0, m1, mn); bases4x(s4.y, 4, m0, m1, mn); bases4x(s4.z, 8, m0, m1, mn); bases4x(s4.w, 12, m0, m1, mn);
+			if (qual) {
+				const int T = P.q + 33;
+				if (T >= 1 && T <= 127) {
+					const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
+					quals4x(q4.x, 0, add, mq); quals4x(q4.y, 4, add, mq); quals4x(q4.z, 8, add, mq); quals4x(q4.w, 12, add, mq);
+				} else { quals16(q4.x, 0, P.q, mq); quals16(q4.y, 4, P.q, mq); quals16(q4.z, 8, P.q, mq); quals16(q4.w, 12, P.q, mq); }
+			} else mq = 0xffffu;
+			unsigned short *p16 = reinterpret_cast<unsigned short *>(pl);
+			if (c < NC16) {
+				p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
+				p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
+			} else { // the last block's piece shares its word with the first spare piece
+				pl[0 * PW + PW - 2] = m0; pl[1 * PW + PW - 2] = m1; pl[2 * PW + PW - 2] = mn; pl[3 * PW + PW - 2] = mq;
+			}
 		}
+		if (threadIdx.x < 4) pl[threadIdx.x * PW + PW - 1] = 0;
+	};
+	// Which tile next.  Two-pass partition: workgroup per tile, dealt XCD-contiguously (rows1 is indexed by the tile).  One pass: the workgroups
+	// of the persistent grid draw tiles from a counter (behind the cursors) -- a workgroup that becomes resident late, because the previous
+	// kernel still held its CU, then simply draws fewer; with a fixed deal such stragglers cost 50 -> 70 ms per c3 step.  The draw for the
+	// tile after the next rides with the cursors' atomics, so that it is known when its bases are to be requested.
+	__shared__ uint32_t s_draw[3];
+	uint32_t *const tile_ctr = ONEPASS ? OP.cursor + (size_t)8 * nb1 * 32 : nullptr;
+	int64_t it = blockIdx.x;
+	int64_t tile, next_tile, next_it = 0;
+	if (ONEPASS) {
+		if (threadIdx.x == 0) { s_draw[0] = atomicAdd(tile_ctr, 1u); s_draw[1] = atomicAdd(tile_ctr, 1u); }
+		__syncthreads();
+		tile = s_draw[0]; next_tile = s_draw[1];
+	} else { tile = xcd_tile(it, n_tiles); next_it = it + gridDim.x; next_tile = xcd_tile(next_it, n_tiles); }
+	if (tile >= n_tiles) return;
+	int cur = 0;
+	for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0;
+	prefetch(tile);
+	make_planes(tile, planes);
+	prefetch(next_tile);
+	__syncthreads();
+	for (;;) {
+		const uint32_t *pl = planes + cur * 4 * PW;
+		RecW<RW> w[S];
+		uint32_t br[S]; // bucket << 16 | rank inside (tile, bucket)
+#pragma unroll
+		for (int j = 0; j < S; ++j) {
+			int r = j * BT + threadIdx.x;
+			asm volatile("" : "+v"(r)); // (opaque, so that nothing of a body is hoisted out of the tile loop: S sets of window addresses would live across it)
+			bool hi;
+			br[j] = 0xffffffffu;
+			U2 y0, y1;
+			bool have;
+			if (P.ablate & 2048) { // (debug: no hashing, pseudo-random buckets -- what the scatter alone costs)
+				const uint32_t z = ((uint32_t)(tile * TILE + r) * 2654435761u) ^ 0x9e3779b9u;
+				y0.lo = z * 0x85ebca6bu; y0.hi = 0; y1.lo = z; y1.hi = 0; hi = true; have = (r % 151) >= 33;
+			} else
+			if constexpr (sizeof(W) == 8) have = kmer_at2<TILE, KC>(pl, r + mis, P.k, y0, y1, hi);
+			else {
+				W a0, a1;
+				have = kmer_at<W, TILE>(pl, r + mis, P.k, m, a0, a1, hi);
+				y0.lo = (uint32_t)a0; y0.hi = 0; y1.lo = (uint32_t)a1; y1.hi = 0;
+			}
+			if (have) {
+				const uint32_t b = blk_in_y0 ? (y0.lo >> b1_shift) & (uint32_t)(nb1 - 1) : fine_id<W>(P, u2_join(y0), u2_join(y1)) >> P.F2;
+				const uint32_t idx = P.idx_rank | (uint32_t)(tile * TILE + r); // end position = file order (rank-major across GPUs)
+				if (RW == 3 && (FAST || PK.ok)) pack3_fast(*reinterpret_cast<RecW<3> *>(&w[j]), PK, y0, y1, idx, hi);
+				else Rec<RW>::pack(w[j], RG, u2_join(y0), u2_join(y1), idx, hi);
+				br[j] = (b << 16) | atomicAdd(&cnt[b], 1u); // (with IDX_BK the record's last dword is made at staging time: bucket << 13 | r)
+				if (ONEPASS) { ++n_k; n_h += hi; }
+			}
+		}
+		__syncthreads();
+		// bucket counters -> exclusive offsets inside the stage; the runs' places in the output are requested now and used after the staging
+		const uint32_t tot = block_scan_excl<BT>(cnt, nb1, wsum1);
+		if (threadIdx.x == 0) s_total = tot;
+		__syncthreads();
+		constexpr int NBT = (BFCG_MAXB + BT - 1) / BT; // buckets per thread
+		uint32_t gd[NBT], g_ex[NBT], g_c[NBT]; // (one-pass: gd holds the cursor's answer until the records are staged)
+		const uint32_t xcd = blockIdx.x & 7u; // (the XCD this workgroup runs on: its slabs)
+		uint32_t draw = 0;
+		if (ONEPASS && threadIdx.x == 0) draw = atomicAdd(tile_ctr, 1u);
+#pragma unroll
+		for (int u = 0; u < NBT; ++u) {
+			const int i = threadIdx.x + u * BT;
+			gd[u] = 0; g_ex[u] = 0; g_c[u] = 0;
+			if (i < nb1) {
+				g_ex[u] = cnt[i];
+				if (!ONEPASS) gd[u] = rows1[tile * nb1 + i]; // global record index = staged position + gdelta[bucket] (u32 modular)
+				else {
+					g_c[u] = (i + 1 < nb1 ? cnt[i + 1] : tot) - g_ex[u];
+					if (g_c[u] && !(P.ablate & 1024)) gd[u] = atomicAdd(&OP.cursor[((size_t)xcd * nb1 + i) * 32], g_c[u]);
+				}
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < S; ++j) {
+			if (br[j] != 0xffffffffu) {
+				const uint32_t b = br[j] >> 16, pos = cnt[b] + (br[j] & 0xffffu);
+#pragma unroll
+				for (int t = 0; t < (IDX_BK ? RW - 1 : RW); ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
+				if (IDX_BK) stage[(size_t)pos * RW + IDX_DW] = (b << 13) | (uint32_t)(j * BT + threadIdx.x);
+				if (KEEP_BK) sbk[pos] = (unsigned short)b;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < NBT; ++u) {
+			const int i = threadIdx.x + u * BT;
+			if (i < nb1) {
+				if (!ONEPASS) gdelta[i] = gd[u] - g_ex[u];
+				else {
+					uint32_t base = gd[u];
+					if (base + g_c[u] > OP.cap) { OP.flags[0] = 1; base = 0; } // the slab is full: this batch will be replayed; meanwhile write where it does no harm
+					gdelta[i] = ((uint32_t)i * 8u + xcd) * OP.cap + base - g_ex[u];
+				}
+			}
+		}
+		if (ONEPASS && threadIdx.x == 0) s_draw[2] = draw;
+		if (next_tile < n_tiles) make_planes(next_tile, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
+		__syncthreads();
+		for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0; // (the offsets have served: counters of the next tile)
+		const uint32_t n_in = s_total;
+		for (uint32_t pos = threadIdx.x; pos < ((P.ablate & 512) ? 0u : n_in); pos += BT) {
+			RecW<RW> rec;
+#pragma unroll
+			for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
+			uint32_t b;
+			if (IDX_BK) { b = rec.d[IDX_DW] >> 13; rec.d[IDX_DW] = P.idx_rank | ((uint32_t)(tile * TILE) + (rec.d[IDX_DW] & 0x1fffu)); }
+			else if (KEEP_BK) b = sbk[pos];
+			else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, RG, 0u, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) >> P.F2; } // (nothing dropped here)
+			const uint64_t dst = (uint32_t)(pos + gdelta[b]);
+			if (!(P.ablate & 256)) rec_store<RW>(out + dst * RW, rec);
+		}
+		tile = next_tile; cur ^= 1;
+		if (tile >= n_tiles) break;
+		if (ONEPASS) next_tile = s_draw[2];
+		else { it = next_it; next_it = it + gridDim.x; next_tile = xcd_tile(next_it, n_tiles); }
+		prefetch(next_tile); // requested behind this tile's stores, used a whole round later
+		__syncthreads(); // the stage, the counters and gdelta are free again only when every wave has copied its records out
 	}
 	if (ONEPASS) { // the statistics k_hist1 keeps in the two-pass partition: k-mers, high-quality k-mers
 		for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
@@ -399,48 +649,6 @@ __global__ __launch_bounds__(BT) void k_scatter1(KParams P, const uint8_t *__res
 			unsigned long long *sl = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 			atomicAdd(&sl[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl[ST_HIGH], (unsigned long long)n_h);
 		}
-	}
-	__syncthreads();
-	{ // bucket counters -> exclusive offsets inside the stage; gdelta = where the bucket's run goes in the output
-		const uint32_t tot = block_scan_excl<BT>(cnt, nb1, wsum1);
-		if (threadIdx.x == 0) s_total = tot;
-		__syncthreads();
-		if (!ONEPASS) {
-			for (int i = threadIdx.x; i < nb1; i += BT) gdelta[i] = rows1[tile * nb1 + i] - cnt[i]; // global record index = staged position + gdelta[bucket] (u32 modular)
-		} else {
-			const uint32_t xcd = blockIdx.x & 7u;
-			for (int i = threadIdx.x; i < nb1; i += BT) {
-				const uint32_t ex = cnt[i], c = (i + 1 < nb1 ? cnt[i + 1] : tot) - ex;
-				uint32_t base = 0;
-				if (c) {
-					base = atomicAdd(&OP.cursor[((size_t)xcd * nb1 + i) * 32], c);
-					if (base + c > OP.cap) { OP.flags[0] = 1; base = 0; } // the slab is full: this batch will be replayed; meanwhile write where it does no harm
-				}
-				gdelta[i] = ((uint32_t)i * 8u + xcd) * OP.cap + base - ex;
-			}
-		}
-	}
-	__syncthreads();
-#pragma unroll
-	for (int j = 0; j < S; ++j) {
-		if (br[j] != 0xffffffffu) {
-			const uint32_t b = br[j] >> 16, pos = cnt[b] + (br[j] & 0xffffu);
-#pragma unroll
-			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
-			if (KEEP_BK) sbk[pos] = (unsigned short)b;
-		}
-	}
-	__syncthreads();
-	const uint32_t n_in = s_total;
-	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
-		RecW<RW> rec;
-#pragma unroll
-		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
-		uint32_t b;
-		if (KEEP_BK) b = sbk[pos];
-		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, RG, 0u, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) >> P.F2; } // (nothing dropped here)
-		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
-		rec_store<RW>(out + dst * RW, rec);
 	}
 }
 
@@ -1718,15 +1926,37 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 
 #define TILE1 BFCG_TILE1
 #define BT1 256
-#define BTS1 512
+// k_scatter1's tile by record size: 4096 positions, 3072 for 20-byte records -- two workgroups of 512 threads per CU (56 / 73 / 68 KiB of LDS).
+// (Three workgroups of 3584 positions, 768 threads on 4608, 1024 threads, one memory-in wave beside seven hashing waves: all measured, none
+// faster -- the kernel's floor is its skeleton of LDS ranks, scan, staging and barriers, not the hashing: DESIGN.md section 6b.)
+template <int RW> struct S1 { static constexpr int BT = 512, TILE = RW == 5 ? 3072 : 4096; };
+static_assert(S1<3>::TILE == 4096 && S1<4>::TILE == 4096 && S1<5>::TILE == 3072, "bfcg_tile1_of_rw (bfcg_internal.h) sizes the host's buffers");
 #define TILE2 BFCG_TILE2
 #define BT2 512
+
+// BFCG_DEBUG_SYNC=1: wait behind every stage's launches and say which one the device failed in (a memory fault names no kernel)
+static void dbg_sync(hipStream_t st, const char *what)
+{
+	static int on = -1;
+	if (on < 0) on = getenv("BFCG_DEBUG_SYNC") != 0;
+	if (!on) return;
+	fprintf(stderr, "[D::sync] %s ...\n", what); fflush(stderr);
+	const hipError_t e = hipStreamSynchronize(st);
+	fprintf(stderr, "[D::sync] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr);
+}
+
+// k_scatter1<..., FAST>: the level-1 bucket is a bit field of y0's low word and a 12-byte record packs from halves (pack3_geom's conditions)
+static inline bool scatter1_fast(const KParams &P)
+{
+	const int a = P.k - P.rec_n;
+	return P.k >= P.bf_shift - 9 && a >= 1 && a <= 31 && a + P.k >= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n <= 31) && !getenv("BFCG_NO_FAST_K1");
+}
 
 // stage A: bases -> records grouped by (global) level-1 bucket in `out1`; B.start1[2^F1+1] = bucket starts
 template <typename W, int RW>
 static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
 {
-	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
+	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
 	const int nb1 = 1 << P.F1;
 	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
 	const int n_chunks = (int)((tiles1 + SCAN_CH - 1) / SCAN_CH);
@@ -1737,7 +1967,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, T2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr});
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr});
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1745,18 +1975,34 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 template <typename W, int RW>
 static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
 {
-	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2;
+	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
 	const int nb1 = 1 << P.F1;
 	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
 	if (ev) hipEventRecord(ev[0], st);
-	hipMemsetAsync(B.op_cursor, 0, (size_t)8 * nb1 * 32 * sizeof(uint32_t), st);
+	hipMemsetAsync(B.op_cursor, 0, ((size_t)8 * nb1 * 32 + 32) * sizeof(uint32_t), st); // the slabs' cursors and, behind them, k_scatter1's tile counter
 	hipMemsetAsync(B.op_flags, 0, 4 * sizeof(uint32_t), st); // this slot's overflow flags (its previous batch's stage B and flag copy are complete: the caller waited)
 	if (ev) hipEventRecord(ev[1], st);
-	const unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8);
-	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW != 5) ? 2 : 0)) + (size_t)8 * nb1, st,
-	                   P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OnePass{B.op_cursor, B.op_cap, B.op_flags, B.stats});
+	unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8);
+	const size_t lds1 = (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1;
+	const OnePass OP{B.op_cursor, B.op_cap, B.op_flags, B.stats};
+	{ // as many workgroups as are resident at once (a CU's 160 KiB of LDS, at most 2048 threads), each walking its tiles; a multiple of 8 (XCDs)
+		static int n_cu = 0;
+		if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+		int per_cu = (int)((size_t)160 * 1024 / (lds1 + 4400)); if (per_cu > 2) per_cu = 2; if (per_cu < 1) per_cu = 1; // (the kernel is built for 4 waves per SIMD)
+		const char *e = getenv("BFCG_S1_WGS"); if (e && atoi(e) > 0) per_cu = atoi(e);
+		const unsigned gp = (unsigned)(n_cu * per_cu) & ~7u;
+		if (gp >= 8 && gp < g1) g1 = gp;
+	}
+	if constexpr (RW == 3) {
+		if (scatter1_fast(P)) {
+			if (sizeof(W) == 8 && P.k == 33) hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
+			else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
+		} else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
+	} else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
+	dbg_sync(st, "k_scatter1 (one pass)");
 	uint32_t *sg = B.op_seg;
 	hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, st, P, B.op_cursor, B.op_cap, B.op_flags, T2, sg, sg + 8 * nb1, sg + 16 * nb1, sg + 24 * nb1 + 1);
+	dbg_sync(st, "k_seg_setup");
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -1783,6 +2029,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 			                   (uint32_t *)B.recs2, OnePass2{nullptr, 0u, nullptr});
 		}
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
+		dbg_sync(st, "level 2");
 	}
 	if (ev) hipEventRecord(ev[3], st);
 	BloomArgs A;
@@ -1802,6 +2049,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
+		dbg_sync(st, "k_bloom");
 		// a CU's LDS holds 160 KB / segment size workgroups: keep its 2048 lanes busy whatever that number is (c4's 64 KiB segments at 256
 		// threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
 		if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
@@ -1814,6 +2062,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		A.stream_out = B.stream_out;
 		hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
+		dbg_sync(st, "k_bloom");
 		hipLaunchKernelGGL((k_commit_stream<W, RW>), dim3((unsigned)((nfine + 4 * COMMIT_RPW - 1) / (4 * COMMIT_RPW))), dim3(256), 0, st, P, A);
 		if (A.flags) hipLaunchKernelGGL(k_seal, dim3(1), dim3(1), 0, st, B.op_flags, B.op_sticky);
 		if (ev) hipEventRecord(ev[5], st);
@@ -1872,9 +2121,13 @@ int bloom_lds_bytes(const KParams &P)
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	constexpr int T1 = RW == 5 ? 3072 : TILE1, T2 = RW == 5 ? 3072 : TILE2;
+	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	if constexpr (RW == 3) {
+		e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	}
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

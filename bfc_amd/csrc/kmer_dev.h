@@ -64,11 +64,65 @@ template <typename W> __device__ __forceinline__ void kmer_hash_from_windows(int
 	W x0 = brev_w(w_lo) >> (nb - k), x1 = brev_w(w_hi) >> (nb - k);
 	W x2 = ~w_lo & m, x3 = ~w_hi & m;
 	int t = k >> 1;
-	bool rev = ((x1 >> t) & 1) > ((x3 >> t) & 1); // the middle base always differs between strands (odd k)
-	W a = rev ? x2 : x0, b = rev ? x3 : x1;
+	// bit t of x1 above bit t of x3 (kmer.h:82-83; the middle base always differs between strands for odd k): bit t of x1 is bit k-1-t of the
+	// window, bit t of x3 the complement of the window's bit t -- as a lane mask, so that the selection is bitwise (no compare, no v_cndmask)
+	const W sel = W(0) - ((w_hi >> t) & (w_hi >> (k - 1 - t)) & W(1));
+	W a = (x0 & ~sel) | (x2 & sel), b = (x1 & ~sel) | (x3 & sel);
 	W h0 = mix_k<W>((a + b) & m, m);
 	W h1 = mix_k<W>(h0 ^ b, m);
 	y0 = (h0 + h1) & m;
+	y1 = h1;
+}
+
+// ---- k > 32 on 32-bit halves -------------------------------------------------------------------------------------------
+// gfx950 issues every 64-bit integer instruction (v_lshl_add_u64, v_mad_u64_u32, the b64 shifts) at the 4-cycle rate of a 32-bit
+// VOP3 one (scripts/probes/valu_rate.hip), so what counts is the NUMBER of instructions.  A k-bit value, 32 < k < 64, is kept as
+// (lo, hi) with hi holding k - 32 bits.  The steps of bfc_hash_64 (kmer.h:30-40) then are
+//     v * C (+ c)   : one v_mad_u64_u32 for lo * C, and hi' = (carry word + hi * C) & mh      (C = 2^21 - 1, 265, 21, 2^31 + 1:
+//                     ~v + (v << 21) = v (2^21 - 1) - 1;  v + (v << 3) + (v << 8) = 265 v;  v + (v << 2) + (v << 4) = 21 v;  v + (v << 31))
+//     v ^= v >> s   : lo ^= alignbit(hi, lo, s); hi ^= hi >> s   (the latter vanishes for k - 32 <= s)
+// instead of the compiler's generic 64-bit code with two masks per step.  KC > 0: k is known at compile time (the masks fold, for
+// k = 33 the carry into the single high bit becomes one v_bitop3); KC == 0: k at run time.
+struct U2 { uint32_t lo, hi; };
+__device__ __forceinline__ uint64_t u2_join(const U2 v) { return ((uint64_t)v.hi << 32) | v.lo; }
+__device__ __forceinline__ U2 u2_split(uint64_t v) { U2 r; r.lo = (uint32_t)v; r.hi = (uint32_t)(v >> 32); return r; }
+
+template <int KC> __device__ __forceinline__ U2 mix2(U2 v, int k) // v.hi may carry garbage above bit k - 32: the first step masks
+{
+	const int kh = (KC ? KC : k) - 32;
+	const uint32_t mh = (1u << kh) - 1u;
+	uint64_t d = (uint64_t)v.lo * 0x1FFFFFu + ~0ULL;
+	v.hi = ((uint32_t)(d >> 32) + v.hi * 0x1FFFFFu) & mh; v.lo = (uint32_t)d;
+	v.lo ^= __builtin_amdgcn_alignbit(v.hi, v.lo, 24); if (!KC || kh > 24) v.hi ^= v.hi >> 24;
+	d = (uint64_t)v.lo * 265u;
+	v.hi = ((uint32_t)(d >> 32) + v.hi * 265u) & mh; v.lo = (uint32_t)d;
+	v.lo ^= __builtin_amdgcn_alignbit(v.hi, v.lo, 14); if (!KC || kh > 14) v.hi ^= v.hi >> 14;
+	d = (uint64_t)v.lo * 21u;
+	v.hi = ((uint32_t)(d >> 32) + v.hi * 21u) & mh; v.lo = (uint32_t)d;
+	v.lo ^= __builtin_amdgcn_alignbit(v.hi, v.lo, 28); if (!KC || kh > 28) v.hi ^= v.hi >> 28;
+	d = (uint64_t)v.lo * 0x80000001u;
+	v.hi = ((uint32_t)(d >> 32) + v.hi) & mh; v.lo = (uint32_t)d; // hi * (2^31 + 1) = hi + (hi << 31): bit 31 lies above mh
+	return v;
+}
+
+// kmer.h:79-88 from the two forward windows given as halves (w?_hi may carry the stream's next bits above bit k - 32).
+// Strand: bit t = k >> 1 of x1 is bit k-1-t of the window, bit t of x3 the complement of its bit t; both lie below bit 32.
+template <int KC> __device__ __forceinline__ void kmer_hash_from_windows2(int k_, uint32_t wl_lo, uint32_t wl_hi, uint32_t wh_lo, uint32_t wh_hi, U2 &y0, U2 &y1)
+{
+	const int k = KC ? KC : k_, kh = k - 32, s = 32 - kh, t = k >> 1;
+	const uint32_t mh = (1u << kh) - 1u;
+	const uint32_t sel = 0u - ((wh_lo >> t) & (wh_lo >> (k - 1 - t)) & 1u); // all ones: the reverse strand is the canonical one
+	const uint32_t rl = __brev(wl_lo), rh = __brev(wh_lo);
+	// forward planes x0, x1 = bit reversal of the window (kmer.h:13-14); reverse planes x2, x3 = its complement (kmer.h:15-16)
+	U2 a, b;
+	a.lo = (__builtin_amdgcn_alignbit(rl, __brev(wl_hi), s) & ~sel) | (~wl_lo & sel);
+	a.hi = ((rl >> s) & ~sel) | (~wl_hi & sel);
+	b.lo = (__builtin_amdgcn_alignbit(rh, __brev(wh_hi), s) & ~sel) | (~wh_lo & sel);
+	b.hi = ((rh >> s) & ~sel) | (~wh_hi & sel); // (garbage above bit kh in a.hi, b.hi: masked by the first step of mix2)
+	const U2 h0 = mix2<KC>(u2_split(u2_join(a) + u2_join(b)), k);
+	U2 x; x.lo = h0.lo ^ b.lo; x.hi = h0.hi ^ b.hi;
+	const U2 h1 = mix2<KC>(x, k);
+	y0 = u2_split(u2_join(h0) + u2_join(h1)); y0.hi &= mh;
 	y1 = h1;
 }
 

@@ -27,6 +27,11 @@ KERNEL(k_lshl_add_u32, asm volatile("v_lshl_add_u32 %0, %0, 3, %4\n v_lshl_add_u
 KERNEL(k_mul_lo_u32, asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_bfrev,     asm volatile("v_bfrev_b32 %0, %0\n v_bfrev_b32 %1, %1\n v_bfrev_b32 %2, %2\n v_bfrev_b32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
 KERNEL(k_cndmask,   asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");)
+KERNEL(k_cndmask_sgpr, asm volatile("v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "s20", "s21");)
+KERNEL(k_cmp_cndmask, asm volatile("v_cmp_lt_u32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_lt_u32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");)
+KERNEL(k_cmp_only, asm volatile("v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 vcc, %1, %4\n v_cmp_lt_u32 vcc, %2, %4\n v_cmp_lt_u32 vcc, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");)
+KERNEL(k_cndmask_dst, asm volatile("v_cndmask_b32 %0, %1, %4, vcc\n v_cndmask_b32 %1, %2, %4, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %0, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");)
+KERNEL(k_bfi, asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_addco_addc, asm volatile("v_add_co_u32 %0, vcc, %0, %4\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_add_co_u32 %2, vcc, %2, %4\n v_addc_co_u32 %3, vcc, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");)
 KERNEL(k_lshl_add_u64, asm volatile("v_lshl_add_u64 %0, %0, 3, %4\n v_lshl_add_u64 %1, %1, 3, %4\n v_lshl_add_u64 %2, %2, 3, %4\n v_lshl_add_u64 %3, %3, 3, %4" : "+v"(A), "+v"(B), "+v"(C2), "+v"(D) : "v"(A));)
 KERNEL(k_mad_u64_u32, asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3" : "+v"(A), "+v"(B), "+v"(C2), "+v"(D) : "v"(e), "v"(f) : "vcc");)
@@ -48,7 +53,7 @@ int main()
 {
 	ent tab[] = {{"v_add_u32", k_add_u32, 4}, {"v_and_b32", k_and_b32, 4}, {"v_alignbit_b32", k_alignbit, 4}, {"v_lshl_add_u32", k_lshl_add_u32, 4},
 	             {"v_mul_lo_u32", k_mul_lo_u32, 4}, {"v_mul_hi_u32", k_mul_hi_u32, 4}, {"v_mad_u32_u24", k_mad_u32_u24, 4}, {"v_bfrev_b32", k_bfrev, 4}, {"v_bfe_u32", k_bfe_u32, 4},
-	             {"v_cndmask_b32", k_cndmask, 4}, {"v_bitop3_b32 (xor3)", k_xor3, 4}, {"v_and_or_b32", k_and_or, 4}, {"v_pk_add_u16", k_pk_add_u16, 4},
+	             {"v_cndmask_b32 (vcc, uninitialised)", k_cndmask, 4}, {"v_cndmask_b32_e64 (sgpr pair)", k_cndmask_sgpr, 4}, {"v_cmp + v_cndmask pairs (count both)", k_cmp_cndmask, 4}, {"v_cmp_lt_u32 -> vcc", k_cmp_only, 4}, {"v_cndmask_b32 dst != src", k_cndmask_dst, 4}, {"v_bfi_b32", k_bfi, 4}, {"v_bitop3_b32 (xor3)", k_xor3, 4}, {"v_and_or_b32", k_and_or, 4}, {"v_pk_add_u16", k_pk_add_u16, 4},
 	             {"v_add_co+v_addc (pair=2)", k_addco_addc, 4}, {"v_lshl_add_u64", k_lshl_add_u64, 4}, {"v_mad_u64_u32", k_mad_u64_u32, 4},
 	             {"v_lshrrev_b64", k_lshrrev_b64, 4}, {"v_lshlrev_b64", k_lshlrev_b64, 4}, {"v_mov_b64", k_mov_b64, 4}, {"v_add_u32 + s_add_u32 interleaved (VALU count)", k_salu_mix, 4}};
 	hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);

@@ -1,6 +1,6 @@
 # round 3: full GPU suite + smoke + a driver-style bench line
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -25 > gpurun_out/r3_gpu_tests.log; tail -8 gpurun_out/r3_gpu_tests.log
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r3_gpu_tests.log; tail -8 gpurun_out/r3_gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 900 python bench.py --steps ${STEPS:-10} --warmup 3 > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.log; echo bench rc=$?
 python - <<'PY'

@@ -532,7 +532,7 @@ def test_trim_pass_on_several_gpus_with_reads_sorted_by_length(tmp_path):
     fn = str(tmp_path / "sorted.fq")
     open(fn, "wb").write(b"".join(recs))
     r = subprocess.run([REFBIN, "-1", "-k", "21", "-b", "24", "-t", "1", fn], capture_output=True, timeout=600)
-    assert r.returncode == 0 and len(r.stdout) > 100_000, r.stderr.decode()[-500:]
+    assert r.returncode == 0 and len(r.stdout) > 10_000, r.stderr.decode()[-500:]
     for devices in ("0", "0,0", "0,0,0,0"):
         g = subprocess.run([GPUTRIM, "-1", "-k", "21", "-b", "24", "-t", "2", fn], capture_output=True, timeout=600,
                            env=dict(os.environ, BFC_GPU_DEVICES=devices, BFC_GPU_BATCH="200000"))
