@@ -21,6 +21,7 @@
 using namespace bfcg;
 
 static thread_local char g_err[512] = "";
+enum { HO_MAX_PAGES = 8 };
 enum { OP_FLAG_WORDS = 12, OP_STICKY = 8 }; // bfcg_ctx.op_flags: two slots of four words, the sticky poison word
 static int set_err(const char *fmt, ...)
 {
@@ -84,6 +85,16 @@ struct bfcg_ctx {
 	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
 	int seg_no_grow;             // the next segment size does not fit (memory / LDS): grow only when a segment overflows or the load passes 85 %
 	int seg_cap_shift;           // the allocation behind B.seg_tab holds segments of up to 2^seg_cap_shift slots
+	// Hand-over log of the region-owned table: the seen k-mers of up to ho_K batches wait per region and are applied in ONE pass over the table
+	// segments (k_commit_seg).  A page = one batch's entries; ho_stride = ho_K x (a region's slab at level 2) entries per region.
+	unsigned long long *ho, *ho_keys, *h_ho_keys[2]; uint32_t *ho_cur, *ho_mark; uint32_t ho_stride; int ho_K;
+	int ho_pending;                     // pages filled since the last commit
+	uint64_t ho_page_call[HO_MAX_PAGES]; // the call a page's batch belongs to
+	int slot_commit[2]; uint64_t slot_page_call[2][HO_MAX_PAGES]; // pages committed inside the stage B of the batch in this slot, and their calls
+	int slot_all_committed[2];          // nothing was left in the log behind that batch: the counters' snapshot is the table's exact state
+	uint64_t keys_known;                // distinct keys after the last absorbed commit
+	int commit_absorbed;                // a commit's key counts have arrived since the last growth forecast
+	uint64_t keys_per_batch; int n_commits, ho_window; // most keys one batch created in the last absorbed commit; commits absorbed since the reset; pages the current window takes
 	unsigned long long *seg_spare; int seg_spare_shift; // the buffer the last growth left behind (kept up to 16 GiB): growth rehashes from one into the other,
 	                             // so a context that counts one data set after the other stops calling hipMalloc / hipFree (tens of ms per multi-GiB call)
 };
@@ -280,7 +291,25 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.seg = 1; P.seg_shift = sh; c->seg_cap_shift = sh;
 		HIPCKN(set_seg_lds_attr());
 		HIPCKN(hipMalloc(&B.seg_tab, ((uint64_t)nfine << sh) * 8));
-		HIPCKN(hipMalloc(&c->stream_out, c->recs2_n * (uint64_t)c->rw));
+		{ // the hand-over log: ho_K pages per region where level 2 bounds a region's share of a batch (its slab), else one batch at its records' offsets
+			const char *e = getenv("BFCG_COMMIT_K");
+			int K = e ? atoi(e) : 4;
+			if (K < 1) K = 1;
+			if (K > HO_MAX_PAGES) K = HO_MAX_PAGES;
+			if (!c->cap2) K = 1;
+			size_t free_b = 0, total_b = 0;
+			const uint64_t page = (uint64_t)nfine * (c->cap2 ? c->cap2 : 1) * 8;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) while (K > 1 && page * (uint64_t)K > (uint64_t)free_b / 4) --K; // (a quarter of what is free, at most)
+			c->ho_K = K;
+			c->ho_stride = c->cap2 ? (uint32_t)K * c->cap2 : 0u;
+			uint64_t entries = (uint64_t)nfine * c->ho_stride;
+			if (entries < c->recs2_n) entries = c->recs2_n; // (two-pass batches hand over at their records' offsets)
+			HIPCKN(hipMalloc(&c->ho, (entries + 4096) * 8));
+			HIPCKN(hipMalloc(&c->ho_cur, sizeof(uint32_t) * (size_t)nfine));
+			HIPCKN(hipMalloc(&c->ho_mark, sizeof(uint32_t) * (size_t)nfine * HO_MAX_PAGES));
+			HIPCKN(hipMalloc(&c->ho_keys, sizeof(unsigned long long) * ST_SLOTS * HO_MAX_PAGES));
+			for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_ho_keys[b], sizeof(unsigned long long) * ST_SLOTS * HO_MAX_PAGES));
+		}
 	}
 	if (P.filter_mode) HIPCKN(hipMalloc(&B.bloom_hi, c->bloom_bytes));
 	else if (!c->seg_ok) HIPCKN(hipMalloc(&B.table, 8ULL << (P.l_pre + P.tab_cshift)));
@@ -322,6 +351,8 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
+	(void)hipFree(c->ho); (void)hipFree(c->ho_cur); (void)hipFree(c->ho_mark); (void)hipFree(c->ho_keys);
+	for (int b = 0; b < 2; ++b) if (c->h_ho_keys[b]) (void)hipHostFree(c->h_ho_keys[b]);
 	for (int b = 0; b < 2; ++b) { (void)hipFree(c->op_cursor[b]); (void)hipFree(c->op_seg[b]); if (c->h_flags[b]) (void)hipHostFree(c->h_flags[b]); }
 	(void)hipFree(c->op_flags); (void)hipFree(c->cnt2); for (int i = 0; i < 4; ++i) free(c->mg_seg[i]);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
@@ -337,6 +368,10 @@ static int replay_poisoned(bfcg_ctx_t *c);
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats);
 static int same_block_offset(bfcg_ctx_t *c, int b, const uint8_t *d_seq, const uint8_t **d_qual, uint64_t n_pos, hipStream_t s);
+static int commit_pending_pages(bfcg_ctx_t *c, int b);
+static void absorb_pages(bfcg_ctx_t *c, int b);
+static int handover_begin(bfcg_ctx_t *c, BatchBufs &Bt, int b, int slabs, uint64_t call);
+static int handover_end(bfcg_ctx_t *c, const BatchBufs &Bt, int b);
 
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
@@ -373,6 +408,9 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 		}
 		if (c->n_batches) c->reused = 1;
 		c->P.seg = 1; c->seg_escaped = 0;
+		HIPCK(hipMemsetAsync(c->ho_cur, 0, sizeof(uint32_t) * (size_t)nfine, c->st));
+		c->ho_pending = 0; c->slot_commit[0] = c->slot_commit[1] = 0; c->slot_all_committed[0] = c->slot_all_committed[1] = 0; c->keys_known = 0; c->commit_absorbed = 0;
+		c->keys_per_batch = 0; c->n_commits = 0; c->ho_window = 1;
 		HIPCK(hipMemsetAsync(c->B.seg_tab, 0, (nfine << c->P.seg_shift) * 8, c->st));
 	}
 	if (c->B.table) HIPCK(hipMemsetAsync(c->B.table, 0, 8ULL << (c->P.l_pre + c->P.tab_cshift), c->st));
@@ -412,7 +450,12 @@ static void fold_snapshot(bfcg_ctx_t *c, int b)
 		c->h_stats[i] = s;
 	}
 	c->h_stats[ST_TAB_OVF] = raw[(size_t)ST_SLOTS * ST_N];
-	c->final_call = c->slot_call[b]; c->call_keys[c->slot_call[b] & 63] = c->h_stats[ST_KEYS];
+	absorb_pages(c, b);
+	if (c->slot_all_committed[b]) { // nothing waits in the hand-over log behind this batch: the snapshot is the table's state
+		c->final_call = c->slot_call[b]; c->call_keys[c->slot_call[b] & 63] = c->h_stats[ST_KEYS];
+		if (c->h_stats[ST_KEYS] > c->keys_known && c->h_stats[ST_KEYS] - c->keys_known > c->keys_per_batch) c->keys_per_batch = c->h_stats[ST_KEYS] - c->keys_known; // (a batch applied at its records' offsets, parked k-mers replayed)
+		c->keys_known = c->h_stats[ST_KEYS]; c->commit_absorbed = 1;
+	}
 	c->pos_final += c->slot_pos[b]; c->slot_pos[b] = 0;
 }
 
@@ -453,13 +496,21 @@ static int drain(bfcg_ctx_t *c)
 	HIPCK(hipGetLastError());
 	c->pend = 0;
 	if (batch_times(c, c->cur ^ 1) != 0) return -1;
+	absorb_pages(c, c->cur); absorb_pages(c, c->cur ^ 1); // (older slot first)
 	if (c->n_opq) { // batches that went through the one-pass partition: were their slabs large enough?
 		uint32_t sticky = 0;
 		HIPCK(hipMemcpy(&sticky, c->op_flags + OP_STICKY, sizeof(sticky), hipMemcpyDeviceToHost));
 		if (sticky) return replay_poisoned(c);
 		c->n_opq = 0;
 	}
+	if (c->P.seg && c->ho_pending) { // what still waits in the hand-over log
+		if (commit_pending_pages(c, 0) != 0) return -1;
+		HIPCK(hipStreamSynchronize(c->st));
+		HIPCK(hipGetLastError());
+		absorb_pages(c, 0);
+	}
 	if (fetch_stats(c) != 0) return -1;
+	c->keys_known = c->h_stats[ST_KEYS]; c->commit_absorbed = 1;
 	c->final_call = c->call_no; c->call_keys[c->call_no & 63] = c->h_stats[ST_KEYS];
 	c->pos_final += c->slot_pos[0] + c->slot_pos[1]; c->slot_pos[0] = c->slot_pos[1] = 0;
 	note_growth(c);
@@ -507,7 +558,10 @@ static void note_growth(bfcg_ctx_t *c)
 		if (np) { c->cold = ds * 5 < np * 2; c->seen_per_pos = (double)ds / (double)np; }
 		c->seen_last = c->h_stats[ST_SEEN]; c->pos_final = 0;
 	}
-	c->grow[1] = c->grow[0]; c->grow[0] = keys > c->keys_last ? keys - c->keys_last : 0; c->keys_last = keys;
+	if (!c->P.seg || c->commit_absorbed) { // (with the hand-over log the table changes when a commit lands: a forecast per commit, not per batch)
+		c->grow[1] = c->grow[0]; c->grow[0] = keys > c->keys_last ? keys - c->keys_last : 0; c->keys_last = keys;
+		c->commit_absorbed = 0;
+	}
 	// more than half of the regions filled their aggregation table in the batch(es) just finalised: aggregation does not pay here
 	const uint64_t crowded = c->h_stats[ST_CROWDED], nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
 	if (!c->stream_mode && c->B.table && !c->P.track && c->P.n_hashes == 4 && c->P.bloom_bt == 512 && !getenv("BFCG_NO_STREAM") && (crowded - c->crowded_last) * 2 > nfine) c->stream_mode = 1;
@@ -583,7 +637,9 @@ static int seg_target_shift(const bfcg_ctx_t *c)
 	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
 	// growing is one coalesced pass over the segments (k_seg_rehash: c3's 4 GiB in 0.9 ms), a batch into segments that are too full is not:
 	// forecast with the larger of the last two batches' additions
-	const uint64_t need = c->h_stats[ST_KEYS] + c->h_stats[ST_TAB_OVF], g = c->grow[0] > c->grow[1] ? c->grow[0] : c->grow[1];
+	// (with the hand-over log the table changes commit by commit: what ONE more batch may add -- the largest page of the last commit, and what a
+	// batch adds only shrinks -- must fit below the growth mark; how many batches a commit then takes is the window's business: handover_begin)
+	const uint64_t need = c->h_stats[ST_KEYS] + c->h_stats[ST_TAB_OVF], g = c->ho_K > 1 ? c->keys_per_batch : c->grow[0] > c->grow[1] ? c->grow[0] : c->grow[1];
 	int t = P.seg_shift;
 	const double full = c->seg_no_grow ? 0.85 : 0.62;
 	while ((double)(need + (c->seg_no_grow ? 0 : g)) > full * (double)(nfine << t)) ++t;
@@ -772,7 +828,9 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2; Bt.op_flags = c->op_flags + 4 * b;
 		HIPCK(hipMemsetAsync(Bt.op_flags, 0, 4 * sizeof(uint32_t), c->st)); // (no one-pass stage A on a rank: stage B clears its slot's flags itself)
 	}
+	if (handover_begin(c, Bt, b, op2, c->call_no + 1) != 0) return -1; // (this call's number: assigned below)
 	run_stage_b(c->P, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	if (handover_end(c, Bt, b) != 0) return -1;
 	if (op2_run) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
 		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
 		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
@@ -795,7 +853,7 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 static int use_stream(bfcg_ctx_t *c)
 {
 	if (c->stream_mode) {
-		if (!c->stream_out) HIPCK(hipMalloc(&c->stream_out, c->recs2_n * (uint64_t)c->rw));
+		if (!c->P.seg && !c->stream_out) HIPCK(hipMalloc(&c->stream_out, c->recs2_n * (uint64_t)c->rw)); // (the segment layout hands over through its log)
 		++c->n_stream_batches;
 	}
 	return 0;
@@ -822,6 +880,90 @@ static int finalise_previous(bfcg_ctx_t *c, int b)
 	}
 	c->pend = 1; c->cur = b ^ 1;
 	return 0;
+}
+
+// ---- hand-over log (region-owned table segments)
+
+// the pages filled so far -> the segments, as a launch of its own on stream st (before a batch that cannot use the log; when the pipeline is
+// drained); the pages' key counts go to the pinned buffer of slot b
+static int commit_pending_pages(bfcg_ctx_t *c, int b)
+{
+	if (!c->ho_pending) return 0;
+	const uint32_t nfine = (uint32_t)(((uint64_t)1 << c->P.F) >> c->log2n);
+	BatchBufs Bt = c->B;
+	Bt.ho = c->ho; Bt.ho_stride = c->ho_stride; Bt.ho_cur = c->ho_cur; Bt.ho_mark = c->ho_mark; Bt.ho_mark_stride = nfine; Bt.ho_keys = c->ho_keys;
+	HIPCK(hipMemsetAsync(c->ho_keys, 0, sizeof(unsigned long long) * ST_SLOTS * (size_t)c->ho_pending, c->st));
+	run_commit_pages(c->P, Bt, nfine, (uint32_t)c->ho_pending, c->st);
+	HIPCK(hipMemcpyAsync(c->h_ho_keys[b], c->ho_keys, sizeof(unsigned long long) * ST_SLOTS * (size_t)c->ho_pending, hipMemcpyDeviceToHost, c->st));
+	c->slot_commit[b] = c->ho_pending;
+	memcpy(c->slot_page_call[b], c->ho_page_call, sizeof(uint64_t) * (size_t)c->ho_pending);
+	c->ho_pending = 0;
+	return 0;
+}
+// Stage B of the batch in slot b is about to be enqueued: where do its seen k-mers go?  `slabs`: its level 2 runs in one pass, so a region's
+// share is bounded by its slab and the batch takes a page of the log; else it hands over at its records' offsets and is applied at once
+// (what waits in the log goes first: the two share the arena).
+static int handover_begin(bfcg_ctx_t *c, BatchBufs &Bt, int b, int slabs, uint64_t call)
+{
+	c->slot_commit[b] = 0; c->slot_all_committed[b] = 1;
+	if (!c->P.seg) return 0;
+	const uint32_t nfine = (uint32_t)(((uint64_t)1 << c->P.F) >> c->log2n);
+	Bt.stream_out = (uint32_t *)c->ho;
+	Bt.ho = c->ho; Bt.ho_cur = c->ho_cur; Bt.ho_mark = c->ho_mark; Bt.ho_mark_stride = nfine; Bt.ho_keys = c->ho_keys;
+	if (!slabs || c->ho_stride == 0 || Bt.seen_out) { // (debug_seen contexts run one batch at a time anyway)
+		if (commit_pending_pages(c, b) != 0) return -1;
+		Bt.ho_stride = 0; Bt.ho_page = 0; Bt.ho_commit = 1; Bt.ho_keys = nullptr;
+		return 0;
+	}
+	if (c->ho_pending == 0) { // a new window: as many batches as the segments have room for, judged by what the last commit's batches created
+		// (a young table grows by most of a batch's k-mers: applied batch by batch, and grown in between, until the keys level off)
+		int w = 1;
+		if (c->ho_K > 1 && c->n_commits > 0) {
+			// (upserts probe in LDS: a window may fill the segments to 85 % on average; what a batch adds only shrinks as the keys level off, so
+			// the last commit's largest page bounds the next batches'; a segment that fills up all the same parks its k-mers, exactly)
+			const double room = 0.85 * (double)((uint64_t)nfine << c->P.seg_shift) - (double)c->keys_known, g = 1.1 * (double)(c->keys_per_batch ? c->keys_per_batch : 1);
+			w = room <= g ? 1 : room / g >= (double)c->ho_K ? c->ho_K : (int)(room / g);
+		}
+		c->ho_window = w;
+		if (getenv("BFCG_DEBUG")) fprintf(stderr, "[D::window] %d batches: keys %llu, largest page of the last commit %llu, slots %llu, commits so far %d\n", w,
+			(unsigned long long)c->keys_known, (unsigned long long)c->keys_per_batch, (unsigned long long)((uint64_t)nfine << c->P.seg_shift), c->n_commits);
+	}
+	Bt.ho_stride = c->ho_stride; Bt.ho_page = (uint32_t)c->ho_pending;
+	c->ho_page_call[c->ho_pending++] = call;
+	Bt.ho_commit = c->ho_pending >= c->ho_window;
+	if (Bt.ho_commit) HIPCK(hipMemsetAsync(c->ho_keys, 0, sizeof(unsigned long long) * ST_SLOTS * (size_t)c->ho_pending, c->st));
+	else c->slot_all_committed[b] = 0;
+	return 0;
+}
+// ... and it has been enqueued: the key counts of a commit it carried follow it to the host
+static int handover_end(bfcg_ctx_t *c, const BatchBufs &Bt, int b)
+{
+	if (!c->P.seg || Bt.ho_stride == 0 || !Bt.ho_commit) return 0;
+	HIPCK(hipMemcpyAsync(c->h_ho_keys[b], c->ho_keys, sizeof(unsigned long long) * ST_SLOTS * (size_t)c->ho_pending, hipMemcpyDeviceToHost, c->st));
+	c->slot_commit[b] = c->ho_pending;
+	memcpy(c->slot_page_call[b], c->ho_page_call, sizeof(uint64_t) * (size_t)c->ho_pending);
+	c->ho_pending = 0;
+	return 0;
+}
+// the key counts of the pages committed with slot b's batch have arrived (its stage B is complete): distinct keys after every page's batch
+static void absorb_pages(bfcg_ctx_t *c, int b)
+{
+	const int J = c->slot_commit[b];
+	if (!J) return;
+	uint64_t run = c->keys_known, most = 0;
+	for (int j = 0; j < J; ++j) {
+		const unsigned long long *row = c->h_ho_keys[b] + (size_t)j * ST_SLOTS;
+		uint64_t d = 0;
+		for (int i = 0; i < ST_SLOTS; ++i) d += row[i];
+		run += d;
+		if (d > most) most = d;
+		c->call_keys[c->slot_page_call[b][j] & 63] = run;
+	}
+	c->keys_per_batch = most; ++c->n_commits;
+	c->final_call = c->slot_page_call[b][J - 1];
+	c->keys_known = run;
+	c->slot_commit[b] = 0;
+	c->commit_absorbed = 1;
 }
 
 // k_scatter1 reads both streams as aligned 16-byte blocks and wants them at the SAME offset inside a block (any offset: sub-batches start
@@ -868,11 +1010,13 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	HIPCK(hipStreamWaitEvent(c->st, c->evA[b], 0));
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, n_pos, c->st));
+	if (handover_begin(c, Bt, b, op && Bt.cap2, c->call_no) != 0) return -1;
 	if (op) {
 		uint32_t *sg = c->op_seg[b];
 		run_stage_b(Pt, Bt, Bt.recs1, sg, sg + 8 * nb1, 8 * nb1, 8, sg + 16 * nb1, sg + 24 * nb1 + 1, n_pos, c->st, c->evt[b]);
 	} else
 	run_stage_b(Pt, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
+	if (handover_end(c, Bt, b) != 0) return -1;
 	if (op_run) {
 		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st)); // behind k_seal: is the run poisoned up to and including this batch?
 		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");

@@ -58,6 +58,10 @@ struct BatchBufs {
 	// reads the slabs through: seg_beg[8 nb1] | seg_end[8 nb1] | row_base[8 nb1 + 1] | bucket_start[nb1 + 1]
 	uint32_t *op_cursor, *op_flags, *op_sticky, *op_seg; uint32_t op_cap;
 	uint32_t *cnt2; uint32_t cap2;            // one-pass level 2: a slab of cap2 records per bloom region in recs2 and its cursor (0: two passes, start2 says where)
+	// hand-over log of the region-owned table (bfcg_kernels.hip: BloomArgs): arena, entries per region (0: this batch's entries go to stream_out at
+	// its records' offsets and are applied at once), cursors, marks [pages][ho_mark_stride], the page this batch fills, whether stage B ends with
+	// the commit of pages 0..ho_page, and the per-page key counters [pages][ST_SLOTS]
+	unsigned long long *ho; uint32_t ho_stride; uint32_t *ho_cur, *ho_mark; uint32_t ho_mark_stride, ho_page; int ho_commit; unsigned long long *ho_keys;
 	unsigned long long *seg_tab;              // region-owned table segments: [regions][2^seg_shift] slots of id << 14 | high << 8 | count (KParams.seg)
 	unsigned long long *tab_first, *sub_last; // order stamps (NULL unless KParams.track)
 	unsigned long long batch_hi;              // batch number << 32
@@ -82,6 +86,8 @@ void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old
 void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
 void run_seg_to_table(const KParams &P, const unsigned long long *seg_tab, uint32_t n_fine, unsigned long long *tab, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
 hipError_t set_seg_lds_attr(void);
+// apply the pages 0..pages-1 of the hand-over log to the segments (no bloom pass): before a batch that cannot use the log, and when the pipeline is drained
+void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st);
 #define BFCG_SEG_MAX_SHIFT 14 /* a segment must fit a CU's LDS: 2^14 slots = 128 KiB */
 void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab,
                       const unsigned long long *old_first, unsigned long long *new_first, hipStream_t st);

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <stdio.h>
 #include "kmer_dev.h"
 #include "bfcg_internal.h"
@@ -997,6 +998,13 @@ struct BloomArgs {
 	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
 	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
 	const uint32_t *cnt2; uint32_t cap2; // one-pass level 2: region f's records are recs[f * cap2 .. + cnt2[f]) (cap2 = 0: start[] says where)
+	// Hand-over log of the region-owned table: region f owns ho[f * ho_stride .. + ho_stride); k_bloom appends its seen k-mers
+	// behind ho_cur[f] -- which lives on from batch to batch -- and notes where the batch ended (ho_mark: this batch's page, one word per
+	// region); k_commit_seg applies the pages of several batches in one pass over the segment and clears the cursor.  ho_stride == 0:
+	// the batch's entries sit at its records' offsets in stream_out instead (two-pass level 2: a region's share has no bound) and are applied at once.
+	unsigned long long *ho; uint32_t ho_stride; uint32_t *ho_cur; uint32_t *ho_mark;
+	uint32_t ho_pages, ho_mark_stride;  // k_commit_seg: pages to apply (page j's marks at ho_mark + j * ho_mark_stride)
+	unsigned long long *ho_keys;        // k_commit_seg: keys created by page j, slotted: ho_keys[j * ST_SLOTS + (f & (ST_SLOTS - 1))]
 	const uint32_t *flags;         // one-pass partition, this batch's slot: [0] a level-1 slab overflowed, [2] a region's slab (NULL: two-pass batch)
 	const uint32_t *sticky;        // an earlier batch of the run overflowed (written by k_seal on stage B's stream only)
 };
@@ -1165,10 +1173,24 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_seen, s_agg_n, s_fs_used, s_pad[2];
 	const uint32_t f = blockIdx.x;
-	if (batch_poisoned(A)) return;
+	const bool ho_log = SEGOUT && A.ho_stride != 0;
+	if (batch_poisoned(A)) { if (ho_log && threadIdx.x == 0) A.ho_mark[f] = A.ho_cur[f]; return; } // (an empty page: the batch will be replayed)
 	uint32_t rs, n;
 	region_list(A, f, rs, n);
-	if (n == 0) { if (threadIdx.x == 0 && A.agg_cnt) A.agg_cnt[f] = 0; return; }
+	if (n == 0) { if (threadIdx.x == 0) { if (ho_log) A.ho_mark[f] = A.ho_cur[f]; else if (A.agg_cnt) A.agg_cnt[f] = 0; } return; }
+	// where this batch's seen k-mers go: behind what earlier batches left in the region's log, or at the records' own offsets
+	uint32_t ho_cur0 = 0;
+	unsigned long long *ho_base = nullptr;
+	if (SEGOUT) {
+		if (ho_log) {
+			ho_cur0 = A.ho_cur[f];
+			if (ho_cur0 + n > A.ho_stride) { // (the host commits before a log can fill up: a bug if it ever happens -- loudly, not silently)
+				if (threadIdx.x == 0) { atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_ERR_POOL], 1ULL); A.ho_mark[f] = ho_cur0; }
+				return;
+			}
+			ho_base = A.ho + (uint64_t)f * A.ho_stride + ho_cur0;
+		} else ho_base = reinterpret_cast<unsigned long long *>(A.stream_out) + rs;
+	}
 	A.stats += (size_t)(f & (ST_SLOTS - 1)) * ST_N; // statistics are slotted: no chip-wide single-address atomics
 	const int region_blocks = 1 << P.R;                 // P.R already clamped to bf_shift-9
 	const uint32_t region_dw = region_blocks * 16;
@@ -1265,7 +1287,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			o0 = __shfl(o0, leader);
 			const uint64_t at = (uint64_t)rs + o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1));
 			if constexpr (SEGOUT) { // region-owned table segments: all k_commit_seg needs is the k-mer's identity inside this region and its quality flag
-				reinterpret_cast<unsigned long long *>(A.stream_out)[at] = (seg_id(seg_geom(P), r.y0, r.y1) << 1) | (unsigned long long)r.hi;
+				ho_base[at - rs] = (seg_id(seg_geom(P), r.y0, r.y1) << 1) | (unsigned long long)r.hi;
 			} else {
 				RecW<RW> w;
 				Rec<RW>::pack(w, rec_geom(P), r.y0, r.y1, r.idx, r.hi);
@@ -1499,7 +1521,8 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (s_seen) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)s_seen);
-		if (A.agg_cnt) A.agg_cnt[f] = s_agg_n;
+		if (ho_log) { A.ho_cur[f] = ho_cur0 + s_agg_n; A.ho_mark[f] = ho_cur0 + s_agg_n; }
+		else if (A.agg_cnt) A.agg_cnt[f] = s_agg_n;
 	}
 	if (timing) {
 		tq[5] = clock64();
@@ -1607,50 +1630,72 @@ __device__ __forceinline__ void seg_park(const BloomArgs &A, uint64_t y0, uint64
 	if (o < A.tab_ovf_cap) { A.tab_ovf[5 * o] = y0; A.tab_ovf[5 * o + 1] = y1; A.tab_ovf[5 * o + 2] = (uint64_t)c | ((uint64_t)h << 32); A.tab_ovf[5 * o + 3] = 0; A.tab_ovf[5 * o + 4] = 0; }
 }
 
-// one workgroup per region: the seen k-mers of region f are the 8-byte entries stream_out[start[f] .. start[f] + agg_cnt[f]) (k_bloom, SEGOUT):
-// identity inside the region << 1 | high-quality flag
+// One workgroup per region: its seen k-mers are 8-byte entries -- identity inside the region << 1 | high-quality flag -- either the pages
+// that the batches since the last commit appended to the region's hand-over log (A.ho_stride != 0: page j = log[mark[j-1][f], mark[j][f])),
+// or this one batch's entries at stream_out[start[f] .. + agg_cnt[f]).  The segment goes through LDS ONCE for all of them: counts are
+// saturating and order-free (htab.c:73-79), so nothing forces a pass over the table per pass over the filter (round 2 made one: 32 of 200 ms
+// on c3, 38 % of c4).  Pages are applied one after the other with a barrier between them, so that the keys a page creates are exactly the
+// keys that batch would have created: bfc_count's `# distinct k-mers` lines (count.c:113) stay exact per chunk.
 template <int BT>
 __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
 	__shared__ uint32_t s_new;
 	const uint32_t f = blockIdx.x;
-	if (batch_poisoned(A)) return;
-	const uint32_t n = A.agg_cnt[f];
+	const bool log = A.ho_stride != 0;
+	const uint32_t pages = log ? A.ho_pages : 1u;
+	uint32_t n;
+	const unsigned long long *recs;
+	if (log) { n = A.ho_mark[(size_t)(pages - 1) * A.ho_mark_stride + f]; recs = A.ho + (uint64_t)f * A.ho_stride; }
+	else {
+		if (batch_poisoned(A)) return;
+		n = A.agg_cnt[f];
+		uint32_t rs0, n0;
+		region_list(A, f, rs0, n0);
+		recs = reinterpret_cast<const unsigned long long *>(A.stream_out) + rs0;
+	}
 	if (n == 0) return;
 	const uint32_t slots = 1u << P.seg_shift, mask = slots - 1;
 	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift);
-	uint32_t rs0, n0;
-	region_list(A, f, rs0, n0);
-	const unsigned long long *recs = reinterpret_cast<const unsigned long long *>(A.stream_out) + rs0;
 	const SegGeom G = seg_geom(P);
 	// few k-mers for a large segment: touch their lines only (this workgroup alone owns the segment, the atomics order its own lanes)
 	const bool direct = (uint64_t)n * 16 < slots;
-	uint32_t n_new = 0;
-	if (threadIdx.x == 0) s_new = 0;
 	if (!direct) {
 		const uint4 *src = reinterpret_cast<const uint4 *>(gseg);
 		uint4 *dst = reinterpret_cast<uint4 *>(lseg);
 		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
 	}
-	__syncthreads();
-	for (uint32_t j = threadIdx.x; j < n; j += BT) {
-		const unsigned long long v = recs[j];
-		const uint64_t id = v >> 1;
-		const uint32_t hi = (uint32_t)(v & 1);
-		const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
-		if (r > 0) ++n_new;
-		else if (r < 0) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); }
+	uint32_t total_new = 0, beg = 0;
+	for (uint32_t pg = 0; pg < pages; ++pg) {
+		const uint32_t end = log ? A.ho_mark[(size_t)pg * A.ho_mark_stride + f] : n;
+		if (threadIdx.x == 0) s_new = 0;
+		__syncthreads(); // (the segment is staged / the page before is applied)
+		uint32_t n_new = 0;
+		for (uint32_t j = beg + threadIdx.x; j < end; j += BT) {
+			const unsigned long long v = recs[j];
+			const uint64_t id = v >> 1;
+			const uint32_t hi = (uint32_t)(v & 1);
+			const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
+			if (r > 0) ++n_new;
+			else if (r < 0) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); }
+		}
+		for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+		if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new, n_new);
+		__syncthreads();
+		const uint32_t pn = s_new;
+		total_new += pn;
+		if (threadIdx.x == 0 && pn && A.ho_keys) atomicAdd(&A.ho_keys[(size_t)pg * ST_SLOTS + (f & (ST_SLOTS - 1))], (unsigned long long)pn);
+		beg = end;
 	}
-	for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
-	if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new, n_new);
-	__syncthreads();
 	if (!direct) {
 		uint4 *dst = reinterpret_cast<uint4 *>(gseg);
 		const uint4 *src = reinterpret_cast<const uint4 *>(lseg);
 		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
 	}
-	if (threadIdx.x == 0 && s_new) atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_KEYS], (unsigned long long)s_new);
+	if (threadIdx.x == 0) {
+		if (total_new) atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_KEYS], (unsigned long long)total_new);
+		if (log) A.ho_cur[f] = 0; // the log is empty again
+	}
 }
 
 // grow: segment f of 2^old_shift slots -> 2^P.seg_shift slots, rebuilt in LDS (all keys are distinct, the new segment is at most half full)
@@ -2006,6 +2051,24 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	if (ev) hipEventRecord(ev[2], st);
 }
 
+// a CU's LDS holds 160 KB / segment size workgroups: keep its 2048 lanes busy whatever that number is (c4's 64 KiB segments at 256
+// threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
+static void launch_commit_seg(const KParams &P, const BloomArgs &A, int nfine, hipStream_t st)
+{
+	if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
+	else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)8 << P.seg_shift, st, P, A);
+	else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+	dbg_sync(st, "k_commit_seg");
+}
+void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st)
+{
+	BloomArgs A;
+	memset(&A, 0, sizeof(A));
+	A.stats = B.stats; A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.seg_tab = B.seg_tab; A.n_fine = n_fine;
+	A.ho = B.ho; A.ho_stride = B.ho_stride; A.ho_cur = B.ho_cur; A.ho_mark = B.ho_mark; A.ho_mark_stride = B.ho_mark_stride; A.ho_pages = pages; A.ho_keys = B.ho_keys;
+	launch_commit_seg(P, A, (int)n_fine, st);
+}
+
 // stage B: records in `in1` as n_seg segments (seg_beg/seg_end, row_base over segments, bucket_start over the
 // nb_loc = n_seg/segs_per_bucket owned level-1 buckets) -> fine buckets -> bloom regions -> table
 template <typename W, int RW>
@@ -2033,6 +2096,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	}
 	if (ev) hipEventRecord(ev[3], st);
 	BloomArgs A;
+	memset(&A, 0, sizeof(A));
 	A.recs = fine_recs; A.start = fine_start; A.bloom = B.bloom; A.bloom_hi = B.bloom_hi; A.table = B.table; A.stats = B.stats;
 	A.tab_ovf = B.tab_ovf; A.tab_ovf_cap = B.tab_ovf_cap; A.ovf_cnt = B.stats + (size_t)ST_SLOTS * ST_N; A.pool = B.pool; A.pool_slices = B.pool_slices; A.seen_out = B.seen_out;
 	A.agg_out = B.agg_out; A.agg_cnt = B.agg_cnt; A.n_fine = (uint32_t)nfine; A.stream_out = nullptr; A.seg_tab = nullptr;
@@ -2044,17 +2108,17 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
 		else if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
-	} else if (P.seg && B.seg_tab && B.stream_out) { // region-owned table segments: seen k-mers are streamed to k_commit_seg, one workgroup per region
+	} else if (P.seg && B.seg_tab && (B.stream_out || B.ho)) { // region-owned table segments: seen k-mers are handed to k_commit_seg, one workgroup per region
 		A.stream_out = B.stream_out; A.seg_tab = B.seg_tab; A.table = nullptr; A.agg_out = nullptr;
+		A.ho = B.ho; A.ho_stride = B.ho_stride; A.ho_cur = B.ho_cur; A.ho_mark = B.ho_stride ? B.ho_mark + (size_t)B.ho_page * B.ho_mark_stride : nullptr;
 		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
 		dbg_sync(st, "k_bloom");
-		// a CU's LDS holds 160 KB / segment size workgroups: keep its 2048 lanes busy whatever that number is (c4's 64 KiB segments at 256
-		// threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
-		if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
-		else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)8 << P.seg_shift, st, P, A);
-		else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+		if (B.ho_stride == 0 || B.ho_commit) { // the log's pages so far (or this batch's entries at its records' offsets) into the segments
+			A.ho_mark = B.ho_mark; A.ho_mark_stride = B.ho_mark_stride; A.ho_pages = B.ho_page + 1; A.ho_keys = B.ho_keys;
+			launch_commit_seg(P, A, nfine, st);
+		}
 		if (A.flags) hipLaunchKernelGGL(k_seal, dim3(1), dim3(1), 0, st, B.op_flags, B.op_sticky);
 		if (ev) hipEventRecord(ev[5], st);
 		return;
