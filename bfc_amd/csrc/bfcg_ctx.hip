@@ -252,7 +252,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], recs1_n * c->rw));
 	{ // a rank of a multi-GPU run partitions what it RECEIVES in one pass (level 2 is the owner's own stage B; level 1 feeds the exchange and stays two-pass)
 		const char *e = getenv("BFCG_ONEPASS");
-		c->mg_op2_ok = n_ranks > 1 && P.F2 > 0 && !(e && atoi(e) == 0);
+		c->mg_op2_ok = P.F2 > 0 && !(e && atoi(e) == 0); // (also the single rank of a group of one: bench.py with BFC_BENCH_FORCE_DIST, tests)
 	}
 	if (c->onepass_ok) {
 		for (int b = 0; b < 2; ++b) {

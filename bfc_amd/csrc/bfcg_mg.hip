@@ -449,19 +449,81 @@ extern "C" int bfcg_group_progress(bfcg_group_t *g, uint64_t *batches, uint64_t 
 	return j;
 }
 
-extern "C" int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos)
+static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
+
+// A group of ONE rank counts a batch far larger than the filter's regions take at full speed in ROUNDS, as a single GPU cuts an oversized call
+// into sub-batches (a region handles only so many k-mers with clear bits per pass -- list_cap -- before it falls onto the exact but slow HBM
+// path).  With several ranks the owner splits what it received by SOURCES instead (process_in_groups): the file order of a global batch is
+// rank-major, so pieces of every rank's share taken round by round would not be in file order -- consecutive sources are.
+static int rounds_for(bfcg_group_t *g, uint64_t local_pos, int *rounds)
 {
-	for (int i = 0; i < g->n_local; ++i) { g->r[i].in_seq = d_seq[i]; g->r[i].in_qual = d_qual ? d_qual[i] : 0; g->r[i].in_pos = n_pos[i]; g->r[i].in_host = 0; }
-	return run_job(g);
+	*rounds = 1;
+	if (g->n_ranks > 1) return 0;
+	uint64_t total = local_pos;
+	if (g->mp) {
+		rank_t &R = g->r[0];
+		std::vector<unsigned long long> all((size_t)g->n_ranks, 0);
+		unsigned long long mine = local_pos;
+		unsigned long long *d = reinterpret_cast<unsigned long long *>(R.d_counts); // (free between batches; N * (nb1 + 1) words >= 2 N)
+		hipError_t he = hipSetDevice(R.device);
+		ncclResult_t ne = ncclSuccess;
+		if (he == hipSuccess) he = hipMemcpyAsync(d + R.rank, &mine, sizeof(mine), hipMemcpyHostToDevice, R.xs);
+		if (he == hipSuccess) ne = ncclAllGather(d + R.rank, d, 1, ncclUint64, R.comm, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipMemcpyAsync(all.data(), d, sizeof(unsigned long long) * (size_t)g->n_ranks, hipMemcpyDeviceToHost, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipStreamSynchronize(R.xs);
+		if (he != hipSuccess || ne != ncclSuccess) { bfcg_set_error("all-gather of the ranks' batch sizes failed"); return -1; }
+		total = 0;
+		for (auto v : all) total += v;
+	}
+	double warm = 1e30;
+	for (auto &R : g->r) { const double w = bfcg_mg_warm_factor(R.ctx); if (w < warm) warm = w; }
+	const double per_rank = 0.8 * (double)total / (double)g->n_ranks, limit = (double)g->kmer_limit * warm * 0.9;
+	int r = per_rank <= limit * 7.0 / 6.0 ? 1 : (int)(per_rank / limit) + 1; // (just above the limit a few slow regions cost less than another pass over filter and table)
+	if (getenv("BFCG_MG_ROUNDS")) r = atoi(getenv("BFCG_MG_ROUNDS"));
+	*rounds = r < 1 ? 1 : r > 64 ? 64 : r;
+	return 0;
 }
 
-static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
+// first position behind a byte that ends every k-mer (not ACGT), at or behind `at`, in a device-resident stream of n bytes
+static uint64_t dev_cut(rank_t &R, const uint8_t *d_seq, uint64_t at, uint64_t n)
+{
+	uint8_t buf[4096];
+	while (at < n) {
+		const uint64_t w = n - at < sizeof(buf) ? n - at : sizeof(buf);
+		if (hipSetDevice(R.device) != hipSuccess || hipMemcpyAsync(buf, d_seq + at, w, hipMemcpyDeviceToHost, R.cs) != hipSuccess || hipStreamSynchronize(R.cs) != hipSuccess) return n;
+		for (uint64_t i = 0; i < w; ++i) if (!is_acgt(buf[i])) return at + i + 1;
+		at += w;
+	}
+	return n;
+}
+
+extern "C" int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos)
+{
+	const int NL = g->n_local;
+	uint64_t local = 0;
+	for (int i = 0; i < NL; ++i) local += n_pos[i];
+	int rounds = 1;
+	if (rounds_for(g, local, &rounds) != 0) return -1;
+	std::vector<uint64_t> cut((size_t)NL * (size_t)(rounds + 1), 0);
+	for (int i = 0; i < NL; ++i) { // every rank's share in `rounds` pieces, cut where a read ends
+		uint64_t *c = &cut[(size_t)i * (size_t)(rounds + 1)];
+		c[rounds] = n_pos[i];
+		for (int r = 1; r < rounds; ++r) { c[r] = n_pos[i] ? dev_cut(g->r[i], d_seq[i], n_pos[i] / (uint64_t)rounds * (uint64_t)r, n_pos[i]) : 0; if (c[r] < c[r - 1]) c[r] = c[r - 1]; }
+	}
+	for (int r = 0; r < rounds; ++r) {
+		for (int i = 0; i < NL; ++i) {
+			const uint64_t *c = &cut[(size_t)i * (size_t)(rounds + 1)];
+			g->r[i].in_seq = d_seq[i] + c[r]; g->r[i].in_qual = d_qual && d_qual[i] ? d_qual[i] + c[r] : 0; g->r[i].in_pos = c[r + 1] - c[r]; g->r[i].in_host = 0;
+		}
+		if (run_job(g) != 0) return -1;
+	}
+	return 0;
+}
 
 // One global batch from host memory (all ranks local): the stream is cut into n_ranks contiguous shares at separator bytes (no k-mer spans
 // one) -- rank r takes the r-th share, which is the rank-major file order the exchange assumes.
-extern "C" int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)
+static int group_host_piece(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)
 {
-	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_count_batch_host needs every rank in this process"); return -1; }
 	const int N = g->n_ranks;
 	uint64_t o = 0;
 	for (int i = 0; i < N; ++i) {
@@ -473,6 +535,21 @@ extern "C" int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq
 		o = e;
 	}
 	return run_job(g);
+}
+extern "C" int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos)
+{
+	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_count_batch_host needs every rank in this process"); return -1; }
+	int rounds = 1; // an oversized batch: in rounds (rounds_for), each a piece of the stream cut where a read ends
+	if (rounds_for(g, n_pos, &rounds) != 0) return -1;
+	uint64_t a = 0;
+	for (int r = 0; r < rounds && a < n_pos; ++r) {
+		uint64_t e = r + 1 == rounds ? n_pos : n_pos / (uint64_t)rounds * (uint64_t)(r + 1);
+		if (e < a) e = a;
+		while (e < n_pos && e > a && is_acgt(h_seq[e - 1])) ++e;
+		if (e > a && group_host_piece(g, h_seq + a, h_qual ? h_qual + a : 0, e - a) != 0) return -1;
+		a = e;
+	}
+	return 0;
 }
 
 // sums over the local ranks (a multi-process caller adds the processes' sums up); table geometry of rank `first`

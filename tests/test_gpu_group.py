@@ -242,3 +242,25 @@ def test_group_c4_geometry_on_4_ranks(gpu_lib):
     assert oracle.l1_digest(*t.export_sorted()) == e["l1_digest"]
     t.close()
     grp.close()
+
+
+def test_bench_through_the_group_path_is_verified(tmp_path):
+    """bench.py as the driver launches it for N > 1 -- under torch.distributed.run, one process per GPU, the RCCL unique id over gloo -- with a
+    world of ONE and BFC_BENCH_FORCE_DIST=1: the records take the group path of libbfc_gpu.so (bfcg_group_*: stage A, sizes all-gather and
+    exchange on the RCCL communicator, stage B behind the exchange stream's events) and the state the last step leaves behind must be the
+    reference's for the workload's read set (tests/golden/baseline.json: "verified")."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BFC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-boundary"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-500:]
+    d = json.loads(line[0])
+    assert d["verified"] is True, d.get("verification")
+    assert "RCCL" in d["config"]["parallelism"] and d["n_gpus"] == 1
+    assert d["roofline"]["kernel"].startswith("bloom-insert path") and 0 < d["roofline"]["frac"] < 1
