@@ -190,6 +190,11 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.fs_cap = fs;
 		P.list_cap = best_list;
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
+		{ // the class table of cold batches lies over the first-setter table and the lists
+			const size_t room = (size_t)P.fs_cap * 4 + (size_t)P.list_cap * 8;
+			uint32_t ct = 1; while ((size_t)ct * 2 * 8 <= room) ct <<= 1;
+			P.ct_cap = ct;
+		}
 	}
 	P.tab_cshift = prm->tab_cshift > 0 ? prm->tab_cshift : (P.l_pre <= 20 ? 5 : 3);
 	if (prm->tab_cshift <= 0) // a first batch can create up to half as many keys as it has k-mers: start with a quarter of the batch's positions in slots
@@ -372,6 +377,10 @@ static int commit_pending_pages(bfcg_ctx_t *c, int b);
 static void absorb_pages(bfcg_ctx_t *c, int b);
 static int handover_begin(bfcg_ctx_t *c, BatchBufs &Bt, int b, int slabs, uint64_t call);
 static int handover_end(bfcg_ctx_t *c, const BatchBufs &Bt, int b);
+
+// k_bloom resolves the copies of a k-mer by class before the bit-level protocol (KParams.dedupe) where that pays: into an empty filter
+// (c3's first launch 14.2 -> 10.3 ms); from the second batch on most k-mers are seen outright and the extra passes cost more than they save
+static int dedupe_hint(const bfcg_ctx_t *c) { return (c->n_batches == 0 || (c->cold && c->seen_per_pos < 0.15)) && !getenv("BFCG_NO_DEDUPE"); }
 
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
@@ -829,7 +838,9 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 		HIPCK(hipMemsetAsync(Bt.op_flags, 0, 4 * sizeof(uint32_t), c->st)); // (no one-pass stage A on a rank: stage B clears its slot's flags itself)
 	}
 	if (handover_begin(c, Bt, b, op2, c->call_no + 1) != 0) return -1; // (this call's number: assigned below)
-	run_stage_b(c->P, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	KParams Pm = c->P;
+	Pm.dedupe = dedupe_hint(c);
+	run_stage_b(Pm, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
 	if (handover_end(c, Bt, b) != 0) return -1;
 	if (op2_run) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
 		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
@@ -994,6 +1005,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	Bt.stream = c->stream_mode; Bt.stream_out = c->stream_out;
 	KParams Pt = c->P;
 	Pt.no_kstats = no_kstats;
+	Pt.dedupe = dedupe_hint(c);
 	const uint8_t *const d_qual_given = d_qual; // (what a replay starts from again)
 	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, sA) != 0) return -1;
 	const int op_run = c->onepass && !no_kstats;  // the run still uses the one-pass partition: an earlier batch may turn out to have overflowed a slab

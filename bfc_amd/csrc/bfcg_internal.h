@@ -37,6 +37,8 @@ struct KParams {
 	int seg_lo, seg_hi;         // bits [seg_lo, seg_hi) of y0 are implied by the region (kmer_dev.h: SegGeom)
 	uint32_t f_base;            // global id of this rank's first bloom region
 	int no_kstats;              // stage A does not count k-mers / high-quality k-mers (a batch that is replayed was counted the first time)
+	int dedupe;                 // this batch goes into a (nearly) empty filter: k_bloom resolves the copies of a k-mer by class first (host's hint, speed only)
+	uint32_t ct_cap;            // entries of k_bloom's class table (a power of two; 8-byte entries over the first-setter table and the lists)
 	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
 };
 

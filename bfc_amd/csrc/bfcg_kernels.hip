@@ -1081,7 +1081,50 @@ __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, 
 }
 
 // one k-mer record of the bloom kernel, decoded
-struct KRec { uint64_t y0, y1; uint32_t idx, bl, h1, h2; bool hi; };
+struct KRec { uint64_t y0, y1; uint32_t idx, bl, h1, h2; bool hi; uint32_t d0, d1; }; // (d0, d1: the 12-byte record's first words, for the fast paths below)
+
+// Bloom address and hand-over entry of a 12-byte record on 32-bit words (what decode_rec / seg_id compute through 64-bit y0, y1).  The record
+// holds y0' = y0 without its level-1 bucket bits [lo, lo+n) in bits [0, a) and y1 in bits [a, a+k); for k >= bf_shift-9 the block id is the low
+// bf_shift-9 bits of y0 (kmer.h:87), so
+//     block inside the region = y0' & (2^R - 1)
+//     h1 | h2 << 9 = bits [bf_shift-9, bf_shift+9) of the hash (h0^h1) << k | y0  =  (y0' >> up) | ((y0 - y1) ^ y1) << (k - (bf_shift-9))
+// (up = where the part of y0 above the block id starts inside y0'; only the low bits of y0 - y1 are needed), and the k-mer's identity inside the
+// region -- y0 without the bits the region implies, then y1 (kmer_dev.h: seg_id) -- is  (y0' & (2^R-1)) | (y0' >> up) << R | y1 << (k - F).
+struct Dec3 { int ok, a, lo, n, up, sh_x, R, sh_flag, sh_y1; uint32_t lowmask, rmask, mk32; };
+__device__ __forceinline__ Dec3 dec3_geom(const KParams &P)
+{
+	Dec3 g;
+	g.a = P.k - P.rec_n; g.lo = P.rec_lo; g.n = P.rec_n; g.up = P.rec_n ? P.rec_lo : P.bf_shift - 9; g.sh_x = P.k - (P.bf_shift - 9);
+	g.R = P.R; g.sh_flag = g.a + P.k - 32; g.sh_y1 = P.k - P.F;
+	g.lowmask = P.rec_n ? (1u << (P.rec_lo & 31)) - 1u : 0xffffffffu; g.rmask = (1u << P.R) - 1u; g.mk32 = P.k >= 32 ? 0xffffffffu : (1u << P.k) - 1u;
+	g.ok = P.k >= P.bf_shift - 9 && P.bf_shift + 9 <= 2 * P.k && g.a >= 1 && g.a <= 31 && g.a + P.k >= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n <= 31)
+	       && g.up <= g.a && g.sh_x >= 0 && g.sh_x <= 31 && g.sh_y1 >= 0 && g.sh_y1 <= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n == P.bf_shift - 9) && P.R <= g.up;
+	return g;
+}
+__device__ __forceinline__ KRec decode_fast3(const Dec3 g, const RecW<3> &w, uint32_t imp)
+{
+	KRec r;
+	r.d0 = w.d[0]; r.d1 = w.d[1]; r.idx = w.d[2];
+	const uint32_t y0d = w.d[0] & ((1u << g.a) - 1u), upper = y0d >> g.up;
+	const uint32_t y0lo = g.n ? (y0d & g.lowmask) | (imp << g.lo) | (upper << (g.lo + g.n)) : y0d; // low word of y0
+	const uint32_t y1lo = __builtin_amdgcn_alignbit(w.d[1], w.d[0], g.a) & g.mk32;
+	const uint32_t x = (y0lo - y1lo) ^ y1lo;            // low bits of h0 ^ h1 (h0 = y0 - y1 mod 2^k, kmer.h:85-86)
+	const uint32_t hh = upper | (x << g.sh_x);
+	r.bl = y0d & g.rmask; r.h1 = hh & 511u; r.h2 = (hh >> 9) & 511u;
+	if ((r.h2 & 31u) == 0) r.h2 = (r.h2 + 1) & 511u;   // bbf.c:33
+	r.hi = (w.d[1] >> g.sh_flag) & 1u;
+	r.y0 = r.y1 = 0;
+	return r;
+}
+// the 8-byte hand-over entry: identity inside the region << 1 | high-quality flag
+__device__ __forceinline__ unsigned long long entry_fast3(const Dec3 g, const KRec &r, int k)
+{
+	const unsigned long long A = r.d0 | ((unsigned long long)r.d1 << 32);
+	const unsigned long long y1 = (A >> g.a) & (k >= 64 ? ~0ULL : (1ULL << k) - 1);
+	const uint32_t y0d = r.d0 & ((1u << g.a) - 1u);
+	const unsigned long long id = (unsigned long long)((y0d & g.rmask) | ((y0d >> g.up) << g.R)) | (y1 << g.sh_y1);
+	return (id << 1) | (unsigned long long)r.hi;
+}
 
 template <typename W, int RW>
 __device__ __forceinline__ KRec decode_rec(const KParams &P, const RecW<RW> &w, W m, uint32_t rmask, uint32_t imp)
@@ -1090,6 +1133,7 @@ __device__ __forceinline__ KRec decode_rec(const KParams &P, const RecW<RW> &w, 
 	Rec<RW>::unpack(w, rec_geom(P), imp, r.y0, r.y1, r.idx, r.hi);
 	BloomAddr a = bloom_addr(bloom_hash<W>(P.k, (W)r.y0, (W)r.y1, m), P.bf_shift);
 	r.bl = (uint32_t)a.blk & rmask; r.h1 = a.h1; r.h2 = a.h2;
+	r.d0 = r.d1 = 0;
 	return r;
 }
 
@@ -1149,6 +1193,29 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 	return FS32_EMPTY;
 }
 
+// Class table of the cold batches (KParams.dedupe): k-mers with the same bloom block, h1 and h2 touch the same bits, so among the copies of
+// such a class inside one batch only the EARLIEST can be unseen -- the others find every bit set by it.  Entry = class << 32 | file index,
+// the minimum wins; 8-byte entries over the memory the first-setter table and the lists use afterwards.  In an empty filter a batch
+// holds ~1.3 copies of every genome k-mer: without this, every second k-mer contends for all its bits with its own copy (round 2's
+// cold launches: 13.8 / 7.6 / 5.6 ms against 5.5 warm).
+__device__ __forceinline__ uint32_t ct_home(uint32_t cls, uint32_t mask) { return ((cls * 0x9E3779B1u) >> 9 ^ cls) & mask; }
+__device__ __forceinline__ void ct_insert(unsigned long long *ct, uint32_t mask, uint32_t cls, uint32_t idx)
+{
+	const unsigned long long e = ((unsigned long long)cls << 32) | idx;
+	for (uint32_t p = ct_home(cls, mask);; p = (p + 1) & mask) { // (the table has twice the entries a workgroup can bring: always terminates)
+		unsigned long long cur = ct[p];
+		if (cur == FS_EMPTY) { cur = atomicCAS(&ct[p], FS_EMPTY, e); if (cur == FS_EMPTY) return; }
+		if ((uint32_t)(cur >> 32) == cls) { if (e < cur) atomicMin(&ct[p], e); return; }
+	}
+}
+__device__ __forceinline__ uint32_t ct_first(const unsigned long long *ct, uint32_t mask, uint32_t cls)
+{
+	for (uint32_t p = ct_home(cls, mask);; p = (p + 1) & mask) {
+		const unsigned long long cur = ct[p];
+		if ((uint32_t)(cur >> 32) == cls) return (uint32_t)cur;
+	}
+}
+
 // LDS layout (dynamic): region 2^R*64 B | agg id0 ag*8 [| id1 ag*8] | agg cnt ag*8 | fs fs_cap*4 B | list idx list_cap*4 | list (record index | mask<<20) list_cap*4
 //
 // Structure, driven by measurements (SQ_WAIT_ANY 63 % of a workgroup's life, SALU instructions 1.6x VALU):
@@ -1166,7 +1233,9 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 // STREAM: no aggregation; every seen k-mer is appended, as the record it came in, to the region's slice of A.stream_out and k_commit_stream
 // applies them.  For batches in which k-mers hardly repeat (a large genome at ~1x per batch) the aggregation table only costs: it fills
 // with singletons and the rest updates the count table from inside this kernel, a returning atomic in a workgroup that lives microseconds.
-template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false, bool STREAM = false, bool SEGOUT = false>
+// F3 (12-byte records into the hand-over log, geometry checked by the host: bloom_fast3): bloom address and hand-over entry on 32-bit words
+// (decode_fast3 / entry_fast3) -- a variant of its own, so that the generic 64-bit decode does not cost it registers.
+template <typename W, int RW, int BT, int PF, int NH, bool TRACK, bool FM = false, bool STREAM = false, bool SEGOUT = false, bool F3 = false>
 __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, BloomArgs A)
 {
 	if (P.ablate & 8) return;
@@ -1221,6 +1290,16 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	const uint32_t rmask = region_blocks - 1;
 	const uint32_t imp = (P.f_base + f) >> P.F2; // the region's level-1 bucket: the bits of y0 its records do not store
 	const int nh = NH ? NH : P.n_hashes;
+	static_assert(!F3 || (RW == 3 && SEGOUT), "the fast decode is for 12-byte records into the hand-over log");
+	const Dec3 D3 = dec3_geom(P);
+	constexpr bool fast3 = F3;
+	auto dec = [&](const RecW<RW> &w) -> KRec {
+		if constexpr (F3) return decode_fast3(D3, *reinterpret_cast<const RecW<3> *>(&w), imp);
+		else return decode_rec<W, RW>(P, w, m, rmask, imp);
+	};
+	// cold batch (host's hint) and every record of the region fits the threads' registers: copies of a k-mer are resolved by class first, and the
+	// passes over the k-mers with clear bits run on the decoded records in registers (no list of record indices, no second look at HBM)
+	const bool dd = P.dedupe && P.ct_cap >= 2u * BT * PF && n <= (uint32_t)(BT * PF) && n <= P.list_cap;
 
 	const bool timing = (P.ablate & 64) && threadIdx.x == 0;
 	long long tq[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1238,7 +1317,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = threadIdx.x; i < region_dw / 4; i += BT) dst[i] = src[i];
-		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS32_EMPTY;
+		for (uint32_t i = threadIdx.x; i < (dd ? 2u * P.ct_cap : P.fs_cap); i += BT) fs[i] = FS32_EMPTY; // (dd: the class table lies over the first-setter table and the lists)
 		if (FM) {
 			const uint4 *src2 = reinterpret_cast<const uint4 *>(g_region_hi);
 			uint4 *dst2 = reinterpret_cast<uint4 *>(region_hi);
@@ -1287,7 +1366,8 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			o0 = __shfl(o0, leader);
 			const uint64_t at = (uint64_t)rs + o0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1));
 			if constexpr (SEGOUT) { // region-owned table segments: all k_commit_seg needs is the k-mer's identity inside this region and its quality flag
-				ho_base[at - rs] = (seg_id(seg_geom(P), r.y0, r.y1) << 1) | (unsigned long long)r.hi;
+				if constexpr (fast3) ho_base[at - rs] = entry_fast3(D3, r, P.k);
+				else ho_base[at - rs] = (seg_id(seg_geom(P), r.y0, r.y1) << 1) | (unsigned long long)r.hi;
 			} else {
 				RecW<RW> w;
 				Rec<RW>::pack(w, rec_geom(P), r.y0, r.y1, r.idx, r.hi);
@@ -1310,14 +1390,79 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		}
 	};
 
+	// ---- cold batch, copies resolved by class (dd): the thread's records stay in registers (rw[], decoded again in every pass: arithmetic,
+	// not memory) through all passes
+	uint32_t dum[PF], dli[PF]; // clear-bit mask (0: nothing left to decide; bit 31: a later copy of its class -- seen, emitted in pass C); list index
+	constexpr uint32_t DCOPY = 0x80000000u;
+	auto cls_of = [](const KRec &r) { return r.bl | (r.h1 << 10) | (r.h2 << 19); };
+	if (dd) {
+		unsigned long long *ct = reinterpret_cast<unsigned long long *>(fs);
+		const uint32_t ct_mask = P.ct_cap - 1;
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+			dum[u] = 0; dli[u] = 0;
+			if (threadIdx.x + u * BT < n) {
+				const KRec r = dec(rw[u]);
+				dum[u] = clear_mask(r);
+				if (dum[u] == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
+					++n_seen;
+					if (A.seen_out) A.seen_out[r.idx] = 2;
+					emit(r);
+				} else ct_insert(ct, ct_mask, cls_of(r), r.idx);
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < PF; ++u)
+			if (dum[u]) {
+				const KRec r = dec(rw[u]);
+				if (ct_first(ct, ct_mask, cls_of(r)) != r.idx) dum[u] = DCOPY; // an earlier copy sets every bit before this one comes
+			}
+		__syncthreads(); // the class table has served: its memory becomes the first-setter table and the list of file indices
+		for (uint32_t i = threadIdx.x; i < P.fs_cap; i += BT) fs[i] = FS32_EMPTY;
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < PF; ++u) { // a list index for every k-mer still to decide: the first-setter entries name their k-mer by it
+			const bool want = dum[u] != 0 && dum[u] != DCOPY;
+			const unsigned long long vote = __ballot(want);
+			if (vote) {
+				const int leader = __ffsll((long long)vote) - 1;
+				uint32_t li0 = 0;
+				if (lane == leader) li0 = atomicAdd(&s_list_n, (uint32_t)__popcll(vote));
+				li0 = __shfl(li0, leader);
+				if (want) { dli[u] = li0 + (uint32_t)__popcll(vote & ((1ULL << lane) - 1)); list_a[dli[u]] = dec(rw[u]).idx; } // (<= n <= list_cap entries)
+			}
+		}
+		__syncthreads();
+		// pass A: set every clear bit; a bit somebody of this batch set before is contended -> first-setter entry (as below, on the list)
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+			if (!dum[u] || dum[u] == DCOPY) continue;
+			const KRec r = dec(rw[u]);
+			uint32_t z = r.h1;
+#pragma unroll
+			for (int j = 0; j < (NH ? NH : 12); ++j) {
+				if (j >= nh) break;
+				const uint32_t b = bloom_next(z, r.h2);
+				if ((dum[u] >> j) & 1u) {
+					const uint32_t bit = 1u << (b & 31);
+					const uint32_t old = atomicOr(&region[r.bl * 16 + (b >> 5)], bit);
+					if (old & bit) {
+						*(volatile uint32_t *)&s_fs_used = 1;
+						if (!fs32_insert(fs, fs_mask, r.bl * 512 + b, dli[u], r.idx, list_a)) *v_ovf = 1;
+					}
+				}
+			}
+		}
+	}
 	// ---- pass 1: classify; seen -> aggregate, clear bits -> list
-	for (uint32_t base = 0; base < n; base += BT * PF) {
+	for (uint32_t base = 0; !dd && base < n; base += BT * PF) {
 		KRec r[PF]; uint32_t um[PF]; bool act[PF];
 #pragma unroll
 		for (int u = 0; u < PF; ++u) {
 			act[u] = base + threadIdx.x + u * BT < n;
 			um[u] = 0;
-			if (act[u]) { r[u] = decode_rec<W, RW>(P, rw[u], m, rmask, imp); um[u] = clear_mask(r[u]); }
+			if (act[u]) { r[u] = dec(rw[u]); um[u] = clear_mask(r[u]); }
 		}
 #pragma unroll
 		for (int u = 0; u < PF; ++u) {
@@ -1345,7 +1490,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	// touches is trivially set first by that k-mer.  A thread keeps the records of its first LK list entries in registers.
 	constexpr int LK = 2;
 	RecW<RW> lw[LK];
-	if (!*v_ovf) {
+	if (!dd && !*v_ovf) {
 #pragma unroll
 		for (int q = 0; q < LK; ++q) {
 			const uint32_t li = threadIdx.x + q * BT;
@@ -1358,7 +1503,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			RecW<RW> w;
 			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
-			KRec r = decode_rec<W, RW>(P, w, m, rmask, imp);
+			KRec r = dec(w);
 			const uint32_t um = list_b[li] >> 20;
 			uint32_t z = r.h1;
 #pragma unroll
@@ -1383,12 +1528,49 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	if (!s_ovf) {
 		// ---- pass B: the k-mer that set a contended bit first IN EXECUTION ORDER has not entered the competition yet:
 		// every toucher of a bit that has an entry competes for it (earliest in file order wins)
+		if (dd) { // the same two passes on the records in registers
+			if (s_fs_used) {
+#pragma unroll
+				for (int u = 0; u < PF; ++u) {
+					if (!dum[u] || dum[u] == DCOPY) continue;
+					const KRec r = dec(rw[u]);
+					uint32_t z = r.h1;
+#pragma unroll
+					for (int j = 0; j < (NH ? NH : 12); ++j) {
+						if (j >= nh) break;
+						const uint32_t b = bloom_next(z, r.h2);
+						if ((dum[u] >> j) & 1u) fs32_compete(fs, fs_mask, r.bl * 512 + b, dli[u], r.idx, list_a);
+					}
+				}
+				__syncthreads();
+			}
+#pragma unroll
+			for (int u = 0; u < PF; ++u) {
+				if (!dum[u]) continue;
+				const KRec r = dec(rw[u]);
+				bool first = dum[u] != DCOPY && !s_fs_used;
+				if (dum[u] != DCOPY && s_fs_used) {
+					uint32_t z = r.h1;
+#pragma unroll
+					for (int j = 0; j < (NH ? NH : 12); ++j) {
+						if (j >= nh) break;
+						const uint32_t b = bloom_next(z, r.h2);
+						if ((dum[u] >> j) & 1u) {
+							const uint32_t h = fs32_lookup(fs, fs_mask, r.bl * 512 + b);
+							first |= (h == FS32_EMPTY) | (h == dli[u]); // uncontended, or this k-mer won
+						}
+					}
+				}
+				if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
+				if (!first) { ++n_seen; emit(r); }
+			}
+		} else {
 		if (s_fs_used) {
 			for (uint32_t li = threadIdx.x, q = 0; li < ln; li += BT, ++q) {
 				RecW<RW> w;
 				if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 				else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
-				KRec r = decode_rec<W, RW>(P, w, m, rmask, imp);
+				KRec r = dec(w);
 				const uint32_t um = list_b[li] >> 20;
 				uint32_t z = r.h1;
 #pragma unroll
@@ -1405,7 +1587,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			RecW<RW> w;
 			if (q < LK) w = q == 0 ? lw[0] : lw[LK - 1];
 			else w = rec_load<RW>(recs + (uint64_t)(list_b[li] & 0xfffffu) * RW);
-			KRec r = decode_rec<W, RW>(P, w, m, rmask, imp);
+			KRec r = dec(w);
 			const uint32_t um = list_b[li] >> 20;
 			uint32_t z = r.h1; bool first = !s_fs_used;
 			if (!first) {
@@ -1421,6 +1603,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 			}
 			if (A.seen_out) A.seen_out[r.idx] = first ? 1 : 2;
 			if (!first) { ++n_seen; emit(r); }
+		}
 		}
 		dirty = ln != 0;
 		__syncthreads();
@@ -1450,7 +1633,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		__syncthreads();
 		const uint32_t gmask = cap - 1;
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask, imp);
+			KRec r = dec(rec_load<RW>(recs + (uint64_t)i * RW));
 			uint32_t z = r.h1;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, r.h2);
@@ -1460,7 +1643,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 		__threadfence();
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < n; i += BT) {
-			KRec r = decode_rec<W, RW>(P, rec_load<RW>(recs + (uint64_t)i * RW), m, rmask, imp);
+			KRec r = dec(rec_load<RW>(recs + (uint64_t)i * RW));
 			uint32_t z = r.h1; bool first = false, unresolved = false;
 			for (int j = 0; j < nh; ++j) {
 				uint32_t b = bloom_next(z, r.h2), fi;
@@ -2051,6 +2234,14 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	if (ev) hipEventRecord(ev[2], st);
 }
 
+// k_bloom<..., F3>: dec3_geom's conditions, on the host
+static inline bool bloom_fast3(const KParams &P)
+{
+	const int a = P.k - P.rec_n, up = P.rec_n ? P.rec_lo : P.bf_shift - 9, sh_x = P.k - (P.bf_shift - 9), sh_y1 = P.k - P.F;
+	return P.k >= P.bf_shift - 9 && P.bf_shift + 9 <= 2 * P.k && a >= 1 && a <= 31 && a + P.k >= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n <= 31)
+	       && up <= a && sh_x >= 0 && sh_x <= 31 && sh_y1 >= 0 && sh_y1 <= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n == P.bf_shift - 9) && P.R <= up && !getenv("BFCG_NO_FAST_BLOOM");
+}
+
 // a CU's LDS holds 160 KB / segment size workgroups: keep its 2048 lanes busy whatever that number is (c4's 64 KiB segments at 256
 // threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
 static void launch_commit_seg(const KParams &P, const BloomArgs &A, int nfine, hipStream_t st)
@@ -2111,7 +2302,10 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	} else if (P.seg && B.seg_tab && (B.stream_out || B.ho)) { // region-owned table segments: seen k-mers are handed to k_commit_seg, one workgroup per region
 		A.stream_out = B.stream_out; A.seg_tab = B.seg_tab; A.table = nullptr; A.agg_out = nullptr;
 		A.ho = B.ho; A.ho_stride = B.ho_stride; A.ho_cur = B.ho_cur; A.ho_mark = B.ho_stride ? B.ho_mark + (size_t)B.ho_page * B.ho_mark_stride : nullptr;
-		if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
+		bool f3 = false;
+		if constexpr (RW == 3) { if (P.n_hashes == 4 && bloom_fast3(P)) { f3 = true; hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>), dim3(nfine), dim3(512), lds, st, P, A); } }
+		if (f3) ;
+		else if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, false, true, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		if (ev) hipEventRecord(ev[4], st);
 		dbg_sync(st, "k_bloom");
@@ -2201,6 +2395,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
+	if constexpr (RW == 3) { e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; }
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
