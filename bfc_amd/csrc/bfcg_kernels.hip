@@ -1843,10 +1843,16 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	const SegGeom G = seg_geom(P);
 	// few k-mers for a large segment: touch their lines only (this workgroup alone owns the segment, the atomics order its own lanes)
 	const bool direct = (uint64_t)n * 16 < slots;
+	// Segments up to 2^12 slots keep a 32-bit counter pair per slot behind the segment in LDS: an occurrence of a key that is already there is ONE
+	// non-returning LDS add (calls | high-quality calls << 16) instead of a compare-and-swap loop on the slot -- hot keys no longer make their
+	// lanes retry -- and the counters are folded into the slots, saturating, before the segment goes back (htab.c:73-79 is order-free).
+	const bool use_cnt = !direct && P.seg_shift <= 12 && n < 65536u && !(P.ablate & 16);
+	unsigned int *lcnt = reinterpret_cast<unsigned int *>(lseg + slots);
 	if (!direct) {
 		const uint4 *src = reinterpret_cast<const uint4 *>(gseg);
 		uint4 *dst = reinterpret_cast<uint4 *>(lseg);
 		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
+		if (use_cnt) for (uint32_t i = threadIdx.x; i < slots; i += BT) lcnt[i] = 0;
 	}
 	uint32_t total_new = 0, beg = 0;
 	for (uint32_t pg = 0; pg < pages; ++pg) {
@@ -1858,7 +1864,19 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 			const unsigned long long v = recs[j];
 			const uint64_t id = v >> 1;
 			const uint32_t hi = (uint32_t)(v & 1);
-			const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
+			int r;
+			if (use_cnt) { // find or claim the slot; count in the counter pair
+				r = -1;
+				uint32_t p = seg_home(id) & mask;
+				for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
+					unsigned long long cur = lseg[p];
+					if (cur == 0) {
+						cur = atomicCAS(&lseg[p], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); // (the creating call is the slot's count 1)
+						if (cur == 0) { r = 1; break; }
+					}
+					if ((cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); r = 0; break; }
+				}
+			} else r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
 			if (r > 0) ++n_new;
 			else if (r < 0) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); }
 		}
@@ -1869,6 +1887,17 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 		total_new += pn;
 		if (threadIdx.x == 0 && pn && A.ho_keys) atomicAdd(&A.ho_keys[(size_t)pg * ST_SLOTS + (f & (ST_SLOTS - 1))], (unsigned long long)pn);
 		beg = end;
+	}
+	if (use_cnt) { // the counters into their slots (after the last page's barrier)
+		for (uint32_t i = threadIdx.x; i < slots; i += BT) {
+			const uint32_t c = lcnt[i];
+			if (c) {
+				const unsigned long long v = lseg[i];
+				const uint32_t nc = (uint32_t)(v & 0xff) + (c & 0xffffu), nh = (uint32_t)((v >> 8) & 0x3f) + (c >> 16);
+				lseg[i] = (v & ~0x3fffULL) | (nc < 255 ? nc : 255) | ((unsigned long long)(nh < 63 ? nh : 63) << 8);
+			}
+		}
+		__syncthreads();
 	}
 	if (!direct) {
 		uint4 *dst = reinterpret_cast<uint4 *>(gseg);
@@ -2247,8 +2276,8 @@ static inline bool bloom_fast3(const KParams &P)
 static void launch_commit_seg(const KParams &P, const BloomArgs &A, int nfine, hipStream_t st)
 {
 	if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
-	else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)8 << P.seg_shift, st, P, A);
-	else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)8 << P.seg_shift, st, P, A);
+	else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)12 << P.seg_shift, st, P, A); // (+ 4 bytes of counters per slot)
+	else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)12 << P.seg_shift, st, P, A);
 	dbg_sync(st, "k_commit_seg");
 }
 void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st)
