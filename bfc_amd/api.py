@@ -244,7 +244,7 @@ class GpuCounter:
     def count_dev(self, d_seq, d_qual, n_pos):
         self._ck(self.L.bfcg_count_batch_dev(self.ctx, d_seq, d_qual, n_pos))
 
-    # ---- multi-GPU stages (owner computes); the exchange between them lives in bfc_amd/dist.py
+    # ---- multi-GPU stages (owner computes): what bfcg_group_* drives from inside the library; exposed for tests (tests/mg_protocol.py)
     def mg_info(self):
         out = (C.c_int * 4)()
         self.L.bfcg_mg_info(self.ctx, out)

@@ -5,8 +5,8 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r2_bench_final.json 2> gpurun_out/r2_bench_final.log; echo bench rc=$?
 PMC=2 STEPS=1 bash scripts/prof_round2.sh c3 > gpurun_out/prof_c3.out 2>&1; tail -3 gpurun_out/prof_c3.out | cut -c1-200
 PMC=2 STEPS=3 BENCH_ARGS="--workload c2" bash scripts/prof_round2.sh c2 > gpurun_out/prof_c2.out 2>&1; tail -3 gpurun_out/prof_c2.out | cut -c1-200
-python tools/make_round2_md.py gpurun_out/prof_c3 c3 > gpurun_out/round2_c3.md; cp profiles/round2_c3_pmc.json gpurun_out/
-python tools/make_round2_md.py gpurun_out/prof_c2 c2 > gpurun_out/round2_c2.md; cp profiles/round2_c2_pmc.json gpurun_out/
+python tools/make_round_md.py gpurun_out/prof_c3 c3 > gpurun_out/round2_c3.md; cp profiles/round2_c3_pmc.json gpurun_out/
+python tools/make_round_md.py gpurun_out/prof_c2 c2 > gpurun_out/round2_c2.md; cp profiles/round2_c2_pmc.json gpurun_out/
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/r2_bench_final.json'))

@@ -1,7 +1,9 @@
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, bfc_amd
-from bfc_amd import gen, dist as bdist
+from bfc_amd import gen
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import mg_protocol as bdist
 # the overloaded case of scripts/mg_load.py (N ranks, filter fixed at -b33) with stage B in source groups
 N, br = int(sys.argv[1]), 786432
 cl = bdist.LocalCluster(bfc_amd, N, 31, 33, br * 151)

@@ -5,7 +5,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bfc_amd
-from bfc_amd import gen, dist as bdist
+from bfc_amd import gen
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import mg_protocol as bdist
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 br = 786432

@@ -8,7 +8,9 @@ torch.cuda.set_device(local)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 import bfc_amd
-from bfc_amd import gen, dist as bdist
+from bfc_amd import gen
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import mg_protocol as bdist
 rs = gen.ReadSet(seed=2 + rank, G=4_600_000, cov=100)
 seq, qual, off = rs.reads()
 s_seq, s_qual = bfc_amd.to_stream(seq, off), bfc_amd.to_stream(qual, off)

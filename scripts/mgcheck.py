@@ -1,8 +1,11 @@
+import os
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bfc_amd
-from bfc_amd import gen, dist as bdist
+from bfc_amd import gen
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import mg_protocol as bdist
 rs = gen.fixture("g42"); seq, qual, off = rs.reads()
 n = rs.n_reads
 for N in (1, 2):

@@ -2,13 +2,13 @@
 # (pipelined, as benchmarked), a trace with BFCG_SYNC_BATCHES=1 (one batch at a time, no kernel overlap) so that durations can be
 # attributed to single kernels, and -- with PMC=1 -- counter passes of that serial run (counters in their own runs, never combined
 # with other trace domains).  Always under `timeout`: a rocprofv3 run once hung after finishing.
-#   bash scripts/prof_round2.sh [tag] ; summaries: python tools/make_round2_md.py gpurun_out/prof_<tag>
+#   bash scripts/prof_round2.sh [tag] ; summaries: python tools/make_round_md.py gpurun_out/prof_<tag>
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r2}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-verify --no-secondary ${BENCH_ARGS:-}"
+CMD="python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-boundary ${BENCH_ARGS:-}"
 run() { name=$1; shift; timeout -k 5 ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace "$@" -d $OUT/$name -o p -- $CMD > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run trace --stats
 export BFCG_SYNC_BATCHES=1

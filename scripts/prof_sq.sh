@@ -4,7 +4,7 @@ TAG=${1:-sq}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp BFCG_SYNC_BATCHES=1
-CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-secondary ${BENCH_ARGS:-}"
+CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-boundary ${BENCH_ARGS:-}"
 run() { name=$1; shift; timeout -k 5 ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace "$@" -d $OUT/$name -o p -- $CMD > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU
 run sq2 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INSTS_VMEM_WR

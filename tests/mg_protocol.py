@@ -1,4 +1,7 @@
-"""Multi-GPU orchestration: owner-computes partition of the k-mer counting path.
+"""TEST INFRASTRUCTURE (not part of the product: libbfc_gpu.so exchanges its records itself, bfc_amd/csrc/bfcg_mg.hip).
+A Python restatement of the multi-GPU PROTOCOL -- the owner-computes partition of the k-mer counting path -- over
+torch.distributed, so that the protocol (who sends what to whom, in which order the owner applies it) can be pinned with a real all-to-all
+on CPUs (gloo, world size 2, an oracle-based engine: tests/test_multi_rank.py) and with ranks emulated on one device (LocalCluster).
 
 One process per GPU.  Rank r owns 1/N of the bloom regions (contiguous level-1 buckets) and every k-mer that falls
 into them, hence also a disjoint part of the count table.  Per global batch:

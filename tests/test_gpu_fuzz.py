@@ -116,7 +116,7 @@ def test_random_configuration_on_emulated_ranks(gpu_lib, seed, base, monkeypatch
     """the same draws through the multi-GPU stages: 2 / 4 / 8 ranks emulated on one device (LocalCluster), ragged rank shares, ranks
     with nothing to contribute; global batches in rank-major order must equal the sequential oracle.  Seed base 21 is part of the suite: its
     draws found round 2's last bug (a one-pass level 2 replayed from a receive buffer the harness had reused)."""
-    from bfc_amd import dist as bdist
+    import mg_protocol as bdist
     if base:
         monkeypatch.setattr(sys.modules[__name__], "SEED_BASE", SEED_BASE + base)
     prm, seq, qual, off, cuts, kw = _draw(5000 + seed, scale=int(os.environ.get("BFC_FUZZ_RANK_SCALE", "1")))  # 40: the medium-size draws through the rank stages

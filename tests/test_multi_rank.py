@@ -1,5 +1,7 @@
-"""Multi-rank path.  CPU (-m "not gpu"): world_size-2 gloo run of the real exchange code with an oracle-based engine.
-GPU (-m gpu): N ranks emulated on one device (LocalCluster) through the real stage A / stage B kernels."""
+"""Multi-rank PROTOCOL (tests/mg_protocol.py: a Python restatement of the owner-computes exchange, test infrastructure -- the product's
+exchange is C, bfc_amd/csrc/bfcg_mg.hip, covered by tests/test_gpu_group.py).  CPU (-m "not gpu"): a world_size-2 gloo run of that
+exchange with an oracle-based engine pins WHAT is exchanged and in which order the owner applies it.  GPU (-m gpu): N ranks emulated
+on one device (LocalCluster) through the library's real stage A / stage B kernels."""
 import os
 import sys
 
@@ -32,7 +34,7 @@ def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    from bfc_amd import dist as bdist
+    import mg_protocol as bdist
     from mg_cpu_engine import CpuEngine
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     rs = gen.ReadSet(seed=11, G=20000, cov=6)
@@ -73,7 +75,7 @@ def test_gloo_two_ranks_equal_sequential(tmp_path):
 def test_local_cluster_matches_reference_goldens(gpu_lib, g1, n_ranks, k, b):
     """N ranks on one device through the real kernels: bitmap slices concatenate to the sequential bitmap (L0) and the
     union of the per-rank tables is L1-identical to `bfc -t1` (goldens / oracle)."""
-    from bfc_amd import dist as bdist
+    import mg_protocol as bdist
     rs, (seq, qual, off) = g1
     n = 3000 if k != 33 else rs.n_reads
     seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
@@ -99,7 +101,7 @@ def test_local_cluster_source_groups(gpu_lib, g1, n_ranks, limit):
     """A rank that receives more k-mers of a global batch than its regions take at full speed runs stage B once per group of sources
     (dist.process_in_groups; limit 1 = one group per source): rank-major order is file order, so filter, statistics and table are still
     those of the sequential oracle."""
-    from bfc_amd import dist as bdist
+    import mg_protocol as bdist
     rs, (seq, qual, off) = g1
     n, k, b = rs.n_reads, 31, 28
     cl = bdist.LocalCluster(gpu_lib, n_ranks, k, b, max_batch_pos=(n // 2 + 64) * (rs.L + 1), kmer_limit=limit)
@@ -120,7 +122,7 @@ def test_local_cluster_source_groups(gpu_lib, g1, n_ranks, limit):
 @pytest.mark.gpu
 def test_local_cluster_stream_mode(gpu_lib):
     """Emulated ranks on batches whose k-mers hardly repeat: every rank's context switches to the STREAM hand-over; still the oracle's result."""
-    from bfc_amd import dist as bdist
+    import mg_protocol as bdist
     rs = gen.ReadSet(seed=11, G=2_000_000, cov=9)
     seq, qual, off = rs.reads()
     n, k, b, world = rs.n_reads, 33, 28, 4
@@ -144,7 +146,7 @@ def test_local_cluster_stream_mode(gpu_lib):
 def test_local_cluster_exact_dump(gpu_lib, g1, n_ranks, tmp_path):
     """Parity level L2 across GPUs: with order stamps the union of the ranks' tables (bfc_ch_union) dumps to the very bytes of
     `bfc -E -t1 -d` (md5 golden from the reference binary, g1 / k=31 / -b26)."""
-    from bfc_amd import dist as bdist
+    import mg_protocol as bdist
     rs, (seq, qual, off) = g1
     n = rs.n_reads
     cl = bdist.LocalCluster(gpu_lib, n_ranks, 31, 26, max_batch_pos=(n // 3 + 64) * (rs.L + 1), track_order=True)

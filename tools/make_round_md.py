@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a scripts/prof_round2.sh capture (rocprofv3 rocpd databases of `python bench.py`) for profiles/:
 
-    python tools/make_round2_md.py gpurun_out/prof_<tag> <workload> > profiles/round2_<workload>.md   (also writes profiles/round2_<workload>_pmc.json)
+    python tools/make_round_md.py gpurun_out/prof_<tag> <workload> > profiles/round2_<workload>.md   (also writes profiles/round2_<workload>_pmc.json)
 
 The json is what bench.py reads for `roofline.traffic`: HBM bytes per launch of every stage (FETCH_SIZE x 2 + WRITE_SIZE, the
 gfx950 correction of MI355X_MICROARCH.md; counters in KiB) with the build id of the library the counters were measured on."""
@@ -9,10 +9,12 @@ import json
 import os
 import sys
 
+ROUND = os.environ.get("ROUND", "3")
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_profile_md import kernel_rows, pmc_rows, short  # noqa: E402
 
-STAGE = {"k_hist1": "hist1", "k_colsum": "hist1", "k_scan_top": "hist1", "k_apply": "hist1", "k_scatter1": "scatter1",
+STAGE = {"k_seg_setup": "scatter1", "k_hist1": "hist1", "k_colsum": "hist1", "k_scan_top": "hist1", "k_apply": "hist1", "k_scatter1": "scatter1",
          "k_hist2": "level2", "k_scan2": "level2", "k_scatter2": "level2", "k_bloom": "bloom",
          "k_commit": "commit", "k_commit_stream": "commit", "k_commit_seg": "commit"}
 
@@ -36,7 +38,7 @@ def table(rows):
 
 def main(d, workload):
     j = bench_line(os.path.join(d, "trace.log"))
-    print("# Round 2 -- bench.py (workload %s) on one MI355X under rocprofv3\n" % workload)
+    print("# Round %s -- bench.py (workload %s) on one MI355X under rocprofv3\n" % (ROUND, workload))
     print("Command: `python bench.py --steps %d --warmup %d --no-cpu-baseline --no-verify --no-secondary` under `rocprofv3 --kernel-trace --stats` (scripts/prof_round2.sh)." % (j["steps"], j["warmup"]))
     print("Library build: `%s`.  Workload: %s\n" % (j.get("build_id"), j["config"]["workload"]))
     print("## As benchmarked: %.1f %s, %.3f ms/step; stage ms/step (HIP events inside the library) %s\n" % (j["value"], j["unit"], j["ms_per_step"], json.dumps(j["config"]["stage_ms_per_step"])))
@@ -81,7 +83,7 @@ def main(d, workload):
     out = {"workload": workload, "build_id": jp.get("build_id"), "batches": n_batches, "kmers_per_launch": jp["roofline"].get("kmers_per_launch"),
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes of `python bench.py`, BFCG_SYNC_BATCHES=1; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
            "stages": stages}
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round2_%s_pmc.json" % workload), "w") as f:
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round%s_%s_pmc.json" % (ROUND, workload)), "w") as f:
         json.dump(out, f, indent=1)
     print("\nPer batch and stage (what bench.py reports as `traffic`): " + ", ".join("%s %.2f GB" % (k, v["hbm_bytes_per_launch"] / 1e9) for k, v in stages.items()))
 
