@@ -537,6 +537,11 @@ static int replay_poisoned(bfcg_ctx_t *c)
 	bfcg_ctx::opq_t q[4];
 	for (int i = 0; i < n; ++i) q[i] = c->opq[i];
 	c->n_opq = 0; c->onepass = 0; c->mg_op2 = 0;
+	if (getenv("BFCG_DEBUG")) {
+		uint32_t fl[OP_FLAG_WORDS];
+		HIPCK(hipMemcpy(fl, c->op_flags, sizeof(fl), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[D::replay] %d batches; flags (level-1 slab, -, region slab, -) of slot 0: %u %u %u %u, slot 1: %u %u %u %u, sticky %u\n", n, fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], fl[6], fl[7], fl[OP_STICKY]);
+	}
 	HIPCK(hipMemset(c->op_flags, 0, OP_FLAG_WORDS * sizeof(uint32_t)));
 	if (fetch_stats(c) != 0) return -1;
 	c->n_batches -= (uint64_t)n; // the batches keep their places in the count (order stamps carry the batch number)

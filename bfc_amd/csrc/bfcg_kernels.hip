@@ -529,12 +529,26 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 	// of the persistent grid draw tiles from a counter (behind the cursors) -- a workgroup that becomes resident late, because the previous
 	// kernel still held its CU, then simply draws fewer; with a fixed deal such stragglers cost 50 -> 70 ms per c3 step.  The draw for the
 	// tile after the next rides with the cursors' atomics, so that it is known when its bases are to be requested.
+	// A tile BELONGS to an XCD (tile & 7: the slabs its records go to), one counter per XCD; a workgroup draws from its own XCD's counter and,
+	// once that has run out, from the others' -- a slab's load is then the eighth of the batch it was sized for whatever the XCDs' speeds
+	// (one counter for all, slabs by the drawing workgroup's XCD: with 64 KiB table segments being committed on the other stream the XCDs'
+	// shares of c4's batches differed by more than the slabs' margin, and a batch that overflows a slab sends the whole run to two passes).
 	__shared__ uint32_t s_draw[3];
 	uint32_t *const tile_ctr = ONEPASS ? OP.cursor + (size_t)8 * nb1 * 32 : nullptr;
+	uint32_t draw_a = 0; // (thread 0) XCDs whose counters this workgroup has found exhausted, counted from its own
+	auto draw_issue = [&]() -> uint32_t { return draw_a < 8u ? atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u) : 0u; };
+	auto draw_settle = [&](uint32_t t) -> uint32_t {
+		while (draw_a < 8u) {
+			const uint32_t x = (blockIdx.x + draw_a) & 7u;
+			if ((int64_t)t * 8 + x < n_tiles) return t * 8u + x;
+			if (++draw_a < 8u) t = atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u);
+		}
+		return 0xffffffffu;
+	};
 	int64_t it = blockIdx.x;
 	int64_t tile, next_tile, next_it = 0;
 	if (ONEPASS) {
-		if (threadIdx.x == 0) { s_draw[0] = atomicAdd(tile_ctr, 1u); s_draw[1] = atomicAdd(tile_ctr, 1u); }
+		if (threadIdx.x == 0) { s_draw[0] = draw_settle(draw_issue()); s_draw[1] = draw_settle(draw_issue()); }
 		__syncthreads();
 		tile = s_draw[0]; next_tile = s_draw[1];
 	} else { tile = xcd_tile(it, n_tiles); next_it = it + gridDim.x; next_tile = xcd_tile(next_it, n_tiles); }
@@ -583,9 +597,9 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 		__syncthreads();
 		constexpr int NBT = (BFCG_MAXB + BT - 1) / BT; // buckets per thread
 		uint32_t gd[NBT], g_ex[NBT], g_c[NBT]; // (one-pass: gd holds the cursor's answer until the records are staged)
-		const uint32_t xcd = blockIdx.x & 7u; // (the XCD this workgroup runs on: its slabs)
+		const uint32_t xcd = (uint32_t)tile & 7u; // (the XCD this tile belongs to -- this workgroup's own but for the last few: its slabs)
 		uint32_t draw = 0;
-		if (ONEPASS && threadIdx.x == 0) draw = atomicAdd(tile_ctr, 1u);
+		if (ONEPASS && threadIdx.x == 0) draw = draw_issue();
 #pragma unroll
 		for (int u = 0; u < NBT; ++u) {
 			const int i = threadIdx.x + u * BT;
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 				}
 			}
 		}
-		if (ONEPASS && threadIdx.x == 0) s_draw[2] = draw;
+		if (ONEPASS && threadIdx.x == 0) s_draw[2] = draw_settle(draw);
 		if (next_tile < n_tiles) make_planes(next_tile, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
 		__syncthreads();
 		for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0; // (the offsets have served: counters of the next tile)

@@ -21,6 +21,7 @@ ap.add_argument("--batch-reads", type=int, default=4194304)
 ap.add_argument("--filter-mode", type=int, default=0)
 ap.add_argument("--trim", type=int, default=0, help="1 (with --filter-mode 1): then the trim pass of bfc -1 over the same reads (bloom query kernel + longest streak)")
 ap.add_argument("--export", type=int, default=0, help="1 (table mode): bring the count table to the host as bfc_count does and check it there (bfc_ch_count, bfc_ch_hist)")
+ap.add_argument("--per-batch", type=int, default=0, help="1: stage times of the last finalised library batch after every call")
 ap.add_argument("--popcount", type=int, default=0, help="1: bring the filter(s) to the host and count their bits")
 args = ap.parse_args()
 K = args.k
@@ -63,6 +64,8 @@ for r0 in range(0, n_reads, br):
     s, q, nk = cur
     g.count_host(s, q)
     n_kmers += nk; nb += 1
+    if args.per_batch:
+        print("[c4] call %d: last batch %s %s" % (nb, {k_: round(v, 1) for k_, v in g.last_batch_ms().items()}, g.partition_info()), flush=True)
     if th:
         th.join(); cur = nxt["v"]
     if nb % 16 == 0:
@@ -74,7 +77,7 @@ st = g.stats()
 ms, nbt = g.stage_ms()
 assert st["n_kmers"] == n_kmers, (st["n_kmers"], n_kmers)
 res = dict(config="c5 (bfc -1 count pass)" if args.filter_mode else "c4", k=K, b=args.b, reads=n_reads, batch_reads=br, batches=nbt, n_kmers=n_kmers, n_seen=st["n_seen"], n_keys=st["n_keys"],
-           slow_buckets=st["slow_buckets"], tab_cshift=st["tab_cshift"], wall_s_generator_bound=round(wall, 1), gpu_stage_ms={k_: round(v, 1) for k_, v in ms.items()},
+           slow_buckets=st["slow_buckets"], partition=g.partition_info(), tab_cshift=st["tab_cshift"], wall_s_generator_bound=round(wall, 1), gpu_stage_ms={k_: round(v, 1) for k_, v in ms.items()},
            gpu_s=round(ms["total"] / 1e3, 2), G_kmers_per_gpu_s=round(n_kmers / ms["total"] / 1e6, 2), bloom_frac=round(128 * n_kmers / (ms["bloom"] * 1e-3) / 1e9 / 8000, 4))
 if args.popcount:
     import oracle

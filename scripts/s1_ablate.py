@@ -6,7 +6,8 @@ import bfc_amd
 from bfc_amd import gen
 rs = gen.ReadSet(seed=3, G=248_000_000, cov=30.0)
 BR = int(os.environ.get("BR", 3670016))
-g = bfc_amd.GpuCounter(33, 35, max_batch_pos=BR * 151)
+B = int(os.environ.get("B", 35))
+g = bfc_amd.GpuCounter(33, B, max_batch_pos=BR * 151)
 seq, qual, _ = rs.reads(0, BR)
 s, q = gen.to_stream(seq, rs.L, 10), gen.to_stream(qual, rs.L, 33)
 d_s, d_q = g.dev_alloc(len(s)), g.dev_alloc(len(q))
@@ -16,7 +17,7 @@ for rep in range(3):
         g.count_dev(d_s, d_q, len(s)); g.sync()
     except Exception as e:  # noqa: BLE001  (ablated runs leave garbage behind: only stage A's time is of interest)
         print("(", str(e)[:80], ")")
-    print("ablate", os.environ.get("BFCG_ABLATE", "0"), "scatter1 ms:", round(g.last_batch_ms()["scatter1"], 3), flush=True)
+    print("b", B, "ablate", os.environ.get("BFCG_ABLATE", "0"), "scatter1 ms:", round(g.last_batch_ms()["scatter1"], 3), flush=True)
     try:
         g.reset()
     except Exception:  # noqa: BLE001
