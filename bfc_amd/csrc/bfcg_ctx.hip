@@ -254,7 +254,11 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		c->op_min_pos = (e = getenv("BFCG_ONEPASS_MIN_TILES")) ? (uint64_t)atoi(e) * 4096 : (uint64_t)nb1 * 8 * 1024;
 	}
 	const uint64_t recs1_n = c->onepass_ok ? (uint64_t)c->op_cap * nb1 * 8 : B.max_kmers;
-	for (int b = 0; b < 2; ++b) HIPCKN(hipMalloc(&c->recs1[b], recs1_n * c->rw));
+	// (batches above 2^28 positions run on ONE stream -- c->pipeline -- so stage A of a batch never runs beside stage B of the one before: both
+	// slots share one level-1 buffer there, which leaves config c4 34 GB more for the hand-over log and the table's growth)
+	HIPCKN(hipMalloc(&c->recs1[0], recs1_n * c->rw));
+	if (n_ranks == 1 && !c->pipeline) c->recs1[1] = c->recs1[0];
+	else HIPCKN(hipMalloc(&c->recs1[1], recs1_n * c->rw));
 	{ // a rank of a multi-GPU run partitions what it RECEIVES in one pass (level 2 is the owner's own stage B; level 1 feeds the exchange and stays two-pass)
 		const char *e = getenv("BFCG_ONEPASS");
 		c->mg_op2_ok = P.F2 > 0 && !(e && atoi(e) == 0); // (also the single rank of a group of one: bench.py with BFC_BENCH_FORCE_DIST, tests)
@@ -304,7 +308,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 			if (!c->cap2) K = 1;
 			size_t free_b = 0, total_b = 0;
 			const uint64_t page = (uint64_t)nfine * (c->cap2 ? c->cap2 : 1) * 8;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) while (K > 1 && page * (uint64_t)K > (uint64_t)free_b / 4) --K; // (a quarter of what is free, at most)
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) while (K > 1 && page * (uint64_t)K > (uint64_t)free_b / 3) --K; // (a third of what is free, at most: the segments grow into the rest)
 			c->ho_K = K;
 			c->ho_stride = c->cap2 ? (uint32_t)K * c->cap2 : 0u;
 			uint64_t entries = (uint64_t)nfine * c->ho_stride;
@@ -352,7 +356,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	if (!c) return;
 	(void)hipSetDevice(c->prm.device);
 	(void)hipDeviceSynchronize();
-	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
+	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); if (b == 0 || c->recs1[1] != c->recs1[0]) (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);

@@ -411,7 +411,13 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t *cnt, int nb, uint3
 // which only stage B's stream ever touches, turns every batch behind it into a no-op as well) and the host replays those batches through the
 // two-pass partition (bfcg_ctx.hip: replay_poisoned).  The flags are per slot because stage A of batch t+1 runs beside stage B of batch t:
 // an overflow of t+1 must not be seen by the kernels of the clean batch t.
-struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; };
+// Round 3: room is reserved in CHUNKS.  Device-scope atomics on this chip are executed at the memory side, not in the XCD's L2 (TCC_EA0_ATOMIC
+// = TCC_ATOMIC), and they share that path with the records' stores: with 2^10 buckets -- runs of ~3 records, one atomic each -- config c4's
+// level 1 ran at 20 ps per position against 5 without the stores or without the atomics.  A workgroup therefore keeps, per bucket, what is left
+// of the chunk it reserved last (thread-private: a thread owns its buckets for the kernel's life); a run goes there first and the rest into
+// a new chunk of max(chunk, rest) records, so a run is at most two pieces and a slab has no holes except the workgroups' last chunks, which
+// are filled with DEAD records (all ones: no file index is 2^32-1) that level 2 skips.  chunk <= 1: every run reserves exactly its size.
+struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; uint32_t chunk; };
 
 // A 12-byte record from halves without 64-bit shifts (same bits as Rec<3>::pack): possible when the kept part of y0 fits one word
 // (0 < a = k - rec_n < 32), the dropped field ends below bit 32, and y1 reaches into the second word (a + k >= 32)
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 	__shared__ uint32_t s_total;
 	const int nb1 = 1 << P.F1;
 	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem1 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *gdelta = cnt + nb1; // 2 x nb1 counters behind the stage
+	uint32_t *gdelta_b = gdelta + nb1, *splitp = gdelta_b + nb1; // (one pass: a run's second piece, and the staged position where it begins)
 	__shared__ uint32_t wsum1[BT / WAVE];
 	const W m = kmask<W>(P.k);
 	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
@@ -554,6 +561,11 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 	} else { tile = xcd_tile(it, n_tiles); next_it = it + gridDim.x; next_tile = xcd_tile(next_it, n_tiles); }
 	if (tile >= n_tiles) return;
 	int cur = 0;
+	constexpr int NBT = (BFCG_MAXB + BT - 1) / BT; // buckets per thread
+	const uint32_t home = blockIdx.x & 7u;         // this workgroup's own slabs (its XCD's)
+	uint32_t c_ptr[NBT], c_rem[NBT];               // what is left of the chunks this thread's buckets reserved last in the home slabs
+#pragma unroll
+	for (int u = 0; u < NBT; ++u) { c_ptr[u] = 0; c_rem[u] = 0; }
 	for (int i = threadIdx.x; i < nb1; i += BT) cnt[i] = 0;
 	prefetch(tile);
 	make_planes(tile, planes);
@@ -595,9 +607,9 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 		const uint32_t tot = block_scan_excl<BT>(cnt, nb1, wsum1);
 		if (threadIdx.x == 0) s_total = tot;
 		__syncthreads();
-		constexpr int NBT = (BFCG_MAXB + BT - 1) / BT; // buckets per thread
 		uint32_t gd[NBT], g_ex[NBT], g_c[NBT]; // (one-pass: gd holds the cursor's answer until the records are staged)
 		const uint32_t xcd = (uint32_t)tile & 7u; // (the XCD this tile belongs to -- this workgroup's own but for the last few: its slabs)
+		const bool own = xcd == home;             // (a tile taken from another XCD's share reserves exactly, in that XCD's slabs)
 		uint32_t draw = 0;
 		if (ONEPASS && threadIdx.x == 0) draw = draw_issue();
 #pragma unroll
@@ -609,7 +621,11 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 				if (!ONEPASS) gd[u] = rows1[tile * nb1 + i]; // global record index = staged position + gdelta[bucket] (u32 modular)
 				else {
 					g_c[u] = (i + 1 < nb1 ? cnt[i + 1] : tot) - g_ex[u];
-					if (g_c[u] && !(P.ablate & 1024)) gd[u] = atomicAdd(&OP.cursor[((size_t)xcd * nb1 + i) * 32], g_c[u]);
+					const uint32_t left = own ? c_rem[u] : 0u;
+					if (g_c[u] > left && !(P.ablate & 1024)) {
+						const uint32_t need = g_c[u] - left;
+						gd[u] = atomicAdd(&OP.cursor[((size_t)xcd * nb1 + i) * 32], own && OP.chunk > need ? OP.chunk : need);
+					}
 				}
 			}
 		}
@@ -629,9 +645,17 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 			if (i < nb1) {
 				if (!ONEPASS) gdelta[i] = gd[u] - g_ex[u];
 				else {
-					uint32_t base = gd[u];
-					if (base + g_c[u] > OP.cap) { OP.flags[0] = 1; base = 0; } // the slab is full: this batch will be replayed; meanwhile write where it does no harm
-					gdelta[i] = ((uint32_t)i * 8u + xcd) * OP.cap + base - g_ex[u];
+					const uint32_t slab = ((uint32_t)i * 8u + xcd) * OP.cap, left = own ? c_rem[u] : 0u;
+					gdelta[i] = slab + c_ptr[u] - g_ex[u]; // (first piece: what the last chunk still holds; unused when left == 0)
+					if (g_c[u] <= left) { splitp[i] = 0xffffffffu; c_ptr[u] += g_c[u]; c_rem[u] -= g_c[u]; }
+					else {
+						const uint32_t need = g_c[u] - left, sz = own && OP.chunk > need ? OP.chunk : need;
+						uint32_t base = gd[u];
+						if (base + sz > OP.cap) { OP.flags[0] = 1; base = 0; } // the slab is full: this batch will be replayed; meanwhile write where it does no harm
+						splitp[i] = g_ex[u] + left;
+						gdelta_b[i] = slab + base - (g_ex[u] + left);
+						if (own) { c_ptr[u] = base + need; c_rem[u] = sz - need; }
+					}
 				}
 			}
 		}
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 			if (IDX_BK) { b = rec.d[IDX_DW] >> 13; rec.d[IDX_DW] = P.idx_rank | ((uint32_t)(tile * TILE) + (rec.d[IDX_DW] & 0x1fffu)); }
 			else if (KEEP_BK) b = sbk[pos];
 			else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, RG, 0u, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) >> P.F2; } // (nothing dropped here)
-			const uint64_t dst = (uint32_t)(pos + gdelta[b]);
+			const uint64_t dst = (uint32_t)(pos + (ONEPASS && pos >= splitp[b] ? gdelta_b[b] : gdelta[b]));
 			if (!(P.ablate & 256)) rec_store<RW>(out + dst * RW, rec);
 		}
 		tile = next_tile; cur ^= 1;
@@ -657,6 +681,16 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 		else { it = next_it; next_it = it + gridDim.x; next_tile = xcd_tile(next_it, n_tiles); }
 		prefetch(next_tile); // requested behind this tile's stores, used a whole round later
 		__syncthreads(); // the stage, the counters and gdelta are free again only when every wave has copied its records out
+	}
+	if (ONEPASS) { // what is left of the last chunks: dead records
+		RecW<RW> dead;
+#pragma unroll
+		for (int t = 0; t < RW; ++t) dead.d[t] = 0xffffffffu;
+#pragma unroll
+		for (int u = 0; u < NBT; ++u) {
+			const int i = threadIdx.x + u * BT;
+			if (i < nb1) for (uint32_t r = 0; r < c_rem[u]; ++r) rec_store<RW>(out + ((uint64_t)((uint32_t)i * 8u + home) * OP.cap + c_ptr[u] + r) * RW, dead);
+		}
 	}
 	if (ONEPASS) { // the statistics k_hist1 keeps in the two-pass partition: k-mers, high-quality k-mers
 		for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
@@ -785,14 +819,18 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
 			w[j] = rec_load<RW>(in + i * RW);
-			Rec<RW>::unpack(w[j], RG, imp, y0, y1, idx, hi);
-			uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
-			br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+			if (!ONEPASS2 || w[j].d[RW - 1] != 0xffffffffu) { // (a dead record: what a level-1 workgroup left unused of its last chunk -- OnePass)
+				Rec<RW>::unpack(w[j], RG, imp, y0, y1, idx, hi);
+				uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
+				br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+			}
 		}
 	}
 	__syncthreads();
+	uint32_t n_live;
 	{ // bucket counters -> exclusive offsets inside the stage; gdelta = where the bucket's run goes in the output
 		const uint32_t tot = block_scan_excl<BT>(cnt, nb2, wsum2);
+		n_live = tot;
 		__syncthreads();
 		if (!ONEPASS2) {
 			for (int i = threadIdx.x; i < nb2; i += BT) gdelta[i] = rowp[i] - cnt[i]; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
@@ -820,7 +858,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		}
 	}
 	__syncthreads();
-	const uint32_t n_in = min((uint32_t)TILE, e - s - tile * TILE);
+	const uint32_t n_in = ONEPASS2 ? n_live : min((uint32_t)TILE, e - s - tile * TILE);
 	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
 		RecW<RW> rec;
 #pragma unroll
@@ -2238,7 +2276,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, T2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr});
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr, 0u});
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -2254,8 +2292,8 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	hipMemsetAsync(B.op_flags, 0, 4 * sizeof(uint32_t), st); // this slot's overflow flags (its previous batch's stage B and flag copy are complete: the caller waited)
 	if (ev) hipEventRecord(ev[1], st);
 	unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8);
-	const size_t lds1 = (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1;
-	const OnePass OP{B.op_cursor, B.op_cap, B.op_flags, B.stats};
+	const size_t lds1 = (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)16 * nb1;
+	OnePass OP{B.op_cursor, B.op_cap, B.op_flags, B.stats, 1u};
 	{ // as many workgroups as are resident at once (a CU's 160 KiB of LDS, at most 2048 threads), each walking its tiles; a multiple of 8 (XCDs)
 		static int n_cu = 0;
 		if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
@@ -2263,6 +2301,14 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 		const char *e = getenv("BFCG_S1_WGS"); if (e && atoi(e) > 0) per_cu = atoi(e);
 		const unsigned gp = (unsigned)(n_cu * per_cu) & ~7u;
 		if (gp >= 8 && gp < g1) g1 = gp;
+	}
+	if (B.cap2) { // chunked reservations leave dead records behind, which only the one-pass level 2 skips.  What the g1 / 8 workgroups of an XCD
+		// leave unused in a slab -- half a chunk each on average -- stays below a quarter of the slab's head room (a ninth of its capacity).
+		const char *e = getenv("BFCG_S1_CHUNK"); // (tests force chunk sizes on small draws)
+		const int forced = e ? atoi(e) : 0;
+		uint32_t ch = 32;
+		while (ch > 1 && (uint64_t)(g1 / 8) * (ch / 2) * 36 > B.op_cap) ch >>= 1;
+		OP.chunk = forced > 0 ? (uint32_t)forced : ch;
 	}
 	if constexpr (RW == 3) {
 		if (scatter1_fast(P)) {
@@ -2424,10 +2470,10 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	hipError_t e;
 	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
-	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 16 * BFCG_MAXB); if (e != hipSuccess) return e;
 	if constexpr (RW == 3) {
-		e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
-		e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 16 * BFCG_MAXB); if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 16 * BFCG_MAXB); if (e != hipSuccess) return e;
 	}
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;

@@ -227,7 +227,7 @@ class LocalCluster:
     def export_table(self):
         """The ranks' tables as ONE host table (bfc_ch_union); with track_order its dump is byte-identical to `bfc -t1 -d`."""
         import ctypes as C
-        from . import api
+        from bfc_amd import api
         parts = [c.export_table() for c in self.ctx]
         arr = (C.c_void_p * len(parts))(*[p.ptr for p in parts])
         u = api._lib.load().bfc_ch_union(arr, len(parts))

@@ -103,6 +103,18 @@ def test_random_configuration_one_pass_partition(gpu_lib, seed, monkeypatch):
     _check(gpu_lib, *_draw(40000 + seed, scale=12, b_range=(26, 32)))
 
 
+@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("chunk", [3, 32])
+def test_random_configuration_chunked_reservations(gpu_lib, seed, chunk, monkeypatch):
+    """level 1 of the one-pass partition reserves room in its slabs in CHUNKS (round 3: a run goes into what is left of the workgroup's last
+    chunk for that bucket and then into a new one; what the workgroups leave unused is filled with dead records that level 2 skips).  Forced
+    here on draws whose slabs expect a handful of records -- runs split at every chunk size, dead records in most slabs, slabs that overflow
+    because of them (replayed) -- against the oracle bit for bit, like every other draw."""
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    monkeypatch.setenv("BFCG_S1_CHUNK", str(chunk))
+    _check(gpu_lib, *_draw(45000 + seed, scale=12, b_range=(26, 32)))
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_medium_configuration(gpu_lib, seed):
     """the same draws at 40x the size (up to 60 000 reads, tens of millions of positions): many tiles per bucket, multi-chunk scans, full
