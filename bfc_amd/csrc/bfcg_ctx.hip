@@ -150,6 +150,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.F = P.bf_shift - 9 - P.R;
 		if (P.F <= 8) { P.F1 = P.F; P.F2 = 0; }
 		else { P.F2 = (P.F + 1) / 2; if (P.F2 > 10) P.F2 = 10; P.F1 = P.F - P.F2; }
+		if (P.F2 > 0 && (e = getenv("BFCG_F1"))) { // how the two levels share the F bits (profiles/round3_scatter_probe.txt: a 256-bucket level 1 is the cheaper skeleton)
+			const int f1 = atoi(e);
+			if (f1 >= 1 && f1 <= 10 && P.F - f1 >= 1 && P.F - f1 <= 10 && f1 >= log2n) { P.F1 = f1; P.F2 = P.F - f1; }
+		}
 		if (P.F1 > 10) { set_err("bf_shift=%d needs more than two scatter levels at region_shift=%d", P.bf_shift, P.R); free(c); return NULL; }
 		if (n_ranks > 1 && P.F2 == 0) { // with several ranks level 2 also gathers a bucket's records from the sources' blocks: it must exist
 			if (P.F <= log2n) { set_err("bf_shift=%d gives %d bloom regions: too few for %d ranks", P.bf_shift, 1 << P.F, n_ranks); free(c); return NULL; }

@@ -115,6 +115,18 @@ def test_random_configuration_chunked_reservations(gpu_lib, seed, chunk, monkeyp
     _check(gpu_lib, *_draw(45000 + seed, scale=12, b_range=(26, 32)))
 
 
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("f1", [2, 7, 10])
+def test_random_configuration_uneven_level_split(gpu_lib, seed, f1, monkeypatch):
+    """BFCG_F1 moves bits between the two scatter levels (2^F1 level-1 buckets x 2^(F-F1) regions per bucket; the library's own choice is
+    the even split, which the c3 A/B in profiles/round3_f1_split.txt found fastest).  Few fat buckets, many thin ones, through the one-pass
+    and the two-pass partition: the split is a tuning knob and must not change a bit of the filter, the statistics or the table."""
+    monkeypatch.setenv("BFCG_F1", str(f1))
+    if seed & 1:
+        monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    _check(gpu_lib, *_draw(47000 + seed, scale=8, b_range=(28, 34)))
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_medium_configuration(gpu_lib, seed):
     """the same draws at 40x the size (up to 60 000 reads, tens of millions of positions): many tiles per bucket, multi-chunk scans, full
