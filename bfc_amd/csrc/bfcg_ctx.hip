@@ -253,6 +253,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		c->onepass_ok = n_ranks == 1 && P.F2 > 0 && !(e && atoi(e) == 0); // level 2 gathers a bucket's slabs: filters of 2^26 bits and more
 		uint64_t cap = (B.max_kmers + B.max_kmers / 8) / ((uint64_t)nb1 * 8) + 1;
 		while (cap * nb1 * 8 > 0xffffffffULL) --cap;
+		{ const char *w = getenv("BFCG_S1_WC"); if (w && atoi(w) > 0 && cap >= 64) cap &= ~31ULL; } // k_scatter1_wc stores whole 16-byte pieces: slabs of whole lines
 		c->op_cap = (uint32_t)cap;
 		// a slab should expect ~1000 records or more: below that its fill scatters by more than the head room, and the batch would be replayed
 		c->op_min_pos = (e = getenv("BFCG_ONEPASS_MIN_TILES")) ? (uint64_t)atoi(e) * 4096 : (uint64_t)nb1 * 8 * 1024;

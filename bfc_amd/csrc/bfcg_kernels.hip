@@ -702,6 +702,176 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 }
 
 // ------------------------------------------------------------------------------------------
+// k_scatter1_wc (BFCG_S1_WC=1; round 3, opt-in): the one-pass level 1 for 12-byte records with WRITE-COMBINING buffers instead of the tile
+// skeleton above -- profiles/round3_scatter_probe.md is the stand-alone measurement this follows.  A buffer of CAP records per level-1
+// bucket lives in LDS across the workgroup's tiles; a record takes the slot a returning LDS add on the bucket's fill hands out; a buffer
+// that has filled leaves as CAP x 12 contiguous bytes into a chunk of the workgroup's home slab that the bucket's owner thread (thread b for
+// bucket b) reserved one flush AHEAD (same per-XCD cursors on lines of their own); a record whose slot is CAP or more waits for the flush
+// and takes slot - CAP (a loop for the round in which a bucket draws more than two buffers' worth).  Three barriers per tile, no scan, no
+// staging order; the last partial buffers leave padded with dead records, which the one-pass level 2 skips (as with chunked reservations).
+// All of a workgroup's records go to its HOME XCD's slabs, also those of tiles it took from another XCD's share.
+// Same input side as k_scatter1 (aligned 16-byte blocks a round ahead, bit planes in two sets, tiles drawn per XCD); FAST geometry only
+// (scatter1_fast: bucket = bit field of y0's low word, records packed from halves), slabs of a multiple of 32 records (bfcg_ctx.hip).
+template <int TILE, int BT, int CAP, int KC>
+__global__ __launch_bounds__(BT) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
+                                                     uint32_t *__restrict__ out, OnePass OP)
+{
+	constexpr int PW = (TILE + 64) / 32 + 2, S = TILE / BT, NC16 = (TILE + 64) / 16, NCH = NC16 + 1, PIECES = CAP * 12 / 16;
+	static_assert(S * BT == TILE && NCH <= BT && CAP % 4 == 0, "tile = threads x k-mers per thread; a buffer is whole 16-byte pieces");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
+	const int nb1 = 1 << P.F1; // <= BT: thread b owns bucket b
+	uint32_t *buf = reinterpret_cast<uint32_t *>(smem1);      // nb1 buffers of CAP records
+	uint32_t *fill = buf + (size_t)nb1 * CAP * 3;             // slots handed out per bucket (>= CAP: the buffer is due)
+	uint32_t *jobs = fill + nb1, *jpos = jobs + nb1;          // this round's flushes: bucket, chunk position in its slab
+	__shared__ uint32_t planes[2 * 4 * PW];
+	__shared__ uint32_t s_njobs, s_draw[3];
+	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
+	const int b1_shift = P.R + P.F2;
+	const Pack3 PK = pack3_geom(P);
+	uint32_t n_k = 0, n_h = 0;
+	const int tid = threadIdx.x;
+	// ---- the input side: as in k_scatter1
+	const int mis = (int)((uintptr_t)seq & 15);
+	const uint8_t *const sb = seq - mis, *const qb = qual ? qual - mis : nullptr;
+	const int64_t v_end = n_pos + mis, v_last = (v_end - 1) & ~(int64_t)15;
+	uint4 pf_s = make_uint4(0, 0, 0, 0), pf_q = make_uint4(0, 0, 0, 0);
+	const int pf_c = tid < NCH ? tid : NCH - 1;
+	auto prefetch = [&](int64_t t) {
+		const int64_t v = t * TILE - 64 + (int64_t)pf_c * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
+		pf_s = *reinterpret_cast<const uint4 *>(sb + at);
+		if (qual) pf_q = *reinterpret_cast<const uint4 *>(qb + at);
+	};
+	auto make_planes = [&](int64_t t, uint32_t *pl) {
+		const int c = tid;
+		if (c < NCH) {
+			const int64_t v = t * TILE - 64 + (int64_t)c * 16;
+			uint4 s4 = pf_s, q4 = pf_q;
+			if (v < mis || v + 16 > v_end) {
+				const int lo = v >= mis ? 0 : mis - v >= 16 ? 16 : (int)(mis - v), hi = v_end - v >= 16 ? 16 : v_end - v <= 0 ? 0 : (int)(v_end - v);
+				const uint32_t bm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+				auto keep = [&](int d) { return (((bm >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu; };
+				const uint32_t k0 = keep(0), k1 = keep(1), k2 = keep(2), k3 = keep(3);
+				s4.x = (s4.x & k0) | (0x0a0a0a0au & ~k0); s4.y = (s4.y & k1) | (0x0a0a0a0au & ~k1); s4.z = (s4.z & k2) | (0x0a0a0a0au & ~k2); s4.w = (s4.w & k3) | (0x0a0a0a0au & ~k3);
+				q4.x &= k0; q4.y &= k1; q4.z &= k2; q4.w &= k3;
+			}
+			uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
+			bases4x(s4.x, 0, m0, m1, mn); bases4x(s4.y, 4, m0, m1, mn); bases4x(s4.z, 8, m0, m1, mn); bases4x(s4.w, 12, m0, m1, mn);
+			if (qual) {
+				const int T = P.q + 33;
+				if (T >= 1 && T <= 127) {
+					const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
+					quals4x(q4.x, 0, add, mq); quals4x(q4.y, 4, add, mq); quals4x(q4.z, 8, add, mq); quals4x(q4.w, 12, add, mq);
+				} else { quals16(q4.x, 0, P.q, mq); quals16(q4.y, 4, P.q, mq); quals16(q4.z, 8, P.q, mq); quals16(q4.w, 12, P.q, mq); }
+			} else mq = 0xffffu;
+			unsigned short *p16 = reinterpret_cast<unsigned short *>(pl);
+			if (c < NC16) {
+				p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
+				p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
+			} else { pl[0 * PW + PW - 2] = m0; pl[1 * PW + PW - 2] = m1; pl[2 * PW + PW - 2] = mn; pl[3 * PW + PW - 2] = mq; }
+		}
+		if (tid < 4) pl[tid * PW + PW - 1] = 0;
+	};
+	uint32_t *const tile_ctr = OP.cursor + (size_t)8 * nb1 * 32;
+	uint32_t draw_a = 0;
+	auto draw_issue = [&]() -> uint32_t { return draw_a < 8u ? atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u) : 0u; };
+	auto draw_settle = [&](uint32_t t) -> uint32_t {
+		while (draw_a < 8u) {
+			const uint32_t x = (blockIdx.x + draw_a) & 7u;
+			if ((int64_t)t * 8 + x < n_tiles) return t * 8u + x;
+			if (++draw_a < 8u) t = atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u);
+		}
+		return 0xffffffffu;
+	};
+	if (tid == 0) { s_draw[0] = draw_settle(draw_issue()); s_draw[1] = draw_settle(draw_issue()); s_njobs = 0; }
+	if (tid < nb1) fill[tid] = 0;
+	__syncthreads();
+	int64_t tile = s_draw[0], next_tile = s_draw[1];
+	if (tile >= n_tiles) return;
+	// ---- the output side
+	const uint32_t home = blockIdx.x & 7u;
+	uint32_t *const my_cursor = OP.cursor + ((size_t)home * nb1 + (tid < nb1 ? tid : 0)) * 32;
+	uint32_t nextpos = tid < nb1 ? atomicAdd(my_cursor, (uint32_t)CAP) : 0u; // always one chunk ahead
+	RecW<3> w[S]; uint32_t sl[S]; int bk[S];
+	auto put = [&](int j) { uint32_t o = (uint32_t)bk[j] * CAP + sl[j]; o += o << 1; asm volatile("" : "+v"(o)); buf[o] = w[j].d[0]; buf[o + 1] = w[j].d[1]; buf[o + 2] = w[j].d[2]; };
+	auto copy_out = [&](uint32_t nj) {
+		for (uint32_t x = tid; x < nj * PIECES; x += BT) {
+			const uint32_t j = x / PIECES, p = x - j * PIECES, b = jobs[j];
+			reinterpret_cast<uint4 *>(out)[((uint64_t)(b * 8u + home) * OP.cap + jpos[j]) / 4 * 3 + p] = reinterpret_cast<const uint4 *>(buf)[b * PIECES + p];
+		}
+	};
+	auto claim = [&]() -> uint32_t { // (owner thread) the chunk reserved last; a full slab poisons the batch (replayed through two passes)
+		uint32_t at = nextpos;
+		if (at + CAP > OP.cap) { OP.flags[0] = 1; at = 0; }
+		return at;
+	};
+	auto flush = [&]() -> bool {
+		if (tid < nb1) {
+			const uint32_t f = fill[tid];
+			if (f >= CAP) {
+				const uint32_t j = atomicAdd(&s_njobs, 1u);
+				jobs[j] = tid; jpos[j] = claim(); fill[tid] = f - CAP;
+				nextpos = atomicAdd(my_cursor, (uint32_t)CAP);
+			}
+		}
+		__syncthreads();
+		copy_out(s_njobs);
+		__syncthreads();
+		if (tid == 0) s_njobs = 0;
+		bool still = false;
+#pragma unroll
+		for (int j = 0; j < S; ++j) if (bk[j] >= 0 && sl[j] >= CAP) { sl[j] -= CAP; if (sl[j] < CAP) { put(j); bk[j] = -1; } else still = true; }
+		return still;
+	};
+	int cur = 0;
+	prefetch(tile);
+	make_planes(tile, planes);
+	prefetch(next_tile);
+	__syncthreads();
+	for (;;) {
+		const uint32_t *pl = planes + cur * 4 * PW;
+		bool far = false;
+#pragma unroll
+		for (int j = 0; j < S; ++j) {
+			int r = j * BT + tid;
+			asm volatile("" : "+v"(r));
+			bool hi; U2 y0, y1;
+			bk[j] = -1; sl[j] = 0;
+			if (kmer_at2<TILE, KC>(pl, r + mis, P.k, y0, y1, hi)) {
+				bk[j] = (int)((y0.lo >> b1_shift) & (uint32_t)(nb1 - 1));
+				pack3_fast(w[j], PK, y0, y1, P.idx_rank | (uint32_t)(tile * TILE + r), hi);
+				sl[j] = atomicAdd(&fill[bk[j]], 1u);
+				++n_k; n_h += hi;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < S; ++j) if (bk[j] >= 0) { if (sl[j] < CAP) { put(j); bk[j] = -1; } else far |= sl[j] >= 2 * CAP; }
+		uint32_t draw = 0;
+		if (tid == 0) draw = draw_issue();
+		const int any_far = __syncthreads_or(far);
+		if (next_tile < n_tiles) make_planes(next_tile, planes + (cur ^ 1) * 4 * PW); // (this tile's planes have served; the next one's bases arrived a round ago)
+		bool still = flush();
+		if (any_far) while (__syncthreads_or(still)) still = flush();
+		if (tid == 0) s_draw[2] = draw_settle(draw);
+		tile = next_tile; cur ^= 1;
+		if (tile >= n_tiles) break;
+		__syncthreads();
+		next_tile = s_draw[2];
+		prefetch(next_tile);
+	}
+	// what the buffers still hold: each into the chunk reserved last, padded with dead records
+	__syncthreads();
+	for (uint32_t x = tid; x < (uint32_t)nb1 * CAP; x += BT) if (x % CAP >= fill[x / CAP]) { buf[x * 3] = 0xffffffffu; buf[x * 3 + 1] = 0xffffffffu; buf[x * 3 + 2] = 0xffffffffu; }
+	if (tid < nb1) { jobs[tid] = tid; jpos[tid] = claim(); }
+	__syncthreads();
+	copy_out((uint32_t)nb1);
+	for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
+	if ((tid & 63) == 0 && n_k) {
+		unsigned long long *sl2 = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+		atomicAdd(&sl2[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl2[ST_HIGH], (unsigned long long)n_h);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // level 2: one level-1 bucket (blockIdx.y) into its 2^F2 fine buckets, tiles of TILE records.
 // Histogram rows of bucket b1 live at rows2[row_base[b1] + tile][2^F2].
 
@@ -2310,7 +2480,31 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 		while (ch > 1 && (uint64_t)(g1 / 8) * (ch / 2) * 36 > B.op_cap) ch >>= 1;
 		OP.chunk = forced > 0 ? (uint32_t)forced : ch;
 	}
-	if constexpr (RW == 3) {
+	bool wc_done = false;
+	if constexpr (RW == 3 && sizeof(W) == 8) { // opt-in: level 1 with write-combining buffers (k_scatter1_wc)
+		const char *e = getenv("BFCG_S1_WC");
+		constexpr int WBT = 1024, WCAP = 16;
+		const size_t ldsw = (size_t)nb1 * WCAP * 12 + (size_t)12 * nb1;
+		if (e && atoi(e) > 0 && B.cap2 && scatter1_fast(P) && nb1 <= WBT && ldsw <= 150 * 1024 && (B.op_cap & 31u) == 0 && ((uintptr_t)out1 & 15) == 0 && !(P.ablate & 2048)) {
+			static int n_cu = 0;
+			if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+			const int per_cu = ldsw + 4400 <= 80 * 1024 ? 2 : 1;
+			unsigned gw = (unsigned)(((tiles1 + 7) / 8) * 8);
+			const unsigned gp = (unsigned)(n_cu * per_cu) & ~7u;
+			if (gp >= 8 && gp < gw) gw = gp;
+			if (atoi(e) >= 2) fprintf(stderr, "[bfcg] k_scatter1_wc: %d buckets x %d records, slabs of %u, %u workgroups, %lld positions\n", nb1, WCAP, B.op_cap, gw, (long long)n_pos);
+			if (P.k == 33) {
+				hipFuncSetAttribute((const void *)k_scatter1_wc<T1, WBT, WCAP, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); // (per device: every launch)
+				hipLaunchKernelGGL((k_scatter1_wc<T1, WBT, WCAP, 33>), dim3(gw), dim3(WBT), ldsw, st, P, seq, qual, n_pos, out1, OP);
+			} else {
+				hipFuncSetAttribute((const void *)k_scatter1_wc<T1, WBT, WCAP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+				hipLaunchKernelGGL((k_scatter1_wc<T1, WBT, WCAP, 0>), dim3(gw), dim3(WBT), ldsw, st, P, seq, qual, n_pos, out1, OP);
+			}
+			wc_done = true;
+		}
+	}
+	if (wc_done) {}
+	else if constexpr (RW == 3) {
 		if (scatter1_fast(P)) {
 			if (sizeof(W) == 8 && P.k == 33) hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
 			else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);

@@ -115,6 +115,19 @@ def test_random_configuration_chunked_reservations(gpu_lib, seed, chunk, monkeyp
     _check(gpu_lib, *_draw(45000 + seed, scale=12, b_range=(26, 32)))
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch):
+    """BFCG_S1_WC=1 (opt-in, round 3): level 1 of the one-pass partition through write-combining LDS buffers (k_scatter1_wc: 16-record chunks
+    per bucket, dead records padding every workgroup's last chunks, all of a workgroup's records in its home XCD's slabs) on draws with
+    k > 32 and 12-byte records, forced onto tiny slabs (overflows are replayed through two passes) -- bit for bit the oracle's filter,
+    statistics and table, like every other draw (k = 33 and 35 put onto the draws; where 35 needs 16-byte records the default kernels run)."""
+    monkeypatch.setenv("BFCG_S1_WC", os.environ.get("BFC_TEST_S1_WC", "1"))  # 2: the launcher says on stderr when the variant runs
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    prm, seq, qual, off, cuts, kw = _draw(48000 + seed, scale=12, b_range=(26, 33))
+    prm = dict(prm, k=35 if seed % 5 == 4 else 33)  # the geometries the variant serves (12-byte records need k <= 31 + F1 / 2)
+    _check(gpu_lib, prm, seq, qual, off, cuts, kw)
+
+
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("f1", [2, 7, 10])
 def test_random_configuration_uneven_level_split(gpu_lib, seed, f1, monkeypatch):
