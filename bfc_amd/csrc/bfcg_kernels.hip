@@ -717,7 +717,7 @@ __global__ __launch_bounds__(BT) void k_scatter1_wc(KParams P, const uint8_t *__
                                                      uint32_t *__restrict__ out, OnePass OP)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2, S = TILE / BT, NC16 = (TILE + 64) / 16, NCH = NC16 + 1, PIECES = CAP * 12 / 16;
-	static_assert(S * BT == TILE && NCH <= BT && CAP % 4 == 0, "tile = threads x k-mers per thread; a buffer is whole 16-byte pieces");
+	static_assert(S * BT == TILE && NCH <= BT / 2 && CAP % 4 == 0 && (BT / 2) % 64 == 0, "tile = threads x k-mers per thread; planes and owners in the lower half; a buffer is whole 16-byte pieces");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
 	const int nb1 = 1 << P.F1; // <= BT: thread b owns bucket b
 	uint32_t *buf = reinterpret_cast<uint32_t *>(smem1);      // nb1 buffers of CAP records
@@ -737,6 +737,7 @@ __global__ __launch_bounds__(BT) void k_scatter1_wc(KParams P, const uint8_t *__
 	uint4 pf_s = make_uint4(0, 0, 0, 0), pf_q = make_uint4(0, 0, 0, 0);
 	const int pf_c = tid < NCH ? tid : NCH - 1;
 	auto prefetch = [&](int64_t t) {
+		if (tid >= BT / 2) return; // (whole waves: the storing half holds no loads)
 		const int64_t v = t * TILE - 64 + (int64_t)pf_c * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
 		pf_s = *reinterpret_cast<const uint4 *>(sb + at);
 		if (qual) pf_q = *reinterpret_cast<const uint4 *>(qb + at);
@@ -793,8 +794,12 @@ __global__ __launch_bounds__(BT) void k_scatter1_wc(KParams P, const uint8_t *__
 	uint32_t nextpos = tid < nb1 ? atomicAdd(my_cursor, (uint32_t)CAP) : 0u; // always one chunk ahead
 	RecW<3> w[S]; uint32_t sl[S]; int bk[S];
 	auto put = [&](int j) { uint32_t o = (uint32_t)bk[j] * CAP + sl[j]; o += o << 1; asm volatile("" : "+v"(o)); buf[o] = w[j].d[0]; buf[o + 1] = w[j].d[1]; buf[o + 2] = w[j].d[2]; };
+	// Only the UPPER half of the workgroup stores: loads, atomics and stores share one in-order counter (vmcnt), and the lower half -- the
+	// buckets' owners and the threads that build the planes -- would otherwise wait for the previous round's stores whenever it waits for a
+	// prefetched block or a reserved chunk (+1.65 ms per c3 batch: profiles/round3_scatter_probe.md).  The storing waves never wait on memory.
+	constexpr int ST0 = BT / 2;
 	auto copy_out = [&](uint32_t nj) {
-		for (uint32_t x = tid; x < nj * PIECES; x += BT) {
+		if (tid >= ST0) for (uint32_t x = tid - ST0; x < nj * PIECES; x += BT - ST0) {
 			const uint32_t j = x / PIECES, p = x - j * PIECES, b = jobs[j];
 			reinterpret_cast<uint4 *>(out)[((uint64_t)(b * 8u + home) * OP.cap + jpos[j]) / 4 * 3 + p] = reinterpret_cast<const uint4 *>(buf)[b * PIECES + p];
 		}
@@ -2485,7 +2490,7 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 		const char *e = getenv("BFCG_S1_WC");
 		constexpr int WBT = 1024, WCAP = 16;
 		const size_t ldsw = (size_t)nb1 * WCAP * 12 + (size_t)12 * nb1;
-		if (e && atoi(e) > 0 && B.cap2 && scatter1_fast(P) && nb1 <= WBT && ldsw <= 150 * 1024 && (B.op_cap & 31u) == 0 && ((uintptr_t)out1 & 15) == 0 && !(P.ablate & 2048)) {
+		if (e && atoi(e) > 0 && B.cap2 && scatter1_fast(P) && nb1 <= WBT / 2 && ldsw <= 150 * 1024 && (B.op_cap & 31u) == 0 && ((uintptr_t)out1 & 15) == 0 && !(P.ablate & 2048)) {
 			static int n_cu = 0;
 			if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
 			const int per_cu = ldsw + 4400 <= 80 * 1024 ? 2 : 1;
