@@ -70,6 +70,7 @@ struct bfcg_ctx {
 	uint64_t seen_last, pos_final, slot_pos[2]; // seen k-mers at the last finalised batch; positions of the batch(es) finalised since; positions of a slot's batch
 	int pipeline;                // stage A of batch t+1 on its own stream under stage B of batch t
 	int seg_ok;                  // the geometry allows region-owned table segments (KParams.seg): every reset starts in that layout
+	int b3_ok;                   // ... and the bloom insert of batches without `dedupe` runs k_bloom3 (KParams.b3)
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
 	uint64_t n_seg_grow;         // segment growths since creation
@@ -159,12 +160,22 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 			if (P.F <= log2n) { set_err("bf_shift=%d gives %d bloom regions: too few for %d ranks", P.bf_shift, 1 << P.F, n_ranks); free(c); return NULL; }
 			P.F1 = (P.F + 1) / 2 > log2n ? (P.F + 1) / 2 : log2n; P.F2 = P.F - P.F1;
 		}
+#ifdef BFCG_MEASURE
 		P.ablate = (e = getenv("BFCG_ABLATE")) ? atoi(e) : 0;
+#else
+		P.ablate = 0; // (the measurement switches are not compiled into this library: bfcg_internal.h)
+		if ((e = getenv("BFCG_ABLATE")) && atoi(e)) fprintf(stderr, "[W::bfcg] BFCG_ABLATE=%s ignored: this library was built without -DBFCG_MEASURE\n", e);
+#endif
+		// records do not store the bits of y0 that their level-1 bucket implies (bfcg_kernels.hip: RecGeom) -- where the bucket IS a bit field of y0:
+		// k >= bf_shift - 9 (the bloom block id is the low bf_shift-9 bits of the hash, and those are y0's, kmer.h:87)
+		// -- and where it makes the record smaller (c3: k=33, 9 bucket bits: 12 instead of 16 bytes; c2's k=31 records are 12 bytes anyway)
+		{ const char *e = getenv("BFCG_REC_DROP"); P.rec_n = (P.k >= P.bf_shift - 9 && bfcg_rec_dwords(P.k, P.F1) < bfcg_rec_dwords(P.k, 0) && !(e && atoi(e) == 0)) ? P.F1 : 0; P.rec_lo = P.R + P.F2; }
+		c->rw = 4 * bfcg_rec_dwords(P.k, P.rec_n);
 		P.ag_cap = (e = getenv("BFCG_AG")) ? (uint32_t)atoi(e) : 256;
 		// LDS budget: a third of a CU (3 workgroups of 512 threads resident = 24 waves), else half, else all of it -- the first tier that
 		// leaves 16 KiB for the list and the first-setter table next to the region and the second slice / aggregation table
 		const size_t region = (size_t)64 << P.R;
-		const size_t rwb = 8; // list entry: file-order index + (record index | mask)
+		size_t rwb = 8; // list entry: file-order index + (record index | mask)
 		{ // region-owned table segments (bfcg_kernels.hip: k_commit_seg) where a k-mer's identity inside its region fits the 50 key bits of a slot;
 		  // decided here because the bloom kernel then needs no aggregation table in LDS: the room goes to the list (larger batches at full speed)
 			const char *es = getenv("BFCG_SEG");
@@ -174,6 +185,11 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 			const int id_bits = 2 * P.k - (P.seg_hi - P.seg_lo);
 			c->seg_ok = !prm->filter_mode && !prm->track_order && P.R <= 8 && !getenv("BFCG_BT") && id_bits <= BFC_CH_KEYBITS && prm->table_layout != 1 && !(es && atoi(es) == 0);
 			P.seg = c->seg_ok;
+			// the default path's bloom insert (bfcg_kernels.hip: k_bloom3) keeps 10-byte list entries: bloom address and clear-bit mask instead of
+			// the record's index, which gets two bytes of its own
+			c->b3_ok = c->seg_ok && prm->n_hashes == 4 && c->rw == 12 && bloom3_geometry_ok(P) && !getenv("BFCG_NO_B3");
+			P.b3 = c->b3_ok;
+			if (P.b3) rwb = 10;
 		}
 		const size_t second = prm->filter_mode ? region : P.seg ? 0 : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (prm->track_order ? 8 : 0)); // second filter's slice, or the aggregation table
 		size_t budget = (size_t)53000;
@@ -195,7 +211,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.list_cap = best_list;
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
 		{ // the class table of cold batches lies over the first-setter table and the lists
-			const size_t room = (size_t)P.fs_cap * 4 + (size_t)P.list_cap * 8;
+			const size_t room = (size_t)P.fs_cap * 4 + (size_t)P.list_cap * 8; // (k_bloom, which serves those batches, uses 8 of a list entry's bytes)
 			uint32_t ct = 1; while ((size_t)ct * 2 * 8 <= room) ct <<= 1;
 			P.ct_cap = ct;
 		}
@@ -206,11 +222,6 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	P.track = (prm->track_order && !prm->filter_mode) ? 1 : 0;
 	// one workgroup per CU (regions of 32 KiB and more: -b36, -b37) runs 1024 threads so that the CU still has 16 waves; no such variant with order stamps
 	{ const char *e = getenv("BFCG_BT"); P.bloom_bt = e ? atoi(e) : (bloom_lds_bytes(P) > 80 * 1024 && !P.track && P.n_hashes == 4) ? 1024 : 512; if (P.bloom_bt != 1024 || P.track || P.n_hashes != 4) P.bloom_bt = 512; }
-	// records do not store the bits of y0 that their level-1 bucket implies (bfcg_kernels.hip: RecGeom) -- where the bucket IS a bit field of y0:
-	// k >= bf_shift - 9 (the bloom block id is the low bf_shift-9 bits of the hash, and those are y0's, kmer.h:87)
-	// -- and where it makes the record smaller (c3: k=33, 9 bucket bits: 12 instead of 16 bytes; c2's k=31 records are 12 bytes anyway)
-	{ const char *e = getenv("BFCG_REC_DROP"); P.rec_n = (P.k >= P.bf_shift - 9 && bfcg_rec_dwords(P.k, P.F1) < bfcg_rec_dwords(P.k, 0) && !(e && atoi(e) == 0)) ? P.F1 : 0; P.rec_lo = P.R + P.F2; }
-	c->rw = 4 * bfcg_rec_dwords(P.k, P.rec_n);
 	c->n_ranks = n_ranks; c->rank = prm->rank; c->log2n = log2n;
 	// Stage A of the next batch runs under stage B of this one (two streams): c2 14.2 vs 15.4 ms per step.  While the count table was updated by
 	// random device-scope atomics the overlap HURT config c3 (389 vs 328 ms per step: the scatter kernels crawled beside k_commit_stream); with
@@ -258,7 +269,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		// a slab should expect ~1000 records or more: below that its fill scatters by more than the head room, and the batch would be replayed
 		c->op_min_pos = (e = getenv("BFCG_ONEPASS_MIN_TILES")) ? (uint64_t)atoi(e) * 4096 : (uint64_t)nb1 * 8 * 1024;
 	}
-	const uint64_t recs1_n = c->onepass_ok ? (uint64_t)c->op_cap * nb1 * 8 : B.max_kmers;
+	// (one pass: + a tile and a chunk of slack behind the last slab.  A run that finds its slab full is still stored, at the slab's start -- the batch
+	// is poisoned and replayed, nobody reads it -- and a run is up to a whole tile where every k-mer of it falls into one bucket (poly-A reads):
+	// with slabs smaller than a tile such a run reaches into the following slabs, and behind the last one it must still be inside the buffer)
+	const uint64_t recs1_n = c->onepass_ok ? (uint64_t)c->op_cap * nb1 * 8 + (uint64_t)bfcg_tile1_of_rw(c->rw / 4) + 64 : B.max_kmers;
 	// (batches above 2^28 positions run on ONE stream -- c->pipeline -- so stage A of a batch never runs beside stage B of the one before: both
 	// slots share one level-1 buffer there, which leaves config c4 34 GB more for the hand-over log and the table's growth)
 	HIPCKN(hipMalloc(&c->recs1[0], recs1_n * c->rw));
@@ -425,7 +439,7 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 			}
 		}
 		if (c->n_batches) c->reused = 1;
-		c->P.seg = 1; c->seg_escaped = 0;
+		c->P.seg = 1; c->P.b3 = c->b3_ok; c->seg_escaped = 0;
 		HIPCK(hipMemsetAsync(c->ho_cur, 0, sizeof(uint32_t) * (size_t)nfine, c->st));
 		c->ho_pending = 0; c->slot_commit[0] = c->slot_commit[1] = 0; c->slot_all_committed[0] = c->slot_all_committed[1] = 0; c->keys_known = 0; c->commit_absorbed = 0;
 		c->keys_per_batch = 0; c->n_commits = 0; c->ho_window = 1;
@@ -753,7 +767,7 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 	HIPCK(hipGetLastError());
 	HIPCK(hipFree(B.seg_tab));
 	B.seg_tab = 0;
-	P.seg = 0; c->seg_escaped = 1;
+	P.seg = 0; P.b3 = 0; c->seg_escaped = 1;
 	HIPCK(set_bloom_lds_attr(P)); // the aggregation table is back in the bloom kernel's LDS footprint
 	if (fetch_stats(c) != 0) return -1;
 	c->keys_last = c->h_stats[ST_KEYS];

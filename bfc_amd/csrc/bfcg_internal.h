@@ -11,6 +11,15 @@ static inline int bfcg_tile_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
 /* positions per tile of stage A (k_hist1 / k_scatter1: bfcg_kernels.hip, S1<RW>) */
 static inline int bfcg_tile1_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
 #define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */
+/* The measurement switches (KParams.ablate = BFCG_ABLATE: skip the stores / the cursor atomics / the hashing of k_scatter1, phase clocks in
+   k_bloom, ...) exist only in a library built with -DBFCG_MEASURE (`python -m bfc_amd.build --measure` -> build/libbfc_gpu_measure.so, loaded
+   through BFC_GPU_LIB by the scripts that need them).  In the shipped library BFCG_ABL() is the constant 0: the kernels carry neither the
+   tests nor an environment variable that could turn counts wrong. */
+#ifdef BFCG_MEASURE
+#define BFCG_ABL(P, bits) ((P).ablate & (bits))
+#else
+#define BFCG_ABL(P, bits) 0
+#endif
 #include <stdint.h>
 
 namespace bfcg {
@@ -30,7 +39,7 @@ struct KParams {
 	uint32_t ag_cap;            // LDS aggregation table entries (pow2)
 	uint32_t idx_rank;          // rank << (32 - rank_bits): prefixed to the in-batch position so file order is rank-major
 	int track;                  // 1: keep first/last insertion stamps for the byte-identical dump
-	int ablate;                 // debug: bit0 skip table commits, bit1 skip aggregation+commits, bit3 skip the bloom kernel
+	int ablate;                 // measurement switches (BFCG_ABLATE): honoured only by a library built with -DBFCG_MEASURE (see BFCG_ABL below)
 	int bloom_bt;               // threads per workgroup of the bloom kernel: 512 (three workgroups per CU), 1024 when the LDS footprint allows one only
 	int seg;                    // 1: the count table is kept as region-owned segments (seg_tab) and updated through LDS by k_commit_seg
 	int seg_shift;              // log2 slots per segment
@@ -40,6 +49,7 @@ struct KParams {
 	int dedupe;                 // this batch goes into a (nearly) empty filter: k_bloom resolves the copies of a k-mer by class first (host's hint, speed only)
 	uint32_t ct_cap;            // entries of k_bloom's class table (a power of two; 8-byte entries over the first-setter table and the lists)
 	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
+	int b3;                     // the default path's bloom insert runs k_bloom3: a list entry in LDS is 10 bytes (bloom_lds_bytes), and batches without `dedupe` take that kernel
 };
 
 struct BatchBufs {
@@ -76,6 +86,7 @@ void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, cons
                  const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev);
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev);
 int bloom_lds_bytes(const KParams &P);
+bool bloom3_geometry_ok(const KParams &P); // k_bloom3's conditions (12-byte records whose bloom address is a bit field of their words, 4 hashes, regions of <= 256 blocks)
 hipError_t set_bloom_lds_attr(const KParams &P);
 void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *bloom, uint8_t *flags, hipStream_t st);
 void run_kcov(const KParams &P, const uint8_t *seq, int64_t n_pos, int min_occ, const void *tab, uint8_t *flags, uint16_t *out, hipStream_t st);

@@ -3,6 +3,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("BFCG_ABLATE", "64")
+# the measurement switches exist only in the -DBFCG_MEASURE build (python -m bfc_amd.build --measure, built before the GPU call)
+os.environ.setdefault("BFC_GPU_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libbfc_gpu_measure.so"))
 import numpy as np
 import bfc_amd
 from bfc_amd import gen
@@ -18,5 +20,5 @@ for t in range(int(os.environ.get("NB", 6))):
     cur = np.array(st["phase_cycles"], dtype=np.float64)
     d = cur - prev; prev = cur
     ms = g.last_batch_ms()
-    print("batch %d: bloom %.2f ms; cycles per region (thread 0): %s" % (t, ms["bloom"], {n: int(v / 262144) for n, v in zip(names, d)}), flush=True)
+    print("batch %d: bloom %.2f ms; slow regions so far %d; cycles per region (thread 0): %s" % (t, ms["bloom"], st["slow_buckets"], {n: int(v / 262144) for n, v in zip(names, d)}), flush=True)
 g.close()

@@ -2,6 +2,8 @@
 one batch of c3 reads.    BFCG_ABLATE=2048 python scripts/s1_ablate.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the measurement switches exist only in the -DBFCG_MEASURE build (python -m bfc_amd.build --measure, built before the GPU call)
+os.environ.setdefault("BFC_GPU_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libbfc_gpu_measure.so"))
 import bfc_amd
 from bfc_amd import gen
 rs = gen.ReadSet(seed=3, G=248_000_000, cov=30.0)

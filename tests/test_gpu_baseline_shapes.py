@@ -143,8 +143,8 @@ def test_c5_parameters(gpu_lib):
 def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level, pipeline, monkeypatch):
     """Input the one-pass partition cannot take, at -b30 (128 level-1 buckets x 8 slabs, 8192 regions):
       level 1: 300 000 reads of a 400-base genome -- few, often repeated k-mers overflow the level-1 slabs;
-      level 2: 100 000 reads of a 50 Mbp genome plus 2 000 copies of one read -- every level-1 slab has room (a repeated k-mer adds 250 records
-               to slabs of 16 000), but the regions of the repeated k-mers get 2 000 records more than their slab of ~2 100 holds.
+      level 2: 80 000 reads of a 50 Mbp genome plus 2 000 copies of one read -- every level-1 slab has room (a repeated k-mer adds 250 records
+               to slabs of 13 600), but the regions of the repeated k-mers get 2 000 records more than their slab of ~1 760 holds.
     The batch and the one behind it change nothing on the device, the library replays both through the two-pass partition -- results are the
     oracle's, statistics counted once -- and the rest of the run stays two-pass."""
     monkeypatch.setenv("BFCG_PIPELINE", pipeline)
@@ -156,7 +156,7 @@ def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level, pipeline,
         genome = rng.choice(acgt, G + L)
         pos = rng.integers(0, G, n)
     else:
-        G, n = 50_000_000, 102_000
+        G, n = 50_000_000, 82_000  # (one library batch: below the cold batch limit of 8192 regions x the LDS list, whichever bloom kernel sizes it)
         genome = rng.choice(acgt, G + L)
         pos = rng.integers(0, G, n)
         pos[rng.choice(n, 2000, replace=False)] = 12345
@@ -190,6 +190,43 @@ def test_one_pass_partition_replays_skewed_batches(gpu_lib, fm, level, pipeline,
         assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
     g.reset()  # the next data set starts with the one-pass partition again
     assert g.partition_info()["one_pass"]
+    g.close(); oc.close()
+
+
+@pytest.mark.parametrize("chunk", ["32", "1"])
+def test_level1_run_longer_than_its_slab(gpu_lib, monkeypatch, chunk):
+    """Low-complexity reads (homopolymers, dinucleotide repeats) put EVERY k-mer of a tile into one level-1 bucket: a run of up to 4096 records
+    against slabs of ~1150 (-b30 with batches of 520 K positions).  The run finds its slab full, the batch is poisoned and replayed through the
+    two-pass partition -- and meanwhile the run is still stored from the slab's start on, across the following slabs; behind the LAST slab
+    that needs the slack recs1 is allocated with (without it the stray stores left the buffer).  Results are the oracle's."""
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    monkeypatch.setenv("BFCG_S1_CHUNK", chunk)
+    rng = np.random.default_rng(4242)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, k, b = 150, 31, 30
+    units = [b"A", b"C", b"G", b"T", b"AC", b"AG", b"AT", b"CG", b"CT", b"GT", b"ACG", b"AAT", b"ACGT"]
+    reads = []
+    for u in units:
+        r = np.frombuffer((u * (L // len(u) + 1))[:L], dtype=np.uint8)
+        reads += [r] * 250
+    reads += [rng.choice(acgt, L) for _ in range(200)]
+    order = rng.permutation(len(reads))
+    seq = np.concatenate([reads[i] for i in order]).astype(np.uint8)
+    n = len(reads)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = oracle.Counter(k, b)
+    oc.count(seq, qual, off)
+    g = gpu_lib.GpuCounter(k, b, max_batch_pos=n * (L + 1) + 64)
+    assert g.partition_info()["one_pass"]
+    g.count_host(gen.to_stream(seq, L, 10), gen.to_stream(qual, L, 33))
+    st, ost = g.stats(), oc.stats()
+    assert g.partition_info()["replayed_batches"] >= 1
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
     g.close(); oc.close()
 
 
