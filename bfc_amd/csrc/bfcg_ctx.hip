@@ -71,6 +71,7 @@ struct bfcg_ctx {
 	int pipeline;                // stage A of batch t+1 on its own stream under stage B of batch t
 	int seg_ok;                  // the geometry allows region-owned table segments (KParams.seg): every reset starts in that layout
 	int b3_ok;                   // ... and the bloom insert of batches without `dedupe` runs k_bloom3 (KParams.b3)
+	uint32_t fs_cap_w, list_cap_w; // k_bloom3's LDS tables for batches into a WARM filter (0: none): a footprint of a quarter of a CU's LDS
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
 	uint64_t n_seg_grow;         // segment growths since creation
@@ -210,6 +211,21 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		P.fs_cap = fs;
 		P.list_cap = best_list;
 		if (P.list_cap > 8191) P.list_cap = 8191; // 13-bit list index inside a first-setter entry
+		// Into a warm filter only the unseen k-mers take list entries and the library sizes such batches for 60 % of the list above (split_rule):
+		// a list of 3/4 of that size still has a quarter of head room, and with a first-setter table of half the size (contended bits are few once
+		// the filter is warm) the footprint drops to a quarter of a CU's LDS -- FOUR workgroups of k_bloom3 per CU instead of three (c3: the same 9
+		// batches, bloom stage 65.5 -> see profiles/round4_k_bloom.md).  A region that does overflow takes the exact slow path as ever.
+		c->fs_cap_w = c->list_cap_w = 0;
+		if (P.b3 && !getenv("BFCG_LDS") && !(getenv("BFCG_B3_WARM") && atoi(getenv("BFCG_B3_WARM")) == 0)) {
+			const size_t bw = 40900;
+			if (bw > region + 16 + 8192) {
+				const size_t lw = bw - region - 16;
+				uint32_t fw = fs; while (fw > 1024 && (size_t)fw * 4 + (size_t)(P.list_cap / 4 * 3) * rwb > lw) fw >>= 1;
+				uint32_t l = (size_t)fw * 4 < lw ? (uint32_t)((lw - (size_t)fw * 4) / rwb) : 0;
+				if (l > P.list_cap) l = P.list_cap;
+				if (l >= P.list_cap / 4 * 3 && fw >= 1024) { c->fs_cap_w = fw; c->list_cap_w = l; }
+			}
+		}
 		{ // the class table of cold batches lies over the first-setter table and the lists
 			const size_t room = (size_t)P.fs_cap * 4 + (size_t)P.list_cap * 8; // (k_bloom, which serves those batches, uses 8 of a list entry's bytes)
 			uint32_t ct = 1; while ((size_t)ct * 2 * 8 <= room) ct <<= 1;
@@ -403,6 +419,12 @@ static int handover_end(bfcg_ctx_t *c, const BatchBufs &Bt, int b);
 
 // k_bloom resolves the copies of a k-mer by class before the bit-level protocol (KParams.dedupe) where that pays: into an empty filter
 // (c3's first launch 14.2 -> 10.3 ms); from the second batch on most k-mers are seen outright and the extra passes cost more than they save
+// k_bloom3 with the short list and four workgroups per CU for a batch into a warm filter (see bfcg_create)
+static void warm_tables(const bfcg_ctx_t *c, KParams &Pt)
+{
+	Pt.b3_warm = 0;
+	if (Pt.b3 && !Pt.dedupe && !c->cold && c->list_cap_w) { Pt.fs_cap = c->fs_cap_w; Pt.list_cap = c->list_cap_w; Pt.b3_warm = 1; }
+}
 static int dedupe_hint(const bfcg_ctx_t *c) { return (c->n_batches == 0 || (c->cold && c->seen_per_pos < 0.15)) && !getenv("BFCG_NO_DEDUPE"); }
 
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -868,6 +890,7 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	if (handover_begin(c, Bt, b, op2, c->call_no + 1) != 0) return -1; // (this call's number: assigned below)
 	KParams Pm = c->P;
 	Pm.dedupe = dedupe_hint(c);
+	warm_tables(c, Pm);
 	run_stage_b(Pm, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
 	if (handover_end(c, Bt, b) != 0) return -1;
 	if (op2_run) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
@@ -1034,6 +1057,7 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	KParams Pt = c->P;
 	Pt.no_kstats = no_kstats;
 	Pt.dedupe = dedupe_hint(c);
+	warm_tables(c, Pt);
 	const uint8_t *const d_qual_given = d_qual; // (what a replay starts from again)
 	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, sA) != 0) return -1;
 	const int op_run = c->onepass && !no_kstats;  // the run still uses the one-pass partition: an earlier batch may turn out to have overflowed a slab

@@ -50,6 +50,7 @@ struct KParams {
 	uint32_t ct_cap;            // entries of k_bloom's class table (a power of two; 8-byte entries over the first-setter table and the lists)
 	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
 	int b3;                     // the default path's bloom insert runs k_bloom3: a list entry in LDS is 10 bytes (bloom_lds_bytes), and batches without `dedupe` take that kernel
+	int b3_warm;                // this batch goes into a warm filter: fs_cap / list_cap are the SHORT list's (four workgroups of k_bloom3 per CU instead of three)
 };
 
 struct BatchBufs {

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include "kmer_dev.h"
 #include "bfcg_internal.h"
+#include "bfcg_dev.h"
 
 using namespace bfcg;
 
@@ -205,23 +206,6 @@ __device__ __forceinline__ RecGeom rec_geom(const KParams &P) { RecGeom g; g.k =
 __device__ __forceinline__ uint64_t y0_drop(const RecGeom g, uint64_t y0) { return g.n ? (y0 & ((1ULL << g.lo) - 1)) | ((y0 >> (g.lo + g.n)) << g.lo) : y0; }
 __device__ __forceinline__ uint64_t y0_join(const RecGeom g, uint64_t y0c, uint32_t imp)
 { return g.n ? (y0c & ((1ULL << g.lo) - 1)) | ((uint64_t)imp << g.lo) | ((y0c >> g.lo) << (g.lo + g.n)) : y0c; }
-
-template <int RD> struct RecW { uint32_t d[RD]; };
-
-template <int RD> __device__ __forceinline__ RecW<RD> rec_load(const uint32_t *p);
-template <> __device__ __forceinline__ RecW<3> rec_load<3>(const uint32_t *p)
-{ const uint3 v = *reinterpret_cast<const uint3 *>(p); RecW<3> r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; return r; }
-template <> __device__ __forceinline__ RecW<4> rec_load<4>(const uint32_t *p)
-{ const uint4 v = *reinterpret_cast<const uint4 *>(p); RecW<4> r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; return r; }
-template <> __device__ __forceinline__ RecW<5> rec_load<5>(const uint32_t *p) // records are only dword-aligned
-{ RecW<5> r; r.d[0] = p[0]; r.d[1] = p[1]; r.d[2] = p[2]; r.d[3] = p[3]; r.d[4] = p[4]; return r; }
-template <int RD> __device__ __forceinline__ void rec_store(uint32_t *p, const RecW<RD> &r);
-template <> __device__ __forceinline__ void rec_store<3>(uint32_t *p, const RecW<3> &r)
-{ *reinterpret_cast<uint3 *>(p) = make_uint3(r.d[0], r.d[1], r.d[2]); }
-template <> __device__ __forceinline__ void rec_store<4>(uint32_t *p, const RecW<4> &r)
-{ *reinterpret_cast<uint4 *>(p) = make_uint4(r.d[0], r.d[1], r.d[2], r.d[3]); }
-template <> __device__ __forceinline__ void rec_store<5>(uint32_t *p, const RecW<5> &r)
-{ p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; p[3] = r.d[3]; p[4] = r.d[4]; }
 
 // pack: y0 is the FULL word (the bucket's bits are dropped here); unpack: imp = the record's (global) level-1 bucket
 template <int RD> struct Rec;
@@ -1091,17 +1075,6 @@ __global__ __launch_bounds__(1024) void k_seg_setup(KParams P, const uint32_t *_
 
 __device__ __forceinline__ SegGeom seg_geom(const KParams &P) { SegGeom g; g.k = P.k; g.lo = P.seg_lo; g.hi = P.seg_hi; return g; }
 
-// Optional order bookkeeping for the byte-identical `-d` dump: per slot the stamp (batch << 32 | file index)
-// of the FIRST bfc_ch_insert call that created the key, per sub-table the stamp of the LAST call of any kind.  The host
-// replays khash's growth from them (bfc_host.c).  Both are order-independent (min / max), so parking and replay keep them exact.
-struct TabOrder {
-	unsigned long long *first, *sub_last; // NULL: not tracked
-	__device__ __forceinline__ void note(uint32_t sub, uint64_t slot, unsigned long long sf, unsigned long long sl) const
-	{
-		if (first) { atomicMin(&first[slot], sf); atomicMax(&sub_last[sub], sl); }
-	}
-};
-
 // ------------------------------------------------------------------------------------------
 // count table in HBM: 2^l_pre regions of 2^tab_cshift u64 slots, slot = key(50)<<14|high(6)<<8|count(8)
 // exactly as htab.c:7-17 stores it; empty = 0.  Home slot = low bits of key>>14 (as khash does),
@@ -1175,76 +1148,6 @@ __global__ void k_table_rehash(KParams P, const unsigned long long *__restrict__
 // ------------------------------------------------------------------------------------------
 // bloom region kernel
 
-#define FS_EMPTY 0xffffffffffffffffULL
-
-// first-setter table: entry = bit offset inside the region (high 32) | k-mer index (low 32);
-// atomicMin keeps, per bit, the earliest k-mer (file order) that finds the bit clear.
-template <bool GLOBAL>
-__device__ __forceinline__ bool fs_insert(unsigned long long *tab, uint32_t cap_mask, uint32_t bitoff, uint32_t idx, uint32_t max_probe)
-{
-	const unsigned long long e = ((unsigned long long)bitoff << 32) | idx;
-	uint32_t p = ((bitoff * 0x9E3779B1u) >> 12 ^ bitoff) & cap_mask; // low bits of a multiplicative hash are weak: fold the high half in
-	for (uint32_t probe = 0; probe <= max_probe; ++probe, p = (p + 1) & cap_mask) {
-		unsigned long long cur = GLOBAL ? __hip_atomic_load(&tab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[p];
-		if (cur == FS_EMPTY) {
-			cur = atomicCAS(&tab[p], FS_EMPTY, e);
-			if (cur == FS_EMPTY) return true;
-		}
-		if ((uint32_t)(cur >> 32) == bitoff) { if (e < cur) atomicMin(&tab[p], e); return true; }
-	}
-	return false;
-}
-// true and the first setter's index if the bit has an entry (<=> it was clear before the batch)
-template <bool GLOBAL>
-__device__ __forceinline__ bool fs_lookup(const unsigned long long *tab, uint32_t cap_mask, uint32_t bitoff, uint32_t &first)
-{
-	uint32_t p = ((bitoff * 0x9E3779B1u) >> 12 ^ bitoff) & cap_mask;
-	for (uint32_t probe = 0; probe <= cap_mask; ++probe, p = (p + 1) & cap_mask) {
-		unsigned long long cur = GLOBAL ? __hip_atomic_load((unsigned long long *)&tab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[p];
-		if (cur == FS_EMPTY) return false;
-		if ((uint32_t)(cur >> 32) == bitoff) { first = (uint32_t)cur; return true; }
-	}
-	return false;
-}
-
-struct BloomArgs {
-	const uint32_t *recs;          // fine-bucketed records (RD dwords each)
-	const uint32_t *start;         // fine bucket starts (n_fine+1)
-	unsigned long long *bloom;     // first bloom filter (device)
-	unsigned long long *bloom_hi;  // second bloom filter (filter mode) or NULL
-	unsigned long long *table;     // count table or NULL
-	unsigned long long *stats;
-	uint64_t *tab_ovf; uint32_t tab_ovf_cap; unsigned long long *ovf_cnt;
-	unsigned long long *pool; uint32_t pool_slices;        // slow-path first-setter pool: pool_slices lock words, then pool_slices slices of 2^(R+10) entries
-	uint8_t *seen_out;             // optional debug: seen flag (1/2) per batch position
-	uint64_t *agg_out;             // aggregated seen k-mers: three planes [y0 | y1 | count|high<<16] of [n_fine][ag_cap], or NULL = commit inline
-	uint32_t *agg_cnt;             // entries per fine bucket
-	uint32_t *stream_out;          // STREAM mode: seen k-mers as records, region f's at [start[f], start[f] + agg_cnt[f])
-	unsigned long long *seg_tab;   // region-owned table segments (KParams.seg) or NULL
-	uint32_t n_fine;               // fine buckets (= bloom regions) this launch owns
-	TabOrder ord;                  // optional first/last stamps (byte-identical dump)
-	unsigned long long batch_hi;   // batch number << 32: high half of a stamp
-	const uint32_t *cnt2; uint32_t cap2; // one-pass level 2: region f's records are recs[f * cap2 .. + cnt2[f]) (cap2 = 0: start[] says where)
-	// Hand-over log of the region-owned table: region f owns ho[f * ho_stride .. + ho_stride); k_bloom appends its seen k-mers
-	// behind ho_cur[f] -- which lives on from batch to batch -- and notes where the batch ended (ho_mark: this batch's page, one word per
-	// region); k_commit_seg applies the pages of several batches in one pass over the segment and clears the cursor.  ho_stride == 0:
-	// the batch's entries sit at its records' offsets in stream_out instead (two-pass level 2: a region's share has no bound) and are applied at once.
-	unsigned long long *ho; uint32_t ho_stride; uint32_t *ho_cur; uint32_t *ho_mark;
-	uint32_t ho_pages, ho_mark_stride;  // k_commit_seg: pages to apply (page j's marks at ho_mark + j * ho_mark_stride)
-	unsigned long long *ho_keys;        // k_commit_seg: keys created by page j, slotted: ho_keys[j * ST_SLOTS + (f & (ST_SLOTS - 1))]
-	const uint32_t *flags;         // one-pass partition, this batch's slot: [0] a level-1 slab overflowed, [2] a region's slab (NULL: two-pass batch)
-	const uint32_t *sticky;        // an earlier batch of the run overflowed (written by k_seal on stage B's stream only)
-};
-
-// where region f's records are
-__device__ __forceinline__ void region_list(const BloomArgs &A, uint32_t f, uint32_t &rs, uint32_t &n)
-{
-	if (A.cap2) { const uint32_t c = A.cnt2[f]; rs = f * A.cap2; n = c < A.cap2 ? c : A.cap2; }
-	else { rs = A.start[f]; n = A.start[f + 1] - rs; }
-}
-// A batch the one-pass partition gave up on must change nothing: the host replays it (and every batch behind it) through the two-pass one.
-__device__ __forceinline__ bool batch_poisoned(const BloomArgs &A) { return (A.sticky && *A.sticky) || (A.flags && (A.flags[0] | A.flags[2])); }
-
 // what finally happens to a k-mer that was seen c times (h of them high quality) in this batch
 template <typename W, bool TRACK>
 __device__ __forceinline__ void commit_seen(const KParams &P, const BloomArgs &A, uint64_t y0, uint64_t y1, uint32_t c, uint32_t h,
@@ -1310,24 +1213,6 @@ __device__ __forceinline__ void emit_seen(const KParams &P, const BloomArgs &A, 
 // one k-mer record of the bloom kernel, decoded
 struct KRec { uint64_t y0, y1; uint32_t idx, bl, h1, h2; bool hi; uint32_t d0, d1; }; // (d0, d1: the 12-byte record's first words, for the fast paths below)
 
-// Bloom address and hand-over entry of a 12-byte record on 32-bit words (what decode_rec / seg_id compute through 64-bit y0, y1).  The record
-// holds y0' = y0 without its level-1 bucket bits [lo, lo+n) in bits [0, a) and y1 in bits [a, a+k); for k >= bf_shift-9 the block id is the low
-// bf_shift-9 bits of y0 (kmer.h:87), so
-//     block inside the region = y0' & (2^R - 1)
-//     h1 | h2 << 9 = bits [bf_shift-9, bf_shift+9) of the hash (h0^h1) << k | y0  =  (y0' >> up) | ((y0 - y1) ^ y1) << (k - (bf_shift-9))
-// (up = where the part of y0 above the block id starts inside y0'; only the low bits of y0 - y1 are needed), and the k-mer's identity inside the
-// region -- y0 without the bits the region implies, then y1 (kmer_dev.h: seg_id) -- is  (y0' & (2^R-1)) | (y0' >> up) << R | y1 << (k - F).
-struct Dec3 { int ok, a, lo, n, up, sh_x, R, sh_flag, sh_y1; uint32_t lowmask, rmask, mk32; };
-__device__ __forceinline__ Dec3 dec3_geom(const KParams &P)
-{
-	Dec3 g;
-	g.a = P.k - P.rec_n; g.lo = P.rec_lo; g.n = P.rec_n; g.up = P.rec_n ? P.rec_lo : P.bf_shift - 9; g.sh_x = P.k - (P.bf_shift - 9);
-	g.R = P.R; g.sh_flag = g.a + P.k - 32; g.sh_y1 = P.k - P.F;
-	g.lowmask = P.rec_n ? (1u << (P.rec_lo & 31)) - 1u : 0xffffffffu; g.rmask = (1u << P.R) - 1u; g.mk32 = P.k >= 32 ? 0xffffffffu : (1u << P.k) - 1u;
-	g.ok = P.k >= P.bf_shift - 9 && P.bf_shift + 9 <= 2 * P.k && g.a >= 1 && g.a <= 31 && g.a + P.k >= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n <= 31)
-	       && g.up <= g.a && g.sh_x >= 0 && g.sh_x <= 31 && g.sh_y1 >= 0 && g.sh_y1 <= 32 && (P.rec_n == 0 || P.rec_lo + P.rec_n == P.bf_shift - 9) && P.R <= g.up;
-	return g;
-}
 __device__ __forceinline__ KRec decode_fast3(const Dec3 g, const RecW<3> &w, uint32_t imp)
 {
 	KRec r;
@@ -1362,64 +1247,6 @@ __device__ __forceinline__ KRec decode_rec(const KParams &P, const RecW<RW> &w, 
 	r.bl = (uint32_t)a.blk & rmask; r.h1 = a.h1; r.h2 = a.h2;
 	r.d0 = r.d1 = 0;
 	return r;
-}
-
-// first-setter table in LDS, 4 bytes per entry: bit offset in the region << 13 | index into the LDS list of
-// k-mers with clear bits.  The earliest k-mer (file order = record idx, read through the list) wins a bit.
-#define FS32_EMPTY 0xffffffffu
-__device__ __forceinline__ uint32_t fs32_slot(uint32_t bitoff, uint32_t mask) { return ((bitoff * 0x9E3779B1u) >> 12 ^ bitoff) & mask; }
-
-__device__ __forceinline__ bool fs32_insert(unsigned int *fs, uint32_t mask, uint32_t bitoff, uint32_t li, uint32_t idx, const unsigned int *list_idx)
-{
-	const uint32_t e = (bitoff << 13) | li;
-	uint32_t p = fs32_slot(bitoff, mask);
-	for (int probe = 0; probe < 1024; ++probe, p = (p + 1) & mask) {
-		uint32_t cur = fs[p];
-		if (cur == FS32_EMPTY) {
-			cur = atomicCAS(&fs[p], FS32_EMPTY, e);
-			if (cur == FS32_EMPTY) return true;
-		}
-		if ((cur >> 13) == bitoff) {
-			while (list_idx[cur & 0x1fffu] > idx) { // the holder is later in file order: take the bit over
-				uint32_t old = atomicCAS(&fs[p], cur, e);
-				if (old == cur) break;
-				cur = old;
-			}
-			return true;
-		}
-	}
-	return false;
-}
-// a k-mer that touches a bit which HAS an entry competes for it (no entry is created: the bit is uncontended)
-// (returns whether the bit has an entry)
-__device__ __forceinline__ bool fs32_compete(unsigned int *fs, uint32_t mask, uint32_t bitoff, uint32_t li, uint32_t idx, const unsigned int *list_idx)
-{
-	const uint32_t e = (bitoff << 13) | li;
-	uint32_t p = fs32_slot(bitoff, mask);
-	for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
-		uint32_t cur = fs[p];
-		if (cur == FS32_EMPTY) return false;
-		if ((cur >> 13) == bitoff) {
-			while (list_idx[cur & 0x1fffu] > idx) {
-				uint32_t old = atomicCAS(&fs[p], cur, e);
-				if (old == cur) break;
-				cur = old;
-			}
-			return true;
-		}
-	}
-	return false;
-}
-// list index of the first setter of a bit, or FS32_EMPTY if the bit has no entry
-__device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t mask, uint32_t bitoff)
-{
-	uint32_t p = fs32_slot(bitoff, mask);
-	for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
-		uint32_t cur = fs[p];
-		if (cur == FS32_EMPTY) return FS32_EMPTY;
-		if ((cur >> 13) == bitoff) return cur & 0x1fffu;
-	}
-	return FS32_EMPTY;
 }
 
 // Class table of the cold batches (KParams.dedupe): k-mers with the same bloom block, h1 and h2 touch the same bits, so among the copies of
@@ -1944,359 +1771,6 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	(void)s_pad;
 }
 
-// ------------------------------------------------------------------------------------------
-// k_bloom3 (round 4): the bloom insert of the DEFAULT path -- 12-byte records on 32-bit words (dec3_geom), n_hashes = 4, seen k-mers into the
-// hand-over log / stream of the region-owned table -- written for INSTRUCTION COUNT.  k_bloom on config c3 issued 5.0 VALU and 4.5 SALU wave
-// instructions per k-mer at 62 % of the chip's VALU issue rate (profiles/round4_k_bloom.md: SQ counters); it was bound by what it executed, not
-// by memory: divergent loops (bloom_next's skip of the lock byte four times per k-mer and pass, probe loops inlined per bit), one ballot + one
-// LDS atomic round trip per record and output, the record decoded again in every pass over the list, and a pass C that looked every bit up again.
-// Same protocol (the comment above k_bloom), restated:
-//   pass 1  every record: decode, the four bit positions WITHOUT a loop (a conditional step over the lock byte per position; the one-in-4000
-//           k-mer that would need a second step in a row takes the loop), four LDS reads back to back, then ONE LDS atomic per wave and round for
-//           the seen k-mers' slots in the hand-over log and ONE for the list slots of the k-mers with clear bits.  A list entry is 10 bytes:
-//           file index | block, h1, h2, clear-bit mask (30 bits: no pass decodes a record again) | record index (16 bits: only an emit needs it);
-//   pass A  the returning ORs of a k-mer's clear bits are issued back to back; contended bits (rare once the filter is warm: 2 % of the touches)
-//           enter the first-setter table in a loop over the lane's contended bits, not in four inlined copies;
-//   pass B  the home slots of a k-mer's clear bits in the first-setter table are read back to back; an empty home slot means no entry, i.e. the
-//           k-mer alone touched that bit: it is a first setter, NOT seen, and needs no pass C (bit 30 of its list word stays clear).  Bits with a
-//           non-empty home slot compete as before;
-//   pass C  only k-mers ALL of whose clear bits have entries look them up; those that won none are seen and emitted (record re-read by index).
-// The records of round t+1 are requested before round t is processed.  Regions whose list, first-setter table or record index overflow take the
-// same exact HBM-pool path as in k_bloom.  Cold batches with copies resolved by class (KParams.dedupe) stay with k_bloom<..., F3>.
-#define B3_UND 0x40000000u /* list word: every clear bit of this k-mer has a first-setter entry -- pass C decides */
-struct B3Pos { uint32_t b0, b1, b2, b3; };
-// bbf.c:33-41: positions z = h1, h1 + h2, ... (mod 512), those below 8 (the lock byte) skipped
-__device__ __forceinline__ B3Pos b3_positions(uint32_t h1, uint32_t h2)
-{
-	B3Pos p;
-	uint32_t z = h1, t;
-	t = (z + h2) & 511u; z = z < 8u ? t : z; p.b0 = z; z = (z + h2) & 511u;
-	t = (z + h2) & 511u; z = z < 8u ? t : z; p.b1 = z; z = (z + h2) & 511u;
-	t = (z + h2) & 511u; z = z < 8u ? t : z; p.b2 = z; z = (z + h2) & 511u;
-	t = (z + h2) & 511u; z = z < 8u ? t : z; p.b3 = z;
-	if (__builtin_expect(min(min(p.b0, p.b1), min(p.b2, p.b3)) < 8u, 0)) { // two steps into the lock byte in a row (h2 < 8): the reference's loop
-		z = h1;
-		p.b0 = bloom_next(z, h2); p.b1 = bloom_next(z, h2); p.b2 = bloom_next(z, h2); p.b3 = bloom_next(z, h2);
-	}
-	return p;
-}
-__device__ __forceinline__ uint32_t b3_word(uint32_t bl, uint32_t b) { return (bl << 4) | (b >> 5); } // dword of bit b of block bl inside the region
-
-template <int BT, int PF>
-__global__ __launch_bounds__(BT, 6) void k_bloom3(KParams P, BloomArgs A)
-{
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_emit_n, s_fs_used, s_pad3[3];
-	const uint32_t f = blockIdx.x;
-	const bool ho_log = A.ho_stride != 0;
-	if (batch_poisoned(A)) { if (ho_log && threadIdx.x == 0) A.ho_mark[f] = A.ho_cur[f]; return; } // (an empty page: the batch will be replayed)
-	uint32_t rs, n;
-	region_list(A, f, rs, n);
-	if (n == 0) { if (threadIdx.x == 0) { if (ho_log) A.ho_mark[f] = A.ho_cur[f]; else if (A.agg_cnt) A.agg_cnt[f] = 0; } return; }
-	uint32_t ho_cur0 = 0;
-	unsigned long long *ho_base;
-	if (ho_log) {
-		ho_cur0 = A.ho_cur[f];
-		if (ho_cur0 + n > A.ho_stride) { // (the host commits before a log can fill up: a bug if it ever happens -- loudly, not silently)
-			if (threadIdx.x == 0) { atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_ERR_POOL], 1ULL); A.ho_mark[f] = ho_cur0; }
-			return;
-		}
-		ho_base = A.ho + (uint64_t)f * A.ho_stride + ho_cur0;
-	} else ho_base = reinterpret_cast<unsigned long long *>(A.stream_out) + rs;
-	A.stats += (size_t)(f & (ST_SLOTS - 1)) * ST_N;
-	const uint32_t region_dw = 16u << P.R;
-	unsigned char *sp = smem;
-	unsigned int *region = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
-	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.fs_cap * 4;
-	unsigned int *la = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4;   // file-order index
-	unsigned int *lb = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4;   // block | h1 << 8 | h2 << 17 | clear-bit mask << 26 (| B3_UND)
-	unsigned short *lc = reinterpret_cast<unsigned short *>(sp);                              // record index inside the region's slab
-	const uint32_t fs_mask = P.fs_cap - 1;
-	const uint32_t *recs = A.recs + (uint64_t)rs * 3;
-	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
-	const uint32_t imp = (P.f_base + f) >> P.F2; // the region's level-1 bucket: the bits of y0 its records do not store
-	const Dec3 D = dec3_geom(P);
-	const int tid = threadIdx.x, lane = tid & 63;
-	const uint32_t mask_a = (1u << D.a) - 1u, imp_sh = D.n ? imp << D.lo : 0u, sh_up = D.lo + D.n;
-#ifdef BFCG_MEASURE
-	const bool timing = BFCG_ABL(P, 64) && tid == 0;
-	long long tq[7] = {0, 0, 0, 0, 0, 0, 0};
-	if (timing) tq[0] = clock64();
-#endif
-	// block (8 bits at R = 8) | h1 << 8 | h2 << 17 of a record (decode_fast3, packed)
-	auto addr3 = [&](uint32_t d0, uint32_t d1) -> uint32_t {
-		const uint32_t y0d = d0 & mask_a, upper = y0d >> D.up;
-		const uint32_t y0lo = D.n ? (y0d & D.lowmask) | imp_sh | (upper << sh_up) : y0d;
-		const uint32_t y1lo = __builtin_amdgcn_alignbit(d1, d0, D.a) & D.mk32;
-		const uint32_t hh = upper | (((y0lo - y1lo) ^ y1lo) << D.sh_x);
-		uint32_t h2 = (hh >> 9) & 511u;
-		h2 |= (uint32_t)((h2 & 31u) == 0); // bbf.c:33 (the low five bits are zero: + 1 is | 1)
-		return (y0d & D.rmask) | ((hh & 511u) << 8) | (h2 << 17);
-	};
-	auto entry3 = [&](uint32_t d0, uint32_t d1) -> unsigned long long { // the 8-byte hand-over entry: identity inside the region << 1 | high-quality flag
-		const unsigned long long AA = d0 | ((unsigned long long)d1 << 32);
-		const unsigned long long y1 = (AA >> D.a) & ((1ULL << P.k) - 1);
-		const uint32_t y0d = d0 & mask_a;
-		const unsigned long long id = (unsigned long long)((y0d & D.rmask) | ((y0d >> D.up) << D.R)) | (y1 << D.sh_y1);
-		return (id << 1) | (unsigned long long)((d1 >> D.sh_flag) & 1u);
-	};
-	RecW<3> cur[PF], nxt[PF];
-#pragma unroll
-	for (int u = 0; u < PF; ++u) {
-		const uint32_t i = tid + u * BT;
-		cur[u].d[0] = cur[u].d[1] = cur[u].d[2] = 0; nxt[u] = cur[u]; // (lanes beyond the region's records compute on zeros)
-		if (i < n) cur[u] = rec_load<3>(recs + (uint64_t)i * 3);
-		if (i + BT * PF < n) nxt[u] = rec_load<3>(recs + (uint64_t)(i + BT * PF) * 3);
-	}
-	{ // stage the region (16-byte loads), clear the first-setter table
-		const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
-		uint4 *dst = reinterpret_cast<uint4 *>(region);
-		for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
-		uint4 *f4 = reinterpret_cast<uint4 *>(fs);
-		for (uint32_t i = tid; i < P.fs_cap / 4; i += BT) f4[i] = make_uint4(FS32_EMPTY, FS32_EMPTY, FS32_EMPTY, FS32_EMPTY);
-		if (tid == 0) { s_list_n = 0; s_emit_n = 0; s_ovf = 0; s_fs_used = 0; }
-	}
-	__syncthreads();
-#ifdef BFCG_MEASURE
-	if (timing) tq[1] = clock64();
-#endif
-	volatile uint32_t *v_ovf = &s_ovf;
-
-	// ---- pass 1: classify against the pre-batch region; seen -> hand-over log, clear bits -> list
-	for (uint32_t base = 0; base < n; base += BT * PF) {
-		uint32_t pk[PF], um[PF];
-#pragma unroll
-		for (int u = 0; u < PF; ++u) {
-			pk[u] = addr3(cur[u].d[0], cur[u].d[1]);
-			const B3Pos b = b3_positions((pk[u] >> 8) & 511u, pk[u] >> 17);
-			const uint32_t bl = pk[u] & 255u;
-			const uint32_t w0 = region[b3_word(bl, b.b0)], w1 = region[b3_word(bl, b.b1)], w2 = region[b3_word(bl, b.b2)], w3 = region[b3_word(bl, b.b3)];
-			um[u] = (((w0 >> (b.b0 & 31u)) & 1u) | (((w1 >> (b.b1 & 31u)) & 1u) << 1) | (((w2 >> (b.b2 & 31u)) & 1u) << 2) | (((w3 >> (b.b3 & 31u)) & 1u) << 3)) ^ 15u;
-		}
-		unsigned long long ms[PF], ml[PF];
-		uint32_t tot_s = 0, tot_l = 0;
-#pragma unroll
-		for (int u = 0; u < PF; ++u) {
-			const bool act = base + tid + u * BT < n;
-			ms[u] = __ballot(act && um[u] == 0); ml[u] = __ballot(act && um[u] != 0);
-			tot_s += (uint32_t)__popcll(ms[u]); tot_l += (uint32_t)__popcll(ml[u]);
-		}
-		uint32_t o_s = 0, o_l = 0;
-		if (lane == 0) { if (tot_s) o_s = atomicAdd(&s_emit_n, tot_s); if (tot_l) o_l = atomicAdd(&s_list_n, tot_l); }
-		o_s = __builtin_amdgcn_readfirstlane(o_s); o_l = __builtin_amdgcn_readfirstlane(o_l);
-#pragma unroll
-		for (int u = 0; u < PF; ++u) {
-			const uint32_t below_lo = (uint32_t)__builtin_amdgcn_mbcnt_lo((uint32_t)ms[u], 0u), below_s = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms[u] >> 32), below_lo);
-			const uint32_t blow_lo = (uint32_t)__builtin_amdgcn_mbcnt_lo((uint32_t)ml[u], 0u), below_l = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml[u] >> 32), blow_lo);
-			const bool act = base + tid + u * BT < n;
-			if (act && um[u] == 0) { // every bit was set before this batch: seen, whatever the order inside the batch
-				ho_base[o_s + below_s] = entry3(cur[u].d[0], cur[u].d[1]);
-				if (A.seen_out) A.seen_out[cur[u].d[2]] = 2;
-			} else if (act) {
-				const uint32_t li = o_l + below_l;
-				if (li < P.list_cap) { la[li] = cur[u].d[2]; lb[li] = pk[u] | (um[u] << 26); lc[li] = (unsigned short)(base + tid + u * BT); }
-			}
-			o_s += (uint32_t)__popcll(ms[u]); o_l += (uint32_t)__popcll(ml[u]);
-		}
-		if (base + BT * PF < n) {
-#pragma unroll
-			for (int u = 0; u < PF; ++u) {
-				cur[u] = nxt[u];
-				const uint32_t i = base + 2 * BT * PF + tid + u * BT;
-				if (i < n) nxt[u] = rec_load<3>(recs + (uint64_t)i * 3);
-			}
-		}
-	}
-	__syncthreads();
-#ifdef BFCG_MEASURE
-	if (timing) tq[2] = clock64();
-#endif
-	const uint32_t ln = s_list_n;
-	const bool ovf_list = ln > P.list_cap || ln > 8191 || n > 65535u; // (13-bit list index in a first-setter entry, 16-bit record index in the list)
-	bool dirty = true;
-	if (!ovf_list) {
-		// ---- pass A (dense over the list): set every clear bit; the returning OR tells whether another k-mer of this batch got there first
-		for (uint32_t li = tid; li < ln; li += BT) {
-			const uint32_t w = lb[li], bl = w & 255u, um = (w >> 26) & 15u;
-			const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
-			uint32_t cm = 0;
-			{
-				uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-				if (um & 1u) o0 = atomicOr(&region[b3_word(bl, b.b0)], 1u << (b.b0 & 31u));
-				if (um & 2u) o1 = atomicOr(&region[b3_word(bl, b.b1)], 1u << (b.b1 & 31u));
-				if (um & 4u) o2 = atomicOr(&region[b3_word(bl, b.b2)], 1u << (b.b2 & 31u));
-				if (um & 8u) o3 = atomicOr(&region[b3_word(bl, b.b3)], 1u << (b.b3 & 31u));
-				cm = (((o0 >> (b.b0 & 31u)) & 1u) | (((o1 >> (b.b1 & 31u)) & 1u) << 1) | (((o2 >> (b.b2 & 31u)) & 1u) << 2) | (((o3 >> (b.b3 & 31u)) & 1u) << 3)) & um;
-			}
-			if (cm) { // contended bits: file order decides them
-				*(volatile uint32_t *)&s_fs_used = 1;
-				const uint32_t idx = la[li];
-				const uint32_t p01 = b.b0 | (b.b1 << 16), p23 = b.b2 | (b.b3 << 16);
-				while (cm) {
-					const int j = __ffs((int)cm) - 1;
-					cm &= cm - 1;
-					const uint32_t bj = ((j & 2 ? p23 : p01) >> ((j & 1) << 4)) & 0xffffu;
-					if (!fs32_insert(fs, fs_mask, bl * 512u + bj, li, idx, la)) *v_ovf = 1;
-				}
-			}
-		}
-	}
-	__syncthreads();
-#ifdef BFCG_MEASURE
-	if (timing) tq[6] = clock64();
-#endif
-	const bool ovf = ovf_list || s_ovf; // (the same for every thread: nothing writes s_ovf behind this barrier)
-	if (!ovf) {
-		if (s_fs_used) {
-			// ---- pass B: every toucher of a bit that has an entry competes for it (this brings in the k-mer that set the bit first in EXECUTION
-			// order).  A clear bit without an entry is this k-mer's alone: it is a first setter and not seen -- nothing left to decide.
-			for (uint32_t li = tid; li < ln; li += BT) {
-				const uint32_t w = lb[li], bl = w & 255u, um = (w >> 26) & 15u;
-				const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
-				const uint32_t q0 = bl * 512u + b.b0, q1 = bl * 512u + b.b1, q2 = bl * 512u + b.b2, q3 = bl * 512u + b.b3;
-				const uint32_t c0 = fs[fs32_slot(q0, fs_mask)], c1 = fs[fs32_slot(q1, fs_mask)], c2 = fs[fs32_slot(q2, fs_mask)], c3 = fs[fs32_slot(q3, fs_mask)];
-				uint32_t todo = ((uint32_t)(c0 != FS32_EMPTY) | ((uint32_t)(c1 != FS32_EMPTY) << 1) | ((uint32_t)(c2 != FS32_EMPTY) << 2) | ((uint32_t)(c3 != FS32_EMPTY) << 3)) & um;
-				bool und = todo == um; // (a home slot that is empty: no entry for that bit)
-				if (todo) {
-					const uint32_t idx = la[li];
-					const uint32_t p01 = b.b0 | (b.b1 << 16), p23 = b.b2 | (b.b3 << 16);
-					while (todo) {
-						const int j = __ffs((int)todo) - 1;
-						todo &= todo - 1;
-						const uint32_t bj = ((j & 2 ? p23 : p01) >> ((j & 1) << 4)) & 0xffffu;
-						und &= fs32_compete(fs, fs_mask, bl * 512u + bj, li, idx, la);
-					}
-				}
-				if (und) lb[li] = w | B3_UND;
-			}
-			__syncthreads();
-			// ---- pass C: seen iff an earlier k-mer of the batch is the first setter of each of its clear bits
-			for (uint32_t li0 = 0; li0 < ln; li0 += BT) {
-				const uint32_t li = li0 + tid;
-				bool seen = false;
-				uint32_t w = 0;
-				if (li < ln) {
-					w = lb[li];
-					if (w & B3_UND) {
-						const uint32_t bl = w & 255u, um = (w >> 26) & 15u;
-						const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
-						bool first = false;
-						if (um & 1u) first |= fs32_lookup(fs, fs_mask, bl * 512u + b.b0) == li;
-						if (um & 2u) first |= fs32_lookup(fs, fs_mask, bl * 512u + b.b1) == li;
-						if (um & 4u) first |= fs32_lookup(fs, fs_mask, bl * 512u + b.b2) == li;
-						if (um & 8u) first |= fs32_lookup(fs, fs_mask, bl * 512u + b.b3) == li;
-						seen = !first;
-					}
-					if (A.seen_out) A.seen_out[la[li]] = seen ? 2 : 1;
-				}
-				const unsigned long long vote = __ballot(seen);
-				if (vote) { // (wave-uniform) the seen k-mers of this wave take consecutive slots behind what pass 1 emitted
-					uint32_t o = 0;
-					if (lane == 0) o = atomicAdd(&s_emit_n, (uint32_t)__popcll(vote));
-					o = __builtin_amdgcn_readfirstlane(o);
-					if (seen) {
-						const RecW<3> r = rec_load<3>(recs + (uint64_t)lc[li] * 3);
-						ho_base[o + (uint32_t)__popcll(vote & ((1ULL << lane) - 1))] = entry3(r.d[0], r.d[1]);
-					}
-				}
-			}
-		} else if (A.seen_out) {
-			for (uint32_t li = tid; li < ln; li += BT) A.seen_out[la[li]] = 1; // nobody shares a clear bit: every listed k-mer is a first setter
-		}
-		dirty = ln != 0;
-		__syncthreads();
-	} else {
-		// ---- slow path (as in k_bloom): first-setter table in HBM, one locked slice of the pool
-		const int nh = 4;
-		uint64_t want = (uint64_t)n * nh * 2;
-		const uint64_t lim = (uint64_t)(1u << P.R) * 512 * 2;
-		if (want > lim) want = lim;
-		uint32_t cap = 1024; while (cap < want) cap <<= 1;
-		// (pass 1's emits are discarded: the region starts again from the pre-batch state, every seen k-mer is emitted below)
-		if (tid == 0) {
-			uint32_t sl = f & (A.pool_slices - 1);
-			while (atomicCAS(&A.pool[sl], 0ULL, 1ULL) != 0ULL) sl = (sl + 1) & (A.pool_slices - 1);
-			s_pool_off = sl; s_emit_n = 0;
-			atomicAdd(&A.stats[ST_SLOW_BUCKETS], 1ULL);
-		}
-		{
-			const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
-			uint4 *dst = reinterpret_cast<uint4 *>(region);
-			for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
-		}
-		__syncthreads();
-		unsigned long long *gfs = A.pool + A.pool_slices + (uint64_t)s_pool_off * lim;
-		for (uint32_t i = tid; i < cap; i += BT) gfs[i] = FS_EMPTY;
-		__threadfence();
-		__syncthreads();
-		const uint32_t gmask = cap - 1;
-		for (uint32_t i = tid; i < n; i += BT) {
-			const RecW<3> r = rec_load<3>(recs + (uint64_t)i * 3);
-			const uint32_t w = addr3(r.d[0], r.d[1]), bl = w & 255u;
-			uint32_t z = (w >> 8) & 511u;
-			for (int j = 0; j < nh; ++j) {
-				const uint32_t b = bloom_next(z, w >> 17);
-				if (!((region[b3_word(bl, b)] >> (b & 31)) & 1u)) fs_insert<true>(gfs, gmask, bl * 512 + b, r.d[2], gmask);
-			}
-		}
-		__threadfence();
-		__syncthreads();
-		for (uint32_t i0 = 0; i0 < n; i0 += BT) {
-			const uint32_t i = i0 + tid;
-			bool seen = false;
-			RecW<3> r; r.d[0] = r.d[1] = r.d[2] = 0;
-			if (i < n) {
-				r = rec_load<3>(recs + (uint64_t)i * 3);
-				const uint32_t w = addr3(r.d[0], r.d[1]), bl = w & 255u;
-				uint32_t z = (w >> 8) & 511u; bool first = false, unresolved = false;
-				for (int j = 0; j < nh; ++j) {
-					uint32_t b = bloom_next(z, w >> 17), fi;
-					if (fs_lookup<true>(gfs, gmask, bl * 512 + b, fi)) { // has an entry <=> was clear before the batch
-						unresolved = true; first |= (fi == r.d[2]);
-						atomicOr(&region[b3_word(bl, b)], 1u << (b & 31));
-					}
-				}
-				seen = !unresolved || !first;
-				if (A.seen_out) A.seen_out[r.d[2]] = seen ? 2 : 1;
-			}
-			const unsigned long long vote = __ballot(seen);
-			if (vote) {
-				uint32_t o = 0;
-				if (lane == 0) o = atomicAdd(&s_emit_n, (uint32_t)__popcll(vote));
-				o = __builtin_amdgcn_readfirstlane(o);
-				if (seen) ho_base[o + (uint32_t)__popcll(vote & ((1ULL << lane) - 1))] = entry3(r.d[0], r.d[1]);
-			}
-		}
-		__syncthreads();
-		if (tid == 0) { __threadfence(); atomicExch(&A.pool[s_pool_off], 0ULL); } // release the slice
-	}
-#ifdef BFCG_MEASURE
-	if (timing) tq[3] = clock64();
-#endif
-	if (dirty) { // write the region back
-		uint4 *dst = reinterpret_cast<uint4 *>(g_region);
-		const uint4 *src = reinterpret_cast<const uint4 *>(region);
-		for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
-	}
-#ifdef BFCG_MEASURE
-	if (timing) tq[4] = clock64();
-#endif
-	if (tid == 0) { // every seen k-mer was emitted exactly once: the log's fill is the count
-		const uint32_t ns = s_emit_n;
-		if (ns) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)ns);
-		if (ho_log) { A.ho_cur[f] = ho_cur0 + ns; A.ho_mark[f] = ho_cur0 + ns; }
-		else if (A.agg_cnt) A.agg_cnt[f] = ns;
-	}
-#ifdef BFCG_MEASURE
-	if (timing) {
-		tq[5] = clock64();
-		for (int t = 0; t < 5; ++t) atomicAdd(&A.stats[10 + t], (unsigned long long)(tq[t + 1] - tq[t]));
-		atomicAdd(&A.stats[15], (unsigned long long)(tq[6] - tq[2])); // pass A alone (part of slot 12)
-	}
-#endif
-	(void)s_pad3;
-}
-
 // apply the aggregated k-mers of every bucket.  WALK = false: one thread per slot of agg_out (full occupancy; best up to ~2^18 regions);
 // WALK = true: a wave walks COMMIT_RPW regions, lane j takes entries j, j+64, ... (at 2^20 regions a thread per slot launches a million
 // nearly empty waves: 12.5 instead of 9 ms per batch on config c4)
@@ -2405,10 +1879,10 @@ template <int BT>
 __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
-	__shared__ uint32_t s_new;
+	__shared__ uint32_t s_new[8], s_mark[8]; // (HO_MAX_PAGES, bfcg_ctx.hip)
 	const uint32_t f = blockIdx.x;
 	const bool log = A.ho_stride != 0;
-	const uint32_t pages = log ? A.ho_pages : 1u;
+	const uint32_t pages = log ? (A.ho_pages < 8u ? A.ho_pages : 8u) : 1u;
 	uint32_t n;
 	const unsigned long long *recs;
 	if (log) { n = A.ho_mark[(size_t)(pages - 1) * A.ho_mark_stride + f]; recs = A.ho + (uint64_t)f * A.ho_stride; }
@@ -2423,6 +1897,16 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	const uint32_t slots = 1u << P.seg_shift, mask = slots - 1;
 	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift);
 	const SegGeom G = seg_geom(P);
+	// Round 4: everything a page needs is requested BEFORE the segment is staged -- every page's end mark (one lane each, not one dependent
+	// load per page in front of its barrier) and a thread's first two entries -- and a page costs one barrier, not two (a counter of new keys
+	// per page instead of one that is cleared in between).  With 64 KiB segments (config c4: 1024 threads, ~1.2 entries per thread and page)
+	// a page was two exposed memory latencies and two barriers for a microsecond of upserts: 22 ms per batch beside 23 ms for the stream.
+	if (threadIdx.x < 8) {
+		s_new[threadIdx.x] = 0;
+		s_mark[threadIdx.x] = threadIdx.x < pages ? (log ? A.ho_mark[(size_t)threadIdx.x * A.ho_mark_stride + f] : n) : n;
+	}
+	uint32_t j = threadIdx.x;
+	const unsigned long long pre0 = j < n ? recs[j] : 0ULL, pre1 = j + BT < n ? recs[j + BT] : 0ULL;
 	// few k-mers for a large segment: touch their lines only (this workgroup alone owns the segment, the atomics order its own lanes)
 	const bool direct = (uint64_t)n * 16 < slots;
 	// Segments up to 2^12 slots keep a 32-bit counter pair per slot behind the segment in LDS: an occurrence of a key that is already there is ONE
@@ -2436,41 +1920,62 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
 		if (use_cnt) for (uint32_t i = threadIdx.x; i < slots; i += BT) lcnt[i] = 0;
 	}
-	uint32_t total_new = 0, beg = 0;
-	for (uint32_t pg = 0; pg < pages; ++pg) {
-		const uint32_t end = log ? A.ho_mark[(size_t)pg * A.ho_mark_stride + f] : n;
-		if (threadIdx.x == 0) s_new = 0;
-		__syncthreads(); // (the segment is staged / the page before is applied)
-		uint32_t n_new = 0;
-		for (uint32_t j = beg + threadIdx.x; j < end; j += BT) {
-			const unsigned long long v = recs[j];
-			const uint64_t id = v >> 1;
-			const uint32_t hi = (uint32_t)(v & 1);
-			int r;
-			if (use_cnt) { // find or claim the slot; count in the counter pair
-				r = -1;
-				uint32_t p = seg_home(id) & mask;
-				for (uint32_t probe = 0; probe <= mask; ++probe, p = (p + 1) & mask) {
+	__syncthreads(); // (the segment is staged, the marks are there)
+	if (use_cnt) {
+		// Entries and probes in ONE loop (round 4): a lane whose entry is done takes its next one while its neighbours still probe, so a wave runs
+		// as many probe steps as its busiest LANE needs for all its entries, not the sum over entries of the longest probe among 64 lanes (at 60 %
+		// load a key sits 2 slots from home on average, but the longest of 64 probes is 8 - 10: the counter passes showed 130 lane-instructions
+		// per upsert).  The entries two and three ahead are already requested (v1, v2): a lane never waits for memory inside the loop.
+		unsigned long long v0 = pre0, v1 = pre1, v2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL;
+		uint32_t p = seg_home(v0 >> 1) & mask, probes = 0;
+		for (uint32_t pg = 0; pg < pages; ++pg) {
+			const uint32_t end = s_mark[pg];
+			uint32_t n_new = 0;
+			while (__any(j < end)) {
+				if (j < end) {
+					const uint64_t id = v0 >> 1;
+					const uint32_t hi = (uint32_t)(v0 & 1);
 					unsigned long long cur = lseg[p];
+					bool done = false;
 					if (cur == 0) {
 						cur = atomicCAS(&lseg[p], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); // (the creating call is the slot's count 1)
-						if (cur == 0) { r = 1; break; }
+						if (cur == 0) { ++n_new; done = true; }
 					}
-					if ((cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); r = 0; break; }
+					if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+					if (!done) {
+						p = (p + 1) & mask;
+						if (++probes > mask) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); done = true; } // (the segment is full)
+					}
+					if (done) { // this lane's next entry
+						j += BT; v0 = v1; v1 = v2;
+						v2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL;
+						p = seg_home(v0 >> 1) & mask; probes = 0;
+					}
 				}
-			} else r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
+			}
+			for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+			if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new[pg], n_new);
+			__syncthreads(); // (the page is applied: the keys it created are its own -- bfc_count's `# distinct k-mers` lines stay exact per chunk)
+		}
+	} else {
+	uint32_t k = 0; // entries this thread has applied
+	for (uint32_t pg = 0; pg < pages; ++pg) {
+		const uint32_t end = s_mark[pg];
+		uint32_t n_new = 0;
+		for (; j < end; j += BT, ++k) {
+			const unsigned long long v = k == 0 ? pre0 : k == 1 ? pre1 : recs[j];
+			const uint64_t id = v >> 1;
+			const uint32_t hi = (uint32_t)(v & 1);
+			const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
 			if (r > 0) ++n_new;
 			else if (r < 0) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); }
 		}
 		for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
-		if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new, n_new);
-		__syncthreads();
-		const uint32_t pn = s_new;
-		total_new += pn;
-		if (threadIdx.x == 0 && pn && A.ho_keys) atomicAdd(&A.ho_keys[(size_t)pg * ST_SLOTS + (f & (ST_SLOTS - 1))], (unsigned long long)pn);
-		beg = end;
+		if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new[pg], n_new);
+		__syncthreads(); // (the page is applied: the keys it created are its own -- bfc_count's `# distinct k-mers` lines stay exact per chunk)
 	}
-	if (use_cnt) { // the counters into their slots (after the last page's barrier)
+	}
+	if (use_cnt) { // the counters into their slots (behind the last page's barrier)
 		for (uint32_t i = threadIdx.x; i < slots; i += BT) {
 			const uint32_t c = lcnt[i];
 			if (c) {
@@ -2486,10 +1991,14 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 		const uint4 *src = reinterpret_cast<const uint4 *>(lseg);
 		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
 	}
-	if (threadIdx.x == 0) {
-		if (total_new) atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_KEYS], (unsigned long long)total_new);
-		if (log) A.ho_cur[f] = 0; // the log is empty again
+	if (threadIdx.x < pages) { // the keys page j created, slotted
+		const uint32_t pn = s_new[threadIdx.x];
+		if (pn) {
+			if (A.ho_keys) atomicAdd(&A.ho_keys[(size_t)threadIdx.x * ST_SLOTS + (f & (ST_SLOTS - 1))], (unsigned long long)pn);
+			atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_KEYS], (unsigned long long)pn);
+		}
 	}
+	if (threadIdx.x == 0 && log) A.ho_cur[f] = 0; // the log is empty again
 }
 
 // grow: segment f of 2^old_shift slots -> 2^P.seg_shift slots, rebuilt in LDS (all keys are distinct, the new segment is at most half full)
@@ -2949,7 +2458,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		A.ho = B.ho; A.ho_stride = B.ho_stride; A.ho_cur = B.ho_cur; A.ho_mark = B.ho_stride ? B.ho_mark + (size_t)B.ho_page * B.ho_mark_stride : nullptr;
 		bool f3 = false;
 		if constexpr (RW == 3) {
-			if (P.b3 && !P.dedupe) { f3 = true; hipLaunchKernelGGL((k_bloom3<512, 4>), dim3(nfine), dim3(512), lds, st, P, A); } // (cold batches with copies resolved by class stay with k_bloom)
+			if (P.b3 && !P.dedupe) { f3 = true; run_bloom3(P, A, nfine, lds, st); } // (bfcg_bloom3.hip; cold batches with copies resolved by class stay with k_bloom)
 			else if (P.n_hashes == 4 && bloom_fast3(P)) { f3 = true; hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>), dim3(nfine), dim3(512), lds, st, P, A); }
 		}
 		if (f3) ;
@@ -3044,7 +2553,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	if constexpr (RW == 3) { e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; }
-	if constexpr (RW == 3) { e = hipFuncSetAttribute((const void *)k_bloom3<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; }
+	if constexpr (RW == 3) { e = set_bloom3_lds_attr(lds); if (e != hipSuccess) return e; }
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;

@@ -39,6 +39,10 @@ CASES = {
     "c5s": dict(gen=dict(seed=5, G=20_000_000, cov=30.0), k=51, b=37, fm=1),
     # c4's parameters (`-s 3g`: k=33, -b37, table mode) on the same small read set
     "c4s": dict(gen=dict(seed=5, G=20_000_000, cov=30.0), k=33, b=37, fm=0),
+    # an EIGHTH of c4 itself (round 4): `-s 3g` => k=33, -b37 on a 387.5 Mbp genome (bfcgen seed 4) at 30x -- 77.5 M reads, 9.1 G k-mers, 2^20 regions
+    # loaded as a whole GPU's share of the 8-GPU configuration would be; ~2.5 h of one core and ~35 GB here.  bench.py's secondary `c4e` and
+    # tests/test_gpu_baseline_shapes.py hold the GPU path to it
+    "c4e": dict(gen=dict(seed=4, G=387_500_000, cov=30.0), k=33, b=37, fm=0),
 }
 
 
