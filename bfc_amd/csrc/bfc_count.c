@@ -104,10 +104,15 @@ static void print_progress(bfcg_ctx_t *ctx, bfcg_group_t *grp, const bfc_opt_t *
 	int n_keys = 63;
 	if (grp) n_keys = bfcg_group_progress(grp, 0, &final, keys, 63); /* several GPUs: a "call" is a global batch, the keys are the ranks' sums */
 	else bfcg_progress(ctx, 0, &final, keys, 63);
-	while (*lo != hi && pend_call[*lo & 63] <= final && final - pend_call[*lo & 63] < (uint64_t)n_keys) {
+	while (*lo != hi && pend_call[*lo & 63] <= final && n_keys > 0) {
 		const double rt = now_real() - t0, eff = 100. * now_cpu() / (rt + 1e-6);
+		/* keys[a] = distinct keys after the call `a` calls before the last complete one.  A batch that has fallen out of that window (the
+		 * library cut it into many calls, or nobody asked for a while) is printed with the oldest count still known -- never left waiting,
+		 * which would stall every line behind it and let the 64-entry ring of pending batches wrap */
+		uint64_t age = final - pend_call[*lo & 63];
+		if (age >= (uint64_t)n_keys) age = (uint64_t)n_keys - 1;
 		if (!opt->filter_mode)
-			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, pend_seqs[*lo & 63], (long)keys[final - pend_call[*lo & 63]]);
+			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences; # distinct k-mers: %ld\n", "bfc_count_cb", rt, eff, pend_seqs[*lo & 63], (long)keys[age]);
 		else
 			fprintf(stderr, "[M::%s @%.1f*%.1f%%] processed %d sequences\n", "bfc_count_cb", rt, eff, pend_seqs[*lo & 63]);
 		++*lo;

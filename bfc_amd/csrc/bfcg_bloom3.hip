@@ -58,7 +58,7 @@ template <int BT, int PF>
 __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_emit_n, s_fs_used, s_pad3[3];
+	__shared__ uint32_t s_list_n, s_ovf, s_pool_off, s_emit_n, s_fs_used, s_wb_n, s_pad3[2];
 	const uint32_t f = blockIdx.x;
 	const bool ho_log = A.ho_stride != 0;
 	if (batch_poisoned(A)) { if (ho_log && threadIdx.x == 0) A.ho_mark[f] = A.ho_cur[f]; return; } // (an empty page: the batch will be replayed)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 		for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
 		uint4 *f4 = reinterpret_cast<uint4 *>(fs);
 		for (uint32_t i = tid; i < P.fs_cap / 4; i += BT) f4[i] = make_uint4(FS32_EMPTY, FS32_EMPTY, FS32_EMPTY, FS32_EMPTY);
-		if (tid == 0) { s_list_n = 0; s_emit_n = 0; s_ovf = 0; s_fs_used = 0; }
+		if (tid == 0) { s_list_n = 0; s_emit_n = 0; s_ovf = 0; s_fs_used = 0; s_wb_n = 0; }
 	}
 	__syncthreads();
 #ifdef BFCG_MEASURE
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 			uint32_t cm = (b3_bit(o0, b.b0) | (b3_bit(o1, b.b1) << 1) | (b3_bit(o2, b.b2) << 2) | (b3_bit(o3, b.b3) << 3)) & um;
 			if (cm) { // contended bits: file order decides them
 				*(volatile uint32_t *)&s_fs_used = 1;
+				__hip_atomic_fetch_or(&region[bl * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (the block's mark for pass B)
 				const uint32_t idx = la[li];
 				const uint32_t p01 = b.b0 | (b.b1 << 16), p23 = b.b2 | (b.b3 << 16);
 				while (cm) {
@@ -222,7 +223,11 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 		if (s_fs_used) {
 			// ---- pass B: every toucher of a bit that has an entry competes for it (this brings in the k-mer that set the bit first in EXECUTION
 			// order).  A clear bit without an entry is this k-mer's alone: it is a first setter and not seen -- nothing left to decide.
-			for (uint32_t li = tid; li < ln; li += BT) {
+			// Only k-mers of blocks in which pass A met a contended bit can have such a bit (a bit and its touchers share the block): pass A marks
+			// those blocks in their lock byte (bit 0 of the block's first word: positions below 8 are never a k-mer's, bbf.c:37; cleared again before the
+			// region goes back), the k-mers of marked blocks -- a third of the list once the filter is warm -- are gathered in a worklist (the free
+			// tail of the record-index array), and the probing runs DENSE over that worklist instead of in every wave for a few of its lanes.
+			auto compete_entry = [&](uint32_t li) {
 				const uint32_t w = lb[li], bl = w & 255u, um = (w >> 26) & 15u;
 				const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
 				const uint32_t q0 = bl * 512u + b.b0, q1 = bl * 512u + b.b1, q2 = bl * 512u + b.b2, q3 = bl * 512u + b.b3;
@@ -240,15 +245,42 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 					}
 				}
 				if (und) lb[li] = w | B3_UND;
-			}
-			__syncthreads();
-			// ---- pass C: seen iff an earlier k-mer of the batch is the first setter of each of its clear bits
+			};
+			unsigned short *const wb = lc + ln;
+			const uint32_t wb_cap = P.list_cap - ln;
 			for (uint32_t li0 = 0; li0 < ln; li0 += BT) {
 				const uint32_t li = li0 + tid;
-				bool seen = false;
-				uint32_t w = 0;
+				bool want = false;
 				if (li < ln) {
-					w = lb[li];
+					want = (region[(lb[li] & 255u) * 16u] & 1u) != 0;
+					if (!want && A.seen_out) A.seen_out[la[li]] = 1;
+				}
+				const unsigned long long vote = __ballot(want);
+				if (vote) {
+					uint32_t o = 0;
+					if (lane == 0) o = atomicAdd(&s_wb_n, (uint32_t)__popcll(vote));
+					o = __builtin_amdgcn_readfirstlane(o);
+					if (want) {
+						const uint32_t slot = o + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
+						if (slot < wb_cap) wb[slot] = (unsigned short)li;
+						else compete_entry(li); // (no room in the worklist: at once; pass C then walks the whole list)
+					}
+				}
+			}
+			__syncthreads();
+			const uint32_t wb_all = s_wb_n, wb_n = wb_all < wb_cap ? wb_all : wb_cap;
+			for (uint32_t t = tid; t < wb_n; t += BT) compete_entry(wb[t]);
+			__syncthreads();
+			// ---- pass C: seen iff an earlier k-mer of the batch is the first setter of each of its clear bits
+			const bool wl_ok = wb_all <= wb_cap;
+			const uint32_t cn = wl_ok ? wb_n : ln;
+			for (uint32_t t0 = 0; t0 < cn; t0 += BT) {
+				const uint32_t t = t0 + tid;
+				uint32_t li = 0;
+				bool seen = false;
+				if (t < cn) {
+					li = wl_ok ? (uint32_t)wb[t] : t;
+					const uint32_t w = lb[li];
 					if (w & B3_UND) {
 						const uint32_t bl = w & 255u, um = (w >> 26) & 15u;
 						const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
@@ -272,6 +304,7 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 					}
 				}
 			}
+			for (uint32_t i = tid; i < (1u << P.R); i += BT) region[i * 16u] &= ~0xffu; // the blocks' marks: the lock byte goes back as it came, zero
 		} else if (A.seen_out) {
 			for (uint32_t li = tid; li < ln; li += BT) A.seen_out[la[li]] = 1; // nobody shares a clear bit: every listed k-mer is a first setter
 		}

@@ -83,6 +83,7 @@ struct bfcg_ctx {
 	uint32_t *cnt2; uint32_t cap2; uint64_t recs2_n; // one-pass level 2 (region slabs); records recs2 / stream_out hold
 	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; const void *recv; int mg; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
 	int mg_op2_ok, mg_op2, mg_op2_allowed; uint32_t *mg_seg[4];  // a rank of a multi-GPU run: level 2 (its own stage B) in one pass; copies of the queued batches' segment sizes
+	int mg_slab_ok; int mg_seg_slab[4]; // ... level 1 in one pass into per-destination slabs (bfcg_mg_scatter_slabs); which queued copies are slab fills
 	uint64_t n_replayed;
 	int reused;                  // a reset has followed counted batches: this context counts one data set after the other
 	int seg_no_grow;             // the next segment size does not fit (memory / LDS): grow only when a segment overflows or the load passes 85 %
@@ -280,7 +281,6 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		c->onepass_ok = n_ranks == 1 && P.F2 > 0 && !(e && atoi(e) == 0); // level 2 gathers a bucket's slabs: filters of 2^26 bits and more
 		uint64_t cap = (B.max_kmers + B.max_kmers / 8) / ((uint64_t)nb1 * 8) + 1;
 		while (cap * nb1 * 8 > 0xffffffffULL) --cap;
-		{ const char *w = getenv("BFCG_S1_WC"); if (w && atoi(w) > 0 && cap >= 64) cap &= ~31ULL; } // k_scatter1_wc stores whole 16-byte pieces: slabs of whole lines
 		c->op_cap = (uint32_t)cap;
 		// a slab should expect ~1000 records or more: below that its fill scatters by more than the head room, and the batch would be replayed
 		c->op_min_pos = (e = getenv("BFCG_ONEPASS_MIN_TILES")) ? (uint64_t)atoi(e) * 4096 : (uint64_t)nb1 * 8 * 1024;
@@ -298,32 +298,34 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		const char *e = getenv("BFCG_ONEPASS");
 		c->mg_op2_ok = P.F2 > 0 && !(e && atoi(e) == 0); // (also the single rank of a group of one: bench.py with BFC_BENCH_FORCE_DIST, tests)
 	}
-	if (c->onepass_ok) {
+	{ const char *e = getenv("BFCG_MG_SLABS"); c->mg_slab_ok = P.F2 > 0 && !(e && atoi(e) == 0); } // (a rank's level 1 in one pass: bfcg_mg_scatter_slabs; used by groups only)
+	if (c->onepass_ok || c->mg_slab_ok) {
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->op_cursor[b], sizeof(uint32_t) * (8 * nb1 * 32 + 32))); // (+ the tile counter of k_scatter1)
 			HIPCKN(hipMalloc(&c->op_seg[b], sizeof(uint32_t) * ((size_t)25 * nb1 + 8)));
 		}
 	}
-	if (c->onepass_ok || c->mg_op2_ok) {
+	if (c->onepass_ok || c->mg_op2_ok || c->mg_slab_ok) {
 		for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_flags[b], 4 * sizeof(uint32_t)));
 		// per batch slot b: op_flags[4 b + 0] a level-1 slab overflowed (raised on stage A's stream), [4 b + 2] a region's slab (stage B's stream);
 		// op_flags[8]: the run is poisoned (k_seal, stage B's stream only) -- a batch's stage B never reads what another batch's stage A writes
 		HIPCKN(hipMalloc(&c->op_flags, OP_FLAG_WORDS * sizeof(uint32_t)));
 		HIPCKN(hipMemset(c->op_flags, 0, OP_FLAG_WORDS * sizeof(uint32_t)));
 	}
-	if (c->mg_op2_ok) for (int i = 0; i < 4; ++i) c->mg_seg[i] = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_ranks * (size_t)(nb1 >> log2n));
+	if (c->mg_op2_ok) for (int i = 0; i < 4; ++i) c->mg_seg[i] = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_ranks * (size_t)(nb1 >> log2n) * 8); // (slab fills: 8 per source and bucket)
 	B.recs1 = c->recs1[0];
 	c->recs2_n = c->recv_cap;
-	if (c->onepass_ok || c->mg_op2_ok) { // level 2 in one pass: a slab per region, 9/8 of the mean of a full batch's positions + 64 records (k-mers are ~0.8 of the positions)
+	if (c->onepass_ok || c->mg_op2_ok || c->mg_slab_ok) { // level 2 in one pass: a slab per region, 9/8 of the mean of a full batch's positions + 64 records (k-mers are ~0.8 of the positions)
 		const char *e = getenv("BFCG_ONEPASS2");
 		const uint64_t cap2 = (B.max_kmers + B.max_kmers / 8) / (uint64_t)nfine + 64, n2 = cap2 * (uint64_t)nfine + bfcg_tile_of_rw(c->rw / 4);
 		if (!(e && atoi(e) == 0) && n2 < 0xffffffffULL) {
 			c->cap2 = (uint32_t)cap2; c->recs2_n = n2 > c->recv_cap ? n2 : c->recv_cap;
 			HIPCKN(hipMalloc(&c->cnt2, sizeof(uint32_t) * (size_t)nfine));
-		} else c->mg_op2_ok = 0;
+		} else { c->mg_op2_ok = 0; HIPCKN(hipMalloc(&c->cnt2, sizeof(uint32_t) * (size_t)nfine)); } // (the counters also serve the two-pass level 2: BatchBufs.cnt_live)
+		B.cnt_live = c->cnt2;
 	}
 	if (P.F2 > 0) HIPCKN(hipMalloc(&B.recs2, c->recs2_n * c->rw));
-	c->seg_words = (size_t)4 * nb1 + 8;
+	c->seg_words = (size_t)25 * nb1 + 8; // (slab mode: 8 segments per source and bucket)
 	{ HIPCKN(hipMalloc(&c->d_seg, sizeof(uint32_t) * 2 * c->seg_words)); HIPCKN(hipHostMalloc(&c->h_seg, sizeof(uint32_t) * 2 * c->seg_words)); }
 	HIPCKN(hipMalloc(&B.bloom, c->bloom_bytes));
 	P.f_base = (uint32_t)c->rank * (uint32_t)nfine;
@@ -409,6 +411,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 
 static int drain(bfcg_ctx_t *c);
 static int replay_poisoned(bfcg_ctx_t *c);
+static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, uint32_t slab_cap, hipEvent_t *wait, int n_wait);
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats);
 static int same_block_offset(bfcg_ctx_t *c, int b, const uint8_t *d_seq, const uint8_t **d_qual, uint64_t n_pos, hipStream_t s);
@@ -594,9 +597,10 @@ static int replay_poisoned(bfcg_ctx_t *c)
 	for (int i = 0; i < n; ++i) if (q[i].mg) --c->call_no; // (bfcg_mg_process_ev numbers its calls itself)
 	for (int i = 0; i < n; ++i) {
 		if (q[i].mg) { // a rank's stage B: what it received is still in its receive buffer (the exchange of the next batch has not begun: this thread starts it)
-			const size_t w = (size_t)c->n_ranks * (size_t)((1 << c->P.F1) >> c->log2n);
+			const int slab = c->mg_seg_slab[q[i].mg - 1];
+			const size_t w = (size_t)c->n_ranks * (size_t)((1 << c->P.F1) >> c->log2n) * (slab ? 8 : 1);
 			seg.assign(c->mg_seg[q[i].mg - 1], c->mg_seg[q[i].mg - 1] + w);
-			if (bfcg_mg_process_ev(c, q[i].recv, seg.data(), 0, 0) != 0) return -1;
+			if (mg_process_any(c, q[i].recv, seg.data(), slab ? c->op_cap : 0u, 0, 0) != 0) return -1;
 		} else if (enqueue_batch(c, q[i].seq, q[i].qual, q[i].n_pos, 0, 1) != 0) return -1;
 		if (drain(c) != 0) return -1;
 		++c->n_replayed;
@@ -819,7 +823,11 @@ extern "C" int bfcg_mg_info(bfcg_ctx_t *c, int out[4])
 
 // Stage A of a global batch on stream stA: it runs UNDER stage B of the previous batch (stream st), which bfcg_mg_process left
 // running.  Returns when the records are in d_send and their per-bucket counts on the host; the caller may start the exchange.
-extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts)
+static int mg_scatter2(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts, int no_kstats);
+extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts) { return mg_scatter2(c, d_seq, d_qual, n_pos, d_send, counts, 0); }
+// (a batch whose one-pass stage A overflowed a slab, repeated: its k-mers were counted the first time)
+extern "C" int bfcg_mg_scatter_again(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts) { return mg_scatter2(c, d_seq, d_qual, n_pos, d_send, counts, 1); }
+static int mg_scatter2(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts, int no_kstats)
 {
 	const int nb1 = 1 << c->P.F1, b = c->cur;
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
@@ -831,7 +839,9 @@ extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_
 	BatchBufs Bt = c->B;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1;
 	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, c->stA) != 0) return -1;
-	run_stage_a(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
+	KParams Pa = c->P;
+	Pa.no_kstats = no_kstats;
+	run_stage_a(Pa, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
 	HIPCK(hipGetLastError());
 	uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (nb1 + 1));
 	hipError_t e = hipMemcpyAsync(tmp, Bt.start1, sizeof(uint32_t) * (nb1 + 1), hipMemcpyDeviceToHost, c->stA);
@@ -842,21 +852,71 @@ extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_
 	return 0;
 }
 
+// Stage A of a global batch in ONE pass (round 4; bfcg_mg.hip's slab mode): K1 once, the records into 8 slabs of `slab capacity` records per
+// level-1 bucket in d_send (bucket-major: a destination's buckets are one contiguous range of slabs, sent as it is -- the unfilled ends of the
+// slabs travel too), except the rank's OWN buckets, whose slabs lie own_delta records further on: in the receive buffer the group put behind the
+// send buffer, where this rank's block belongs -- no self-copy.  fills[8 * 2^F1]: records in every slab (bucket-major, XCD-minor), on the host
+// when the call returns; *overflow: a slab was too small (skewed input) -- nothing of this batch may be used, the group falls back to
+// bfcg_mg_scatter for it.  count_kmers = 0: a repeated stage A of a batch whose k-mers were counted already.
+extern "C" int bfcg_mg_slab_info(bfcg_ctx_t *c, uint32_t out[2]) { out[0] = c->op_cap; out[1] = (uint32_t)(c->mg_slab_ok && c->op_cursor[0] != 0); return 0; }
+extern "C" int bfcg_mg_scatter_slabs(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *fills, int *overflow)
+{
+	const int nb1 = 1 << c->P.F1, nb_loc = nb1 >> c->log2n, b = c->cur;
+	*overflow = 0;
+	if (!c->mg_slab_ok || !c->op_cursor[b]) return set_err("this context has no slab mode");
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	HIPCK(hipSetDevice(c->prm.device));
+	if (n_pos == 0) { // nothing to contribute to this global batch: keep the timing events defined
+		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], c->stA));
+		memset(fills, 0, sizeof(uint32_t) * (size_t)nb1 * 8); return 0;
+	}
+	BatchBufs Bt = c->B;
+	Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags + 4 * b; Bt.op_cap = c->op_cap; Bt.cap2 = c->cap2;
+	Bt.op_own_lo = (uint32_t)c->rank * (uint32_t)nb_loc; Bt.op_own_n = (uint32_t)nb_loc; Bt.op_own_delta = own_delta;
+	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, c->stA) != 0) return -1;
+	run_stage_a_onepass(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
+	HIPCK(hipGetLastError());
+	std::vector<uint32_t> tmp((size_t)8 * nb1);
+	hipError_t e = hipMemcpyAsync(tmp.data(), Bt.op_seg + (size_t)8 * nb1, sizeof(uint32_t) * (size_t)8 * nb1, hipMemcpyDeviceToHost, c->stA); // the segments' ends (k_seg_setup)
+	if (e == hipSuccess) e = hipMemcpyAsync(c->h_flags[b], Bt.op_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stA);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stA);
+	if (e != hipSuccess) return set_err("reading the slabs' fill failed: %s", hipGetErrorString(e));
+	*overflow = c->h_flags[b][0] != 0;
+	for (int seg = 0; seg < 8 * nb1; ++seg) fills[seg] = *overflow ? 0u : tmp[seg] - (uint32_t)seg * c->op_cap; // (k_seg_setup: the slab of segment seg starts at seg x capacity)
+	return 0;
+}
+
 // d_recv: records for the owned level-1 buckets, source-major (rank 0's block, rank 1's block, ...), inside each block
 // grouped by bucket; seg_cnt[s * nb_loc + b] = records from source s for owned bucket b.
 // Stage B is ENQUEUED (stream st) and left running: the call returns once the PREVIOUS batch is finalised (statistics read,
 // table maintained), so the caller's next bfcg_mg_scatter and exchange overlap with it.  d_recv must stay untouched until the
 // next bfcg_mg_process (or bfcg_sync) returns: callers alternate between two receive buffers.
-extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
-extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt) { return bfcg_mg_process_ev(c, d_recv, seg_cnt, 0, 0); }
-// the same with stage B ordered behind `wait[0..n_wait)` (events of the exchange that fills d_recv, on other streams / devices): no host wait
-extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait)
+// slab_cap != 0 (bfcg_mg_process_slabs): d_recv holds, source-major, every source's SLABS for the owned buckets (8 per bucket, slab_cap records
+// each, at fixed places) and seg_cnt[(s * nb_loc + b) * 8 + x] says how far each is filled.
+static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, uint32_t slab_cap, hipEvent_t *wait, int n_wait);
+extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait) { return mg_process_any(c, d_recv, seg_cnt, 0u, wait, n_wait); }
+extern "C" int bfcg_mg_process(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt) { return mg_process_any(c, d_recv, seg_cnt, 0u, 0, 0); }
+extern "C" int bfcg_mg_process_slabs(bfcg_ctx_t *c, const void *d_recv, const uint32_t *fills, uint32_t slab_cap, hipEvent_t *wait, int n_wait) { return mg_process_any(c, d_recv, fills, slab_cap, wait, n_wait); }
+// (stage B ordered behind `wait[0..n_wait)`: events of the exchange that fills d_recv, on other streams / devices -- no host wait)
+static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, uint32_t slab_cap, hipEvent_t *wait, int n_wait)
 {
-	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, n_seg = nb_loc * N, b = c->cur;
+	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, spb = slab_cap ? N * 8 : N, n_seg = nb_loc * spb, b = c->cur;
 	HIPCK(hipSetDevice(c->prm.device));
 	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
+	if (words > c->seg_words) return set_err("internal: %zu segment words, room for %zu", words, c->seg_words);
 	uint32_t *seg_beg = c->h_seg + (size_t)b * c->seg_words, *seg_end = seg_beg + n_seg, *row_base = seg_end + n_seg, *bucket_start = row_base + n_seg + 1;
 	uint64_t off = 0, rows = 0, tot = 0;
+	if (slab_cap) {
+		for (int s = 0; s < N; ++s)
+			for (int k = 0; k < nb_loc; ++k)
+				for (int x = 0; x < 8; ++x) { // slab (source s, bucket k, XCD x) sits at its fixed place
+					const int seg = (k * N + s) * 8 + x;
+					const uint64_t at = ((uint64_t)((size_t)s * nb_loc + k) * 8 + x) * slab_cap;
+					const uint32_t fill = seg_cnt[((size_t)s * nb_loc + k) * 8 + x];
+					if (fill > slab_cap || at + fill > 0xffffffffULL) return set_err("slab of %u records holds %u", slab_cap, fill);
+					seg_beg[seg] = (uint32_t)at; seg_end[seg] = (uint32_t)at + fill; off += fill;
+				}
+	} else
 	for (int s = 0; s < N; ++s)
 		for (int k = 0; k < nb_loc; ++k) { // position of (source s, bucket k) in the receive buffer
 			int seg = k * N + s;
@@ -868,7 +928,7 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	row_base[n_seg] = (uint32_t)rows;
 	for (int k = 0; k < nb_loc; ++k) {
 		bucket_start[k] = (uint32_t)tot;
-		for (int s = 0; s < N; ++s) tot += seg_cnt[s * nb_loc + k];
+		for (int s = 0; s < spb; ++s) tot += seg_end[k * spb + s] - seg_beg[k * spb + s];
 	}
 	bucket_start[nb_loc] = (uint32_t)tot;
 	uint32_t *d = c->d_seg + (size_t)b * c->seg_words;
@@ -891,14 +951,14 @@ extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint3
 	KParams Pm = c->P;
 	Pm.dedupe = dedupe_hint(c);
 	warm_tables(c, Pm);
-	run_stage_b(Pm, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, N, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
+	run_stage_b(Pm, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, spb, d + 2 * n_seg, d + 3 * n_seg + 1, off, c->st, c->evt[b]);
 	if (handover_end(c, Bt, b) != 0) return -1;
 	if (op2_run) { // was every region's slab large enough?  (as for a single GPU: the flag is read with the batch's snapshot, an overflow is replayed -- stage B only)
 		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
 		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
 		int free_i = 0;
 		for (;; ++free_i) { int used = 0; for (int i = 0; i < c->n_opq; ++i) used |= c->opq[i].mg == free_i + 1; if (!used) break; }
-		memcpy(c->mg_seg[free_i], seg_cnt, sizeof(uint32_t) * (size_t)N * nb_loc);
+		memcpy(c->mg_seg[free_i], seg_cnt, sizeof(uint32_t) * (size_t)N * nb_loc * (slab_cap ? 8 : 1)); c->mg_seg_slab[free_i] = slab_cap != 0;
 		bfcg_ctx::opq_t &q = c->opq[c->n_opq++];
 		q.seq = q.qual = nullptr; q.n_pos = off; q.slot = b; q.recv = d_recv; q.mg = free_i + 1;
 	}

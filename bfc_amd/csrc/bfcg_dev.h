@@ -104,6 +104,7 @@ struct BloomArgs {
 __device__ __forceinline__ void region_list(const BloomArgs &A, uint32_t f, uint32_t &rs, uint32_t &n)
 {
 	if (A.cap2) { const uint32_t c = A.cnt2[f]; rs = f * A.cap2; n = c < A.cap2 ? c : A.cap2; }
+	else if (A.cnt2) { rs = A.start[f]; n = A.cnt2[f]; } // (two-pass level 2 over slabs with dead records: a bucket's last region is followed by a gap)
 	else { rs = A.start[f]; n = A.start[f + 1] - rs; }
 }
 // A batch the one-pass partition gave up on must change nothing: the host replays it (and every batch behind it) through the two-pass one.

@@ -70,7 +70,9 @@ struct BatchBufs {
 	// flags of THIS batch's slot ([0] level 1, [2] level 2) and the run's sticky poison word (stage B's stream only), and the segment arrays level 2
 	// reads the slabs through: seg_beg[8 nb1] | seg_end[8 nb1] | row_base[8 nb1 + 1] | bucket_start[nb1 + 1]
 	uint32_t *op_cursor, *op_flags, *op_sticky, *op_seg; uint32_t op_cap;
+	uint32_t op_own_lo, op_own_n, op_own_delta; // a rank of a multi-GPU group: the slabs of its OWN buckets lie op_own_delta records further on (bfcg_kernels.hip: OnePass)
 	uint32_t *cnt2; uint32_t cap2;            // one-pass level 2: a slab of cap2 records per bloom region in recs2 and its cursor (0: two passes, start2 says where)
+	uint32_t *cnt_live;                       // two-pass level 2: the regions' record counts (k_scan2) -- start2 alone does not say them when the level-1 slabs hold dead records
 	// hand-over log of the region-owned table (bfcg_kernels.hip: BloomArgs): arena, entries per region (0: this batch's entries go to stream_out at
 	// its records' offsets and are applied at once), cursors, marks [pages][ho_mark_stride], the page this batch fills, whether stage B ends with
 	// the commit of pages 0..ho_page, and the per-page key counters [pages][ST_SLOTS]

@@ -207,6 +207,15 @@ __device__ __forceinline__ uint64_t y0_drop(const RecGeom g, uint64_t y0) { retu
 __device__ __forceinline__ uint64_t y0_join(const RecGeom g, uint64_t y0c, uint32_t imp)
 { return g.n ? (y0c & ((1ULL << g.lo) - 1)) | ((uint64_t)imp << g.lo) | ((y0c >> g.lo) << (g.lo + g.n)) : y0c; }
 
+// A DEAD record (all ones) fills what a level-1 workgroup left unused of its last chunk of a slab (k_scatter1, OnePass): level 2 skips it.  For
+// 12- and 20-byte records the last dword is the file index, which is never 2^32 - 1 (a batch has fewer positions); a 16-byte record's last
+// dword mixes index, y1 and the quality flag, so there every dword is tested (a live record with y0' and y1 all ones AND the last index does not exist).
+template <int RD> __device__ __forceinline__ bool rec_dead(const RecW<RD> &w)
+{
+	if (RD == 4) return (w.d[0] & w.d[1] & w.d[2] & w.d[3]) == 0xffffffffu;
+	return w.d[RD - 1] == 0xffffffffu;
+}
+
 // pack: y0 is the FULL word (the bucket's bits are dropped here); unpack: imp = the record's (global) level-1 bucket
 template <int RD> struct Rec;
 template <> struct Rec<3> {
@@ -401,7 +410,9 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t *cnt, int nb, uint3
 // of the chunk it reserved last (thread-private: a thread owns its buckets for the kernel's life); a run goes there first and the rest into
 // a new chunk of max(chunk, rest) records, so a run is at most two pieces and a slab has no holes except the workgroups' last chunks, which
 // are filled with DEAD records (all ones: no file index is 2^32-1) that level 2 skips.  chunk <= 1: every run reserves exactly its size.
-struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; uint32_t chunk; };
+// own_n > 0 (a rank of a multi-GPU group): the slabs of buckets [own_lo, own_lo + own_n) -- the rank's OWN share of the exchange -- lie own_delta
+// records further on: in the rank's receive buffer, which the group allocates behind the send buffer, at the place its block has there.
+struct OnePass { uint32_t *cursor; uint32_t cap; uint32_t *flags; unsigned long long *stats; uint32_t chunk; uint32_t own_lo, own_n, own_delta; };
 
 // A 12-byte record from halves without 64-bit shifts (same bits as Rec<3>::pack): possible when the kept part of y0 fits one word
 // (0 < a = k - rec_n < 32), the dropped field ends below bit 32, and y1 reaches into the second word (a + k >= 32)
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 			if (i < nb1) {
 				if (!ONEPASS) gdelta[i] = gd[u] - g_ex[u];
 				else {
-					const uint32_t slab = ((uint32_t)i * 8u + xcd) * OP.cap, left = own ? c_rem[u] : 0u;
+					const uint32_t slab = ((uint32_t)i * 8u + xcd) * OP.cap + ((uint32_t)i - OP.own_lo < OP.own_n ? OP.own_delta : 0u), left = own ? c_rem[u] : 0u;
 					gdelta[i] = slab + c_ptr[u] - g_ex[u]; // (first piece: what the last chunk still holds; unused when left == 0)
 					if (g_c[u] <= left) { splitp[i] = 0xffffffffu; c_ptr[u] += g_c[u]; c_rem[u] -= g_c[u]; }
 					else {
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 #pragma unroll
 		for (int u = 0; u < NBT; ++u) {
 			const int i = threadIdx.x + u * BT;
-			if (i < nb1) for (uint32_t r = 0; r < c_rem[u]; ++r) rec_store<RW>(out + ((uint64_t)((uint32_t)i * 8u + home) * OP.cap + c_ptr[u] + r) * RW, dead);
+			if (i < nb1) for (uint32_t r = 0; r < c_rem[u]; ++r) rec_store<RW>(out + ((uint64_t)(((uint32_t)i * 8u + home) * OP.cap + ((uint32_t)i - OP.own_lo < OP.own_n ? OP.own_delta : 0u)) + c_ptr[u] + r) * RW, dead);
 		}
 	}
 	if (ONEPASS) { // the statistics k_hist1 keeps in the two-pass partition: k-mers, high-quality k-mers
@@ -682,181 +693,6 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1(KParams P, const uint8_t *__
 			unsigned long long *sl = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 			atomicAdd(&sl[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl[ST_HIGH], (unsigned long long)n_h);
 		}
-	}
-}
-
-// ------------------------------------------------------------------------------------------
-// k_scatter1_wc (BFCG_S1_WC=1; round 3, opt-in): the one-pass level 1 for 12-byte records with WRITE-COMBINING buffers instead of the tile
-// skeleton above -- profiles/round3_scatter_probe.md is the stand-alone measurement this follows.  A buffer of CAP records per level-1
-// bucket lives in LDS across the workgroup's tiles; a record takes the slot a returning LDS add on the bucket's fill hands out; a buffer
-// that has filled leaves as CAP x 12 contiguous bytes into a chunk of the workgroup's home slab that the bucket's owner thread (thread b for
-// bucket b) reserved one flush AHEAD (same per-XCD cursors on lines of their own); a record whose slot is CAP or more waits for the flush
-// and takes slot - CAP (a loop for the round in which a bucket draws more than two buffers' worth).  Three barriers per tile, no scan, no
-// staging order; the last partial buffers leave padded with dead records, which the one-pass level 2 skips (as with chunked reservations).
-// All of a workgroup's records go to its HOME XCD's slabs, also those of tiles it took from another XCD's share.
-// Same input side as k_scatter1 (aligned 16-byte blocks a round ahead, bit planes in two sets, tiles drawn per XCD); FAST geometry only
-// (scatter1_fast: bucket = bit field of y0's low word, records packed from halves), slabs of a multiple of 32 records (bfcg_ctx.hip).
-template <int TILE, int BT, int CAP, int KC>
-__global__ __launch_bounds__(BT) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
-                                                     uint32_t *__restrict__ out, OnePass OP)
-{
-	constexpr int PW = (TILE + 64) / 32 + 2, S = TILE / BT, NC16 = (TILE + 64) / 16, NCH = NC16 + 1, PIECES = CAP * 12 / 16;
-	static_assert(S * BT == TILE && NCH <= BT / 2 && CAP % 4 == 0 && (BT / 2) % 64 == 0, "tile = threads x k-mers per thread; planes and owners in the lower half; a buffer is whole 16-byte pieces");
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
-	const int nb1 = 1 << P.F1; // <= BT: thread b owns bucket b
-	uint32_t *buf = reinterpret_cast<uint32_t *>(smem1);      // nb1 buffers of CAP records
-	uint32_t *fill = buf + (size_t)nb1 * CAP * 3;             // slots handed out per bucket (>= CAP: the buffer is due)
-	uint32_t *jobs = fill + nb1, *jpos = jobs + nb1;          // this round's flushes: bucket, chunk position in its slab
-	__shared__ uint32_t planes[2 * 4 * PW];
-	__shared__ uint32_t s_njobs, s_draw[3];
-	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
-	const int b1_shift = P.R + P.F2;
-	const Pack3 PK = pack3_geom(P);
-	uint32_t n_k = 0, n_h = 0;
-	const int tid = threadIdx.x;
-	// ---- the input side: as in k_scatter1
-	const int mis = (int)((uintptr_t)seq & 15);
-	const uint8_t *const sb = seq - mis, *const qb = qual ? qual - mis : nullptr;
-	const int64_t v_end = n_pos + mis, v_last = (v_end - 1) & ~(int64_t)15;
-	uint4 pf_s = make_uint4(0, 0, 0, 0), pf_q = make_uint4(0, 0, 0, 0);
-	const int pf_c = tid < NCH ? tid : NCH - 1;
-	auto prefetch = [&](int64_t t) {
-		if (tid >= BT / 2) return; // (whole waves: the storing half holds no loads)
-		const int64_t v = t * TILE - 64 + (int64_t)pf_c * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
-		pf_s = *reinterpret_cast<const uint4 *>(sb + at);
-		if (qual) pf_q = *reinterpret_cast<const uint4 *>(qb + at);
-	};
-	auto make_planes = [&](int64_t t, uint32_t *pl) {
-		const int c = tid;
-		if (c < NCH) {
-			const int64_t v = t * TILE - 64 + (int64_t)c * 16;
-			uint4 s4 = pf_s, q4 = pf_q;
-			if (v < mis || v + 16 > v_end) {
-				const int lo = v >= mis ? 0 : mis - v >= 16 ? 16 : (int)(mis - v), hi = v_end - v >= 16 ? 16 : v_end - v <= 0 ? 0 : (int)(v_end - v);
-				const uint32_t bm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-				auto keep = [&](int d) { return (((bm >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu; };
-				const uint32_t k0 = keep(0), k1 = keep(1), k2 = keep(2), k3 = keep(3);
-				s4.x = (s4.x & k0) | (0x0a0a0a0au & ~k0); s4.y = (s4.y & k1) | (0x0a0a0a0au & ~k1); s4.z = (s4.z & k2) | (0x0a0a0a0au & ~k2); s4.w = (s4.w & k3) | (0x0a0a0a0au & ~k3);
-				q4.x &= k0; q4.y &= k1; q4.z &= k2; q4.w &= k3;
-			}
-			uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
-			bases4x(s4.x, 0, m0, m1, mn); bases4x(s4.y, 4, m0, m1, mn); bases4x(s4.z, 8, m0, m1, mn); bases4x(s4.w, 12, m0, m1, mn);
-			if (qual) {
-				const int T = P.q + 33;
-				if (T >= 1 && T <= 127) {
-					const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
-					quals4x(q4.x, 0, add, mq); quals4x(q4.y, 4, add, mq); quals4x(q4.z, 8, add, mq); quals4x(q4.w, 12, add, mq);
-				} else { quals16(q4.x, 0, P.q, mq); quals16(q4.y, 4, P.q, mq); quals16(q4.z, 8, P.q, mq); quals16(q4.w, 12, P.q, mq); }
-			} else mq = 0xffffu;
-			unsigned short *p16 = reinterpret_cast<unsigned short *>(pl);
-			if (c < NC16) {
-				p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
-				p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
-			} else { pl[0 * PW + PW - 2] = m0; pl[1 * PW + PW - 2] = m1; pl[2 * PW + PW - 2] = mn; pl[3 * PW + PW - 2] = mq; }
-		}
-		if (tid < 4) pl[tid * PW + PW - 1] = 0;
-	};
-	uint32_t *const tile_ctr = OP.cursor + (size_t)8 * nb1 * 32;
-	uint32_t draw_a = 0;
-	auto draw_issue = [&]() -> uint32_t { return draw_a < 8u ? atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u) : 0u; };
-	auto draw_settle = [&](uint32_t t) -> uint32_t {
-		while (draw_a < 8u) {
-			const uint32_t x = (blockIdx.x + draw_a) & 7u;
-			if ((int64_t)t * 8 + x < n_tiles) return t * 8u + x;
-			if (++draw_a < 8u) t = atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u);
-		}
-		return 0xffffffffu;
-	};
-	if (tid == 0) { s_draw[0] = draw_settle(draw_issue()); s_draw[1] = draw_settle(draw_issue()); s_njobs = 0; }
-	if (tid < nb1) fill[tid] = 0;
-	__syncthreads();
-	int64_t tile = s_draw[0], next_tile = s_draw[1];
-	if (tile >= n_tiles) return;
-	// ---- the output side
-	const uint32_t home = blockIdx.x & 7u;
-	uint32_t *const my_cursor = OP.cursor + ((size_t)home * nb1 + (tid < nb1 ? tid : 0)) * 32;
-	uint32_t nextpos = tid < nb1 ? atomicAdd(my_cursor, (uint32_t)CAP) : 0u; // always one chunk ahead
-	RecW<3> w[S]; uint32_t sl[S]; int bk[S];
-	auto put = [&](int j) { uint32_t o = (uint32_t)bk[j] * CAP + sl[j]; o += o << 1; asm volatile("" : "+v"(o)); buf[o] = w[j].d[0]; buf[o + 1] = w[j].d[1]; buf[o + 2] = w[j].d[2]; };
-	// Only the UPPER half of the workgroup stores: loads, atomics and stores share one in-order counter (vmcnt), and the lower half -- the
-	// buckets' owners and the threads that build the planes -- would otherwise wait for the previous round's stores whenever it waits for a
-	// prefetched block or a reserved chunk (+1.65 ms per c3 batch: profiles/round3_scatter_probe.md).  The storing waves never wait on memory.
-	constexpr int ST0 = BT / 2;
-	auto copy_out = [&](uint32_t nj) {
-		if (tid >= ST0) for (uint32_t x = tid - ST0; x < nj * PIECES; x += BT - ST0) {
-			const uint32_t j = x / PIECES, p = x - j * PIECES, b = jobs[j];
-			reinterpret_cast<uint4 *>(out)[((uint64_t)(b * 8u + home) * OP.cap + jpos[j]) / 4 * 3 + p] = reinterpret_cast<const uint4 *>(buf)[b * PIECES + p];
-		}
-	};
-	auto claim = [&]() -> uint32_t { // (owner thread) the chunk reserved last; a full slab poisons the batch (replayed through two passes)
-		uint32_t at = nextpos;
-		if (at + CAP > OP.cap) { OP.flags[0] = 1; at = 0; }
-		return at;
-	};
-	auto flush = [&]() -> bool {
-		if (tid < nb1) {
-			const uint32_t f = fill[tid];
-			if (f >= CAP) {
-				const uint32_t j = atomicAdd(&s_njobs, 1u);
-				jobs[j] = tid; jpos[j] = claim(); fill[tid] = f - CAP;
-				nextpos = atomicAdd(my_cursor, (uint32_t)CAP);
-			}
-		}
-		__syncthreads();
-		copy_out(s_njobs);
-		__syncthreads();
-		if (tid == 0) s_njobs = 0;
-		bool still = false;
-#pragma unroll
-		for (int j = 0; j < S; ++j) if (bk[j] >= 0 && sl[j] >= CAP) { sl[j] -= CAP; if (sl[j] < CAP) { put(j); bk[j] = -1; } else still = true; }
-		return still;
-	};
-	int cur = 0;
-	prefetch(tile);
-	make_planes(tile, planes);
-	prefetch(next_tile);
-	__syncthreads();
-	for (;;) {
-		const uint32_t *pl = planes + cur * 4 * PW;
-		bool far = false;
-#pragma unroll
-		for (int j = 0; j < S; ++j) {
-			int r = j * BT + tid;
-			asm volatile("" : "+v"(r));
-			bool hi; U2 y0, y1;
-			bk[j] = -1; sl[j] = 0;
-			if (kmer_at2<TILE, KC>(pl, r + mis, P.k, y0, y1, hi)) {
-				bk[j] = (int)((y0.lo >> b1_shift) & (uint32_t)(nb1 - 1));
-				pack3_fast(w[j], PK, y0, y1, P.idx_rank | (uint32_t)(tile * TILE + r), hi);
-				sl[j] = atomicAdd(&fill[bk[j]], 1u);
-				++n_k; n_h += hi;
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < S; ++j) if (bk[j] >= 0) { if (sl[j] < CAP) { put(j); bk[j] = -1; } else far |= sl[j] >= 2 * CAP; }
-		uint32_t draw = 0;
-		if (tid == 0) draw = draw_issue();
-		const int any_far = __syncthreads_or(far);
-		if (next_tile < n_tiles) make_planes(next_tile, planes + (cur ^ 1) * 4 * PW); // (this tile's planes have served; the next one's bases arrived a round ago)
-		bool still = flush();
-		if (any_far) while (__syncthreads_or(still)) still = flush();
-		if (tid == 0) s_draw[2] = draw_settle(draw);
-		tile = next_tile; cur ^= 1;
-		if (tile >= n_tiles) break;
-		__syncthreads();
-		next_tile = s_draw[2];
-		prefetch(next_tile);
-	}
-	// what the buffers still hold: each into the chunk reserved last, padded with dead records
-	__syncthreads();
-	for (uint32_t x = tid; x < (uint32_t)nb1 * CAP; x += BT) if (x % CAP >= fill[x / CAP]) { buf[x * 3] = 0xffffffffu; buf[x * 3 + 1] = 0xffffffffu; buf[x * 3 + 2] = 0xffffffffu; }
-	if (tid < nb1) { jobs[tid] = tid; jpos[tid] = claim(); }
-	__syncthreads();
-	copy_out((uint32_t)nb1);
-	for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
-	if ((tid & 63) == 0 && n_k) {
-		unsigned long long *sl2 = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
-		atomicAdd(&sl2[ST_KMERS], (unsigned long long)n_k); atomicAdd(&sl2[ST_HIGH], (unsigned long long)n_h);
 	}
 }
 
@@ -894,8 +730,11 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restr
 		uint64_t i = (uint64_t)s + (uint64_t)tile * TILE + j * BT + threadIdx.x;
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
-			Rec<RW>::unpack(rec_load<RW>(in + i * RW), RG, imp, y0, y1, idx, hi);
-			atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
+			const RecW<RW> w = rec_load<RW>(in + i * RW);
+			if (!rec_dead<RW>(w)) { // (dead records: slabs of a one-pass level 1 read by the two-pass level 2 -- a rank of a multi-GPU run, replays)
+				Rec<RW>::unpack(w, RG, imp, y0, y1, idx, hi);
+				atomicAdd(&hist[fine_id<W>(P, y0, y1) & (nb2 - 1)], 1u);
+			}
 		}
 	}
 	__syncthreads();
@@ -905,7 +744,7 @@ __global__ __launch_bounds__(BT) void k_hist2(KParams P, const uint32_t *__restr
 
 // one workgroup per level-1 bucket: column totals -> fine starts; rows -> absolute offsets in place
 __global__ __launch_bounds__(BFCG_MAXB) void k_scan2(KParams P, const uint32_t *__restrict__ bucket_start, int segs_per_bucket,
-                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2, uint32_t *__restrict__ start2)
+                                               const uint32_t *__restrict__ row_base, uint32_t *__restrict__ rows2, uint32_t *__restrict__ start2, uint32_t *__restrict__ cnt_live)
 {
 	__shared__ uint32_t tot[BFCG_MAXB];
 	const int nb2 = 1 << P.F2, b1 = blockIdx.x, c = threadIdx.x;
@@ -926,6 +765,9 @@ __global__ __launch_bounds__(BFCG_MAXB) void k_scan2(KParams P, const uint32_t *
 	if (c < nb2) {
 		uint32_t run = bucket_start[b1] + tot[c] - total;
 		start2[((size_t)b1 << P.F2) + c] = run;
+		// (the level-1 bucket's records were counted WITH the dead ones -- bucket_start -- so its last region is followed by a gap: the regions'
+		// own counts say where they end)
+		if (cnt_live) cnt_live[((size_t)b1 << P.F2) + c] = total;
 #pragma unroll 16
 		for (uint32_t r = r0; r < r1; ++r) { uint32_t v = rows2[(size_t)r * nb2 + c]; rows2[(size_t)r * nb2 + c] = run; run += v; }
 	}
@@ -978,7 +820,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		if (i < e) {
 			uint64_t y0, y1; uint32_t idx; bool hi;
 			w[j] = rec_load<RW>(in + i * RW);
-			if (!ONEPASS2 || w[j].d[RW - 1] != 0xffffffffu) { // (a dead record: what a level-1 workgroup left unused of its last chunk -- OnePass)
+			if (!rec_dead<RW>(w[j])) { // (what a level-1 workgroup left unused of its last chunk -- OnePass)
 				Rec<RW>::unpack(w[j], RG, imp, y0, y1, idx, hi);
 				uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
 				br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
@@ -1017,7 +859,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		}
 	}
 	__syncthreads();
-	const uint32_t n_in = ONEPASS2 ? n_live : min((uint32_t)TILE, e - s - tile * TILE);
+	const uint32_t n_in = n_live;
 	for (uint32_t pos = threadIdx.x; pos < n_in; pos += BT) {
 		RecW<RW> rec;
 #pragma unroll
@@ -1355,7 +1197,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 6 : 8) void k_bloom(KParams P, Bloo
 	};
 	// cold batch (host's hint) and every record of the region fits the threads' registers: copies of a k-mer are resolved by class first, and the
 	// passes over the k-mers with clear bits run on the decoded records in registers (no list of record indices, no second look at HBM)
-	const bool dd = P.dedupe && P.ct_cap >= 2u * BT * PF && n <= (uint32_t)(BT * PF) && n <= P.list_cap;
+	const bool dd = P.dedupe && P.ct_cap >= 2u * BT * PF && n <= (uint32_t)(BT * PF) && n <= P.list_cap && P.R <= 10; // (cls_of packs the block into 10 bits)
 
 	const bool timing = BFCG_ABL(P, 64) && threadIdx.x == 0;
 	long long tq[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2315,7 +2157,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(nb1 < 64 ? 64 : nb1), 0, st, B.chunk1, n_chunks, nb1, B.start1, B.row_base, T2);
 	hipLaunchKernelGGL(k_apply, dim3(n_chunks), dim3(256), 0, st, B.rows1, (int)tiles1, nb1, B.chunk1);
 	if (ev) hipEventRecord(ev[1], st);
-	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr, 0u});
+	hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1>), dim3(g1), dim3(BTS1), (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)8 * nb1, st, P, seq, qual, n_pos, B.rows1, out1, OnePass{nullptr, 0u, nullptr, nullptr, 0u, 0u, 0u, 0u});
 	if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -2332,7 +2174,7 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	if (ev) hipEventRecord(ev[1], st);
 	unsigned g1 = (unsigned)(((tiles1 + 7) / 8) * 8);
 	const size_t lds1 = (size_t)T1 * (RW * 4 + ((P.rec_n > 0 && RW == 4) ? 2 : 0)) + (size_t)16 * nb1;
-	OnePass OP{B.op_cursor, B.op_cap, B.op_flags, B.stats, 1u};
+	OnePass OP{B.op_cursor, B.op_cap, B.op_flags, B.stats, 1u, B.op_own_lo, B.op_own_n, B.op_own_delta};
 	{ // as many workgroups as are resident at once (a CU's 160 KiB of LDS, at most 2048 threads), each walking its tiles; a multiple of 8 (XCDs)
 		static int n_cu = 0;
 		if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
@@ -2341,7 +2183,8 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 		const unsigned gp = (unsigned)(n_cu * per_cu) & ~7u;
 		if (gp >= 8 && gp < g1) g1 = gp;
 	}
-	if (B.cap2) { // chunked reservations leave dead records behind, which only the one-pass level 2 skips.  What the g1 / 8 workgroups of an XCD
+	if (B.cnt_live) { // chunked reservations leave dead records behind, which level 2 skips (both its variants since round 4; the two-pass one needs the
+		// regions' counts for it: cnt_live).  What the g1 / 8 workgroups of an XCD
 		// leave unused in a slab -- half a chunk each on average -- stays below a quarter of the slab's head room (a ninth of its capacity).
 		const char *e = getenv("BFCG_S1_CHUNK"); // (tests force chunk sizes on small draws)
 		const int forced = e ? atoi(e) : 0;
@@ -2349,31 +2192,7 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 		while (ch > 1 && (uint64_t)(g1 / 8) * (ch / 2) * 36 > B.op_cap) ch >>= 1;
 		OP.chunk = forced > 0 ? (uint32_t)forced : ch;
 	}
-	bool wc_done = false;
-	if constexpr (RW == 3 && sizeof(W) == 8) { // opt-in: level 1 with write-combining buffers (k_scatter1_wc)
-		const char *e = getenv("BFCG_S1_WC");
-		constexpr int WBT = 1024, WCAP = 16;
-		const size_t ldsw = (size_t)nb1 * WCAP * 12 + (size_t)12 * nb1;
-		if (e && atoi(e) > 0 && B.cap2 && scatter1_fast(P) && nb1 <= WBT / 2 && ldsw <= 150 * 1024 && (B.op_cap & 31u) == 0 && ((uintptr_t)out1 & 15) == 0 && !BFCG_ABL(P, 2048)) {
-			static int n_cu = 0;
-			if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-			const int per_cu = ldsw + 4400 <= 80 * 1024 ? 2 : 1;
-			unsigned gw = (unsigned)(((tiles1 + 7) / 8) * 8);
-			const unsigned gp = (unsigned)(n_cu * per_cu) & ~7u;
-			if (gp >= 8 && gp < gw) gw = gp;
-			if (atoi(e) >= 2) fprintf(stderr, "[bfcg] k_scatter1_wc: %d buckets x %d records, slabs of %u, %u workgroups, %lld positions\n", nb1, WCAP, B.op_cap, gw, (long long)n_pos);
-			if (P.k == 33) {
-				hipFuncSetAttribute((const void *)k_scatter1_wc<T1, WBT, WCAP, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); // (per device: every launch)
-				hipLaunchKernelGGL((k_scatter1_wc<T1, WBT, WCAP, 33>), dim3(gw), dim3(WBT), ldsw, st, P, seq, qual, n_pos, out1, OP);
-			} else {
-				hipFuncSetAttribute((const void *)k_scatter1_wc<T1, WBT, WCAP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-				hipLaunchKernelGGL((k_scatter1_wc<T1, WBT, WCAP, 0>), dim3(gw), dim3(WBT), ldsw, st, P, seq, qual, n_pos, out1, OP);
-			}
-			wc_done = true;
-		}
-	}
-	if (wc_done) {}
-	else if constexpr (RW == 3) {
+	if constexpr (RW == 3) {
 		if (scatter1_fast(P)) {
 			if (sizeof(W) == 8 && P.k == 33) hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
 			else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
@@ -2432,7 +2251,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 			                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
 		} else {
 			hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2);
-			hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2);
+			hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2, B.cnt_live);
 			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2,
 			                   (uint32_t *)B.recs2, OnePass2{nullptr, 0u, nullptr});
 		}
@@ -2448,6 +2267,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	A.ord.first = B.tab_first; A.ord.sub_last = B.sub_last; A.batch_hi = B.batch_hi;
 	A.cnt2 = nullptr; A.cap2 = 0; A.flags = B.op_flags; A.sticky = B.op_sticky; // (op_flags: NULL unless this batch went through the one-pass partition)
 	if (P.F2 > 0 && B.cap2) { A.cnt2 = B.cnt2; A.cap2 = B.cap2; }
+	else if (P.F2 > 0 && B.cnt_live) A.cnt2 = B.cnt_live; // two passes: the regions' counts beside their starts (region_list)
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
 		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);

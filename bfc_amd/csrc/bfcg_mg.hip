@@ -26,6 +26,10 @@
 #include "bfc_host.h"
 
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
+extern "C" int bfcg_mg_process_slabs(bfcg_ctx_t *c, const void *d_recv, const uint32_t *fills, uint32_t slab_cap, hipEvent_t *wait, int n_wait);
+extern "C" int bfcg_mg_slab_info(bfcg_ctx_t *c, uint32_t out[2]);
+extern "C" int bfcg_mg_scatter_slabs(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *fills, int *overflow);
+extern "C" int bfcg_mg_scatter_again(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts);
 extern "C" void bfcg_set_error(const char *msg);
 extern "C" double bfcg_mg_warm_factor(bfcg_ctx_t *c);
 extern "C" void bfcg_mg_allow_onepass(bfcg_ctx_t *c, int on);
@@ -44,6 +48,7 @@ struct rank_t {
 	hipEvent_t ev_x;           // this rank's part of the exchange is done (its receives with RCCL; its outgoing copies with peer copies)
 	hipEvent_t ev_sent[2]; int sent_pending[2]; // the exchange that reads send buffer [t & 1] has drained (waited for before stage A writes it again)
 	uint8_t *send2[2], *recv[2]; // send buffers alternate, so that stage A of the next batch runs beside this batch's exchange
+	int combined;              // recv[b] lies behind send2[b] in ONE allocation (slab mode: stage A writes the rank's own share straight into it)
 	uint64_t send_cap, recv_cap; // bytes
 	uint32_t *counts;          // this rank's level-1 bucket sizes of the current batch (host) + one word: this rank's group has failed
 	uint32_t *d_counts;        // multi-process: all ranks' rows, device side of the all-gather
@@ -62,6 +67,13 @@ struct bfcg_group {
 	bfcg_params_t prm;
 	int n_ranks, first, n_local, xp, rec_bytes, nb1, nb_loc;
 	int mp;                     // one rank per process: sizes travel by ncclAllGather, records by ncclSend / ncclRecv between the processes
+	// Slab mode (round 4): stage A is ONE pass (K1 once) into 8 slabs per level-1 bucket of the send buffer; a destination's buckets are one
+	// contiguous range of slabs and travel as they are (fill: 8 words per bucket in the sizes), the rank's own share is written into its
+	// receive buffer by the kernel itself (no self-copy).  A slab that overflows anywhere (skewed input) sends the batch -- and the rest of the
+	// run -- back to the two-pass stage A with exact, contiguous buckets.
+	int slabs, slabs_ok;        // in use now; possible at all (every context, the buffers' record indices fit 32 bits)
+	uint32_t slab_cap; uint64_t blk; // records per slab; per block of nb_loc x 8 slabs (what one rank sends to one destination)
+	size_t row_words;           // a rank's row of sizes: up to 8 x nb1 words, then its failure word, then its overflow word
 	uint64_t kmer_limit;        // k-mers of a global batch one rank's regions take at full speed
 	std::vector<rank_t> r;
 	uint32_t *all_counts;       // [n_ranks][nb1 + 1], host (pinned): every rank's bucket sizes of the current batch and its failure word
@@ -123,21 +135,72 @@ static int process_in_groups(bfcg_group_t *g, rank_t &R, const uint8_t *recv, co
 	return 0;
 }
 
+// the same in slab mode: every source's slabs sit at fixed places, so a group of sources is simply the fills of the others set to zero
+static int process_in_groups_slabs(bfcg_group_t *g, rank_t &R, const uint8_t *recv, const uint32_t *fills, hipEvent_t *wait, int n_wait)
+{
+	const int N = g->n_ranks, nb_loc = g->nb_loc;
+	const size_t per = (size_t)nb_loc * 8;
+	std::vector<uint64_t> per_src((size_t)N, 0);
+	uint64_t total = 0;
+	for (int s = 0; s < N; ++s) { for (size_t k = 0; k < per; ++k) per_src[s] += fills[(size_t)s * per + k]; total += per_src[s]; }
+	const uint64_t limit = (uint64_t)((double)g->kmer_limit * bfcg_mg_warm_factor(R.ctx));
+	if (g->prm.track_order || total <= limit || N == 1) return bfcg_mg_process_slabs(R.ctx, recv, fills, g->slab_cap, wait, n_wait);
+	std::vector<uint32_t> seg((size_t)N * per);
+	int s0 = 0, launched = 0;
+	while (s0 < N) {
+		uint64_t acc = per_src[s0]; int s1 = s0 + 1;
+		while (s1 < N && acc + per_src[s1] <= limit) acc += per_src[s1++];
+		if (acc) {
+			memset(seg.data(), 0, seg.size() * sizeof(uint32_t));
+			memcpy(&seg[(size_t)s0 * per], &fills[(size_t)s0 * per], sizeof(uint32_t) * (size_t)(s1 - s0) * per);
+			if (launched) { // stage A and stage B come in pairs (buffer sets, timing events): an empty stage A opens the next pair
+				std::vector<uint32_t> dummy((size_t)g->nb1);
+				if (bfcg_mg_scatter(R.ctx, 0, 0, 0, 0, dummy.data()) != 0) return -1;
+			}
+			if (bfcg_mg_process_slabs(R.ctx, recv, seg.data(), g->slab_cap, launched ? 0 : wait, launched ? 0 : n_wait) != 0) return -1;
+			++launched;
+		}
+		s0 = s1;
+	}
+	if (!launched) return bfcg_mg_process_slabs(R.ctx, recv, fills, g->slab_cap, wait, n_wait);
+	return 0;
+}
+
+// every rank's row of sizes: shared memory between the local ranks, an all-gather over RCCL between processes
+static void publish_sizes(bfcg_group_t *g, rank_t &R)
+{
+	const int N = g->n_ranks, me = R.rank;
+	const size_t cs = g->row_words;
+	memcpy(g->all_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs);
+	if (g->mp) { // between processes: all-gather over RCCL (the local ranks of a multi-process group are one per process)
+		ncclResult_t ne = ncclSuccess;
+		hipError_t he = hipMemcpyAsync(R.d_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs, hipMemcpyHostToDevice, R.xs);
+		if (he == hipSuccess) ne = ncclAllGather(R.d_counts + (size_t)me * cs, R.d_counts, cs, ncclUint32, R.comm, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipMemcpyAsync(g->all_counts, R.d_counts, sizeof(uint32_t) * (size_t)N * cs, hipMemcpyDeviceToHost, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipStreamSynchronize(R.xs);
+		if (he != hipSuccess || ne != ncclSuccess) grp_err(g, "all-gather of the bucket sizes failed: %s", he != hipSuccess ? hipGetErrorString(he) : ncclGetErrorString(ne));
+		else for (int p = 0; p < N; ++p) if (p != me && g->all_counts[(size_t)p * cs + cs - 2]) grp_err(g, "rank %d of the run has failed: this batch is not exchanged", p);
+	}
+}
+
 // one global batch on local rank i (runs on the rank's own host thread)
 static int rank_batch(bfcg_group_t *g, int i)
 {
 	rank_t &R = g->r[i];
 	const int N = g->n_ranks, nb1 = g->nb1, nb_loc = g->nb_loc, me = R.rank;
-	const size_t cs = (size_t)nb1 + 1; // a rank's row: nb1 bucket sizes, then its failure word
+	const size_t cs = g->row_words; // a rank's row: its sizes, then (cs - 2) its failure word, (cs - 1) a slab of its stage A overflowed
 	const uint64_t rb = (uint64_t)g->rec_bytes;
 	int ok = !g->failed;
 	GHIP(hipSetDevice(R.device));
 	// ---- stage A into send buffer [t & 1]: the exchange two batches ago read it last
 	const int sb = (int)(g->t & 1);
 	uint8_t *const send = R.send2[sb];
+	uint8_t *recv = R.recv[g->t & 1];
 	if (R.sent_pending[sb]) { GHIP(hipEventSynchronize(R.ev_sent[sb])); R.sent_pending[sb] = 0; }
+	const uint8_t *ds = R.in_seq, *dq = R.in_qual;
+	int slab = g->slabs; // (the same on every rank: decided between batches)
+	memset(R.counts, 0, sizeof(uint32_t) * cs);
 	if (ok) {
-		const uint8_t *ds = R.in_seq, *dq = R.in_qual;
 		if (R.in_host && R.in_pos) {
 			if (R.in_pos > R.in_cap) { grp_err(g, "share of %llu positions exceeds the staging buffer", (unsigned long long)R.in_pos); ok = 0; }
 			else {
@@ -147,47 +210,61 @@ static int rank_batch(bfcg_group_t *g, int i)
 				ds = R.d_seq; dq = R.in_qual ? R.d_qual : 0;
 			}
 		}
-		if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+		if (ok && slab) {
+			int ovf = 0;
+			// (the rank's own slabs: the same place inside its block of the receive buffer, which lies send_cap bytes behind the send buffer)
+			if (bfcg_mg_scatter_slabs(R.ctx, ds, dq, R.in_pos, send, (uint32_t)(R.send_cap / rb), R.counts, &ovf) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+			R.counts[cs - 1] = ovf ? 1u : 0u;
+		} else if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
 	}
-	if (!ok) memset(R.counts, 0, sizeof(uint32_t) * (size_t)nb1);
+	if (!ok) memset(R.counts, 0, sizeof(uint32_t) * cs);
 	// The failure word travels with the sizes: g->failed is local to a process, and a rank that skipped the exchange while its peers posted
 	// ncclSend / ncclRecv for it would leave them blocked for good.  A group that has failed keeps taking part in this all-gather (and only in it),
 	// so that every process of the run takes the same decision in the same batch.
-	R.counts[nb1] = g->failed ? 1u : 0u;
-	memcpy(g->all_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs);
-	// ---- every rank's bucket sizes
-	if (g->mp) { // between processes: all-gather over RCCL (the local ranks of a multi-process group are one per process)
-		ncclResult_t ne = ncclSuccess;
-		hipError_t he = hipMemcpyAsync(R.d_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs, hipMemcpyHostToDevice, R.xs);
-		if (he == hipSuccess) ne = ncclAllGather(R.d_counts + (size_t)me * cs, R.d_counts, cs, ncclUint32, R.comm, R.xs);
-		if (he == hipSuccess && ne == ncclSuccess) he = hipMemcpyAsync(g->all_counts, R.d_counts, sizeof(uint32_t) * (size_t)N * cs, hipMemcpyDeviceToHost, R.xs);
-		if (he == hipSuccess && ne == ncclSuccess) he = hipStreamSynchronize(R.xs);
-		if (he != hipSuccess || ne != ncclSuccess) grp_err(g, "all-gather of the bucket sizes failed: %s", he != hipSuccess ? hipGetErrorString(he) : ncclGetErrorString(ne));
-		else for (int p = 0; p < N; ++p) if (p != me && g->all_counts[(size_t)p * cs + nb1]) grp_err(g, "rank %d of the run has failed: this batch is not exchanged", p);
-	}
+	R.counts[cs - 2] = g->failed ? 1u : 0u;
+	publish_sizes(g, R);
 	pthread_barrier_wait(&g->bar); // all local ranks have published their sizes
+	if (slab) { // a slab overflowed somewhere: every rank repeats its stage A through the two passes (its k-mers are counted) and the run stays with them
+		int any = 0;
+		for (int p = 0; p < N; ++p) any |= g->all_counts[(size_t)p * cs + cs - 1] != 0;
+		pthread_barrier_wait(&g->bar); // (everybody has read the rows before anybody writes the next ones)
+		if (any) {
+			if (i == 0 && getenv("BFCG_DEBUG_MG")) fprintf(stderr, "[D::group] batch %llu: a level-1 slab overflowed on some rank: two-pass stage A from here on\n", (unsigned long long)g->t);
+			if (i == 0) g->slabs = 0;
+			slab = 0;
+			memset(R.counts, 0, sizeof(uint32_t) * cs);
+			if (ok && bfcg_mg_scatter_again(R.ctx, ds, dq, R.in_pos, send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+			if (!ok) memset(R.counts, 0, sizeof(uint32_t) * cs);
+			R.counts[cs - 2] = g->failed ? 1u : 0u;
+			publish_sizes(g, R);
+			pthread_barrier_wait(&g->bar);
+		}
+	}
 	if (i == 0) g->go = !g->failed; // one decision for all local ranks -- and, the failure words being all-gathered, for all processes
 	pthread_barrier_wait(&g->bar);
 	const uint32_t *C = g->all_counts;
-	// what I send to rank p: my buckets [p*nb_loc, (p+1)*nb_loc); what I get from rank p: its buckets [me*nb_loc, ...), stored source-major
-	std::vector<uint64_t> s_off((size_t)N + 1, 0), r_off((size_t)N + 1, 0);
-	for (int p = 0; p < N; ++p) {
-		uint64_t s = 0, q = 0;
-		for (int k = 0; k < nb_loc; ++k) { s += C[(size_t)me * cs + (size_t)p * nb_loc + k]; q += C[(size_t)p * cs + (size_t)me * nb_loc + k]; }
-		s_off[p + 1] = s_off[p] + s; r_off[p + 1] = r_off[p] + q;
-	}
-	uint8_t *recv = R.recv[g->t & 1];
 	ok = g->go;
-	// every rank can compute every rank's receive size: an overflow anywhere stops the exchange everywhere
-	for (int p = 0; p < N && ok; ++p) {
-		uint64_t q = 0;
-		for (int s2 = 0; s2 < N; ++s2) for (int k = 0; k < nb_loc; ++k) q += C[(size_t)s2 * cs + (size_t)p * nb_loc + k];
-		if (q * rb > R.recv_cap) { grp_err(g, "rank %d receives %llu records of one global batch, its buffer holds %llu: smaller shares or a larger filter", p, (unsigned long long)q, (unsigned long long)(R.recv_cap / rb)); ok = 0; }
+	std::vector<uint64_t> s_off((size_t)N + 1, 0), r_off((size_t)N + 1, 0);
+	if (slab) { // fixed places: block p of my send buffer goes to rank p, block s of my receive buffer comes from rank s
+		for (int p = 0; p <= N; ++p) s_off[p] = r_off[p] = (uint64_t)p * g->blk;
+	} else {
+		// what I send to rank p: my buckets [p*nb_loc, (p+1)*nb_loc); what I get from rank p: its buckets [me*nb_loc, ...), stored source-major
+		for (int p = 0; p < N; ++p) {
+			uint64_t a = 0, q = 0;
+			for (int k = 0; k < nb_loc; ++k) { a += C[(size_t)me * cs + (size_t)p * nb_loc + k]; q += C[(size_t)p * cs + (size_t)me * nb_loc + k]; }
+			s_off[p + 1] = s_off[p] + a; r_off[p + 1] = r_off[p] + q;
+		}
+		// every rank can compute every rank's receive size: an overflow anywhere stops the exchange everywhere
+		for (int p = 0; p < N && ok; ++p) {
+			uint64_t q = 0;
+			for (int s2 = 0; s2 < N; ++s2) for (int k = 0; k < nb_loc; ++k) q += C[(size_t)s2 * cs + (size_t)p * nb_loc + k];
+			if (q * rb > R.recv_cap) { grp_err(g, "rank %d receives %llu records of one global batch, its buffer holds %llu: smaller shares or a larger filter", p, (unsigned long long)q, (unsigned long long)(R.recv_cap / rb)); ok = 0; }
+		}
 	}
 	// ---- records
 	if (g->xp == XP_RCCL) {
 		if (ok) {
-			if (s_off[me + 1] > s_off[me]) GHIP(hipMemcpyAsync(recv + r_off[me] * rb, send + s_off[me] * rb, (s_off[me + 1] - s_off[me]) * rb, hipMemcpyDeviceToDevice, R.xs));
+			if (!slab && s_off[me + 1] > s_off[me]) GHIP(hipMemcpyAsync(recv + r_off[me] * rb, send + s_off[me] * rb, (s_off[me + 1] - s_off[me]) * rb, hipMemcpyDeviceToDevice, R.xs));
 			if (N > 1) GNCCL(ncclGroupStart());
 			for (int step = 1; step < N; ++step) { // ring-shifted peer order: every rank talks to a different peer at any time
 				const int to = (me + step) % N, from = (me - step + N) % N;
@@ -202,13 +279,14 @@ static int rank_batch(bfcg_group_t *g, int i)
 		}
 	} else { // peer copies: I push my records into every owner's receive buffer (all ranks are local)
 		if (ok) {
-			for (int step = 0; step < N; ++step) {
+			for (int step = slab ? 1 : 0; step < N; ++step) {
 				const int to = (me + step) % N;
 				const rank_t &T = g->r[to - g->first];
 				const uint64_t n_to = (s_off[to + 1] - s_off[to]) * rb;
 				// my block in `to`'s buffer starts behind the blocks of the sources before me
 				uint64_t at = 0;
-				for (int p = 0; p < me; ++p) for (int k = 0; k < nb_loc; ++k) at += C[(size_t)p * cs + (size_t)to * nb_loc + k];
+				if (slab) at = (uint64_t)me * g->blk;
+				else for (int p = 0; p < me; ++p) for (int k = 0; k < nb_loc; ++k) at += C[(size_t)p * cs + (size_t)to * nb_loc + k];
 				if (n_to) GHIP(hipMemcpyPeerAsync(T.recv[g->t & 1] + at * rb, T.device, send + s_off[to] * rb, R.device, n_to, R.xs));
 			}
 			GHIP(hipEventRecord(R.ev_x, R.xs));
@@ -217,18 +295,26 @@ static int rank_batch(bfcg_group_t *g, int i)
 	}
 	// ---- stage B behind the exchange
 	if (ok && !g->failed) {
-		std::vector<uint32_t> seg((size_t)N * nb_loc);
-		for (int s = 0; s < N; ++s) memcpy(&seg[(size_t)s * nb_loc], &C[(size_t)s * cs + (size_t)me * nb_loc], sizeof(uint32_t) * (size_t)nb_loc);
 		std::vector<hipEvent_t> ev;
 		if (g->xp == XP_RCCL) ev.push_back(R.ev_x);
 		else for (int j = 0; j < g->n_local; ++j) ev.push_back(g->r[j].ev_x);
-		if (process_in_groups(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+		if (slab) {
+			const size_t per = (size_t)nb_loc * 8;
+			std::vector<uint32_t> seg((size_t)N * per);
+			for (int s = 0; s < N; ++s) memcpy(&seg[(size_t)s * per], &C[(size_t)s * cs + (size_t)me * per], sizeof(uint32_t) * per);
+			if (process_in_groups_slabs(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+		} else {
+			std::vector<uint32_t> seg((size_t)N * nb_loc);
+			for (int s = 0; s < N; ++s) memcpy(&seg[(size_t)s * nb_loc], &C[(size_t)s * cs + (size_t)me * nb_loc], sizeof(uint32_t) * (size_t)nb_loc);
+			if (process_in_groups(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+		}
 	}
 	{ uint64_t calls = 0; bfcg_progress(R.ctx, &calls, 0, 0, 0); R.batch_call[g->t & 63] = calls; } // this global batch is complete on this rank once that call is
 	// The exchange is left running: the next batch's stage A (other send buffer) proceeds beside it.  What the next batch may not do before
 	// this one is through is ordered elsewhere: its exchange follows this one on the stream xs; a receive buffer is written again two batches
 	// on, behind this barrier of the batch in between, which every rank reaches only after its bfcg_mg_process_ev has waited for THIS
-	// batch's stage B (finalise_previous); the other ranks have read all_counts before they come here.
+	// batch's stage B (finalise_previous); the other ranks have read all_counts before they come here.  (Slab mode: stage A of batch t + 2 writes
+	// the rank's own share into receive buffer [t & 1] again -- behind the same wait for this batch's stage B.)
 	if (ok) { GHIP(hipEventRecord(R.ev_sent[sb], R.xs)); R.sent_pending[sb] = 1; }
 	pthread_barrier_wait(&g->bar);
 	return g->failed ? -1 : 0;
@@ -283,7 +369,7 @@ extern "C" void bfcg_group_destroy(bfcg_group_t *g)
 		(void)hipSetDevice(R.device);
 		if (R.ctx) (void)bfcg_sync(R.ctx);
 		if (R.comm) { if (g->failed && g->mp) (void)ncclCommAbort(R.comm); else (void)ncclCommDestroy(R.comm); } // (peers of a failed run may never post what a clean destroy waits for)
-		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
+		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); if (!R.combined) { (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); } (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
 		if (R.ev_x) (void)hipEventDestroy(R.ev_x);
 		for (int b = 0; b < 2; ++b) if (R.ev_sent[b]) (void)hipEventDestroy(R.ev_sent[b]);
 		if (R.xs) (void)hipStreamDestroy(R.xs);
@@ -328,8 +414,19 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		g->nb1 = info[0]; g->nb_loc = info[1]; g->rec_bytes = info[2];
 		g->kmer_limit = (uint64_t)((double)bfcg_batch_limit(g->r[0].ctx) / 0.95);
 	}
-	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * (g->nb1 + 1), hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
 	const uint64_t cap = prm->max_batch_pos, rcap = n_ranks > 1 ? cap + cap / 4 + (1u << 20) : cap; // = the contexts' level-2 capacity
+	{ // slab mode: every context must offer it, and a record index that spans send AND receive buffer must fit 32 bits
+		const char *e = getenv("BFCG_MG_SLABS");
+		g->slabs_ok = !(e && atoi(e) == 0) && !prm->track_order;
+		g->slab_cap = 0;
+		for (auto &R : g->r) { uint32_t si[2]; bfcg_mg_slab_info(R.ctx, si); if (!si[1]) g->slabs_ok = 0; g->slab_cap = si[0]; }
+		g->blk = (uint64_t)g->nb_loc * 8 * g->slab_cap;
+		const uint64_t S = (uint64_t)g->nb1 * 8 * g->slab_cap;
+		if (S + (rcap > S ? rcap : S) + 8192 >= 0xffffffffULL) g->slabs_ok = 0;
+		g->slabs = g->slabs_ok;
+		g->row_words = (size_t)g->nb1 * (g->slabs_ok ? 8 : 1) + 2;
+	}
+	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * g->row_words, hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
 	std::vector<ncclComm_t> comms((size_t)n_local, (ncclComm_t)0);
 	if (g->xp == XP_RCCL && !g->mp && n_ranks > 1) {
 		if (ncclCommInitAll(comms.data(), n_local, devices) != ncclSuccess) { bfcg_set_error("ncclCommInitAll failed"); bfcg_group_destroy(g); return NULL; }
@@ -342,15 +439,23 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		if (e == hipSuccess) e = hipStreamCreateWithFlags(&R.cs, hipStreamNonBlocking);
 		for (int b = 0; b < 2; ++b) if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_sent[b], hipEventDisableTiming);
 		R.send_cap = cap * (uint64_t)g->rec_bytes;
-		for (int b = 0; b < 2; ++b) if (e == hipSuccess) e = hipMalloc(&R.send2[b], R.send_cap);
 		R.recv_cap = rcap * (uint64_t)g->rec_bytes;
-		if (e == hipSuccess) e = hipMalloc(&R.recv[0], R.recv_cap);
-		if (e == hipSuccess) e = hipMalloc(&R.recv[1], R.recv_cap);
-		if (e == hipSuccess) e = hipMalloc(&R.d_counts, sizeof(uint32_t) * (size_t)n_ranks * (g->nb1 + 1));
+		if (g->slabs_ok) { // all slabs of a batch (+ a tile of slack: a run that finds its slab full is still stored), the receive buffer right behind
+			const uint64_t S = (uint64_t)g->nb1 * 8 * g->slab_cap;
+			R.send_cap = S * (uint64_t)g->rec_bytes;
+			if (R.recv_cap < (S + 8192) * (uint64_t)g->rec_bytes) R.recv_cap = (S + 8192) * (uint64_t)g->rec_bytes;
+			R.combined = 1;
+			for (int b = 0; b < 2; ++b) { if (e == hipSuccess) e = hipMalloc(&R.send2[b], R.send_cap + R.recv_cap); if (e == hipSuccess) R.recv[b] = R.send2[b] + R.send_cap; }
+		} else {
+			for (int b = 0; b < 2; ++b) if (e == hipSuccess) e = hipMalloc(&R.send2[b], R.send_cap);
+			if (e == hipSuccess) e = hipMalloc(&R.recv[0], R.recv_cap);
+			if (e == hipSuccess) e = hipMalloc(&R.recv[1], R.recv_cap);
+		}
+		if (e == hipSuccess) e = hipMalloc(&R.d_counts, sizeof(uint32_t) * (size_t)n_ranks * g->row_words);
 		R.in_cap = cap;
 		if (e == hipSuccess) e = hipMalloc(&R.d_seq, cap);
 		if (e == hipSuccess) e = hipMalloc(&R.d_qual, cap);
-		R.counts = (uint32_t *)calloc((size_t)g->nb1 + 1, sizeof(uint32_t));
+		R.counts = (uint32_t *)calloc(g->row_words, sizeof(uint32_t));
 		if (e != hipSuccess) { bfcg_set_error(hipGetErrorString(e)); bfcg_group_destroy(g); return NULL; }
 		if (g->xp == XP_PEER) for (int j = 0; j < n_local; ++j) if (devices[j] != R.device) (void)hipDeviceEnablePeerAccess(devices[j], 0);
 		if (g->xp == XP_RCCL && (n_ranks > 1 || g->mp)) {
@@ -375,6 +480,7 @@ extern "C" int bfcg_group_info(bfcg_group_t *g, int out[6])
 	out[0] = g->n_ranks; out[1] = g->n_local; out[2] = g->xp; out[3] = g->rec_bytes; out[4] = g->nb1; out[5] = g->first;
 	return 0;
 }
+extern "C" int bfcg_group_slab_mode(bfcg_group_t *g) { return g->slabs; }
 extern "C" bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i) { return i >= 0 && i < g->n_local ? g->r[i].ctx : NULL; }
 
 static int drain_exchange(bfcg_group_t *g)
@@ -389,6 +495,11 @@ extern "C" int bfcg_group_reset(bfcg_group_t *g)
 {
 	if (drain_exchange(g) != 0) return -1;
 	for (auto &R : g->r) if (bfcg_reset(R.ctx) != 0) return -1;
+	// the contexts count their calls from zero again: so do the global batches (bfcg_group_progress compares the two), and a run that fell back
+	// to the two-pass stage A starts the next data set in slab mode again
+	g->t = 0;
+	for (auto &R : g->r) memset(R.batch_call, 0, sizeof(R.batch_call));
+	g->slabs = g->slabs_ok;
 	return 0;
 }
 // one rank per process: every process learns whether any of them has failed (one word per rank, all-gathered; the rank threads are idle)

@@ -150,6 +150,9 @@ enum { BFCG_ST_KMERS = 0, BFCG_ST_HIGH, BFCG_ST_SEEN, BFCG_ST_KEYS, BFCG_ST_TAB_
  * bfcg_group_unique_id on one process and handed to the others out of band.  `prm` as for bfcg_create (device / rank / n_ranks are set
  * per rank; max_batch_pos = positions of ONE RANK's share of a global batch).  transport: 0 auto, 1 RCCL, 2 peer copies.
  * A global batch is the ranks' shares in rank order (rank-major file order): results are those of `bfc -t1` on that order.
+ * Stage A of a rank is ONE pass since round 4 (K1 once): its records land in 8 slabs per level-1 bucket, a destination's buckets are one
+ * contiguous range of slabs and travel as they are, the rank's own share is written straight into its receive buffer; input that overflows
+ * a slab (few, often repeated k-mers) sends that batch and the rest of the run through the two-pass stage A with exact bucket sizes.
  * reference: count.c:106 (kt_for over reads), count.c:143 (kt_pipeline) -- the fan-out lives inside bfc_count. */
 typedef struct bfcg_group bfcg_group_t;
 #define BFCG_UID_BYTES 128
@@ -158,11 +161,15 @@ bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks, int first
 void bfcg_group_destroy(bfcg_group_t *g);
 int bfcg_group_info(bfcg_group_t *g, int out[6]);     /* n_ranks, n_local, transport in use (1 RCCL, 2 peer copies), bytes per record, 2^F1, first rank */
 bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i);  /* local rank i's context (statistics, exports of its slice); owned by the group */
+int bfcg_group_slab_mode(bfcg_group_t *g);           /* 1: stage A runs in one pass into slabs; 0: two passes (never possible, switched off, or a slab overflowed in this run) */
 int bfcg_group_reset(bfcg_group_t *g);
 /* one global batch: local rank i contributes the stream d_seq[i] / d_qual[i] (on ITS device) of n_pos[i] positions (0 = nothing) */
 int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos);
 /* one global batch from host memory, cut by the library into n_ranks contiguous shares at read boundaries (all ranks local) */
 int bfcg_group_count_batch_host(bfcg_group_t *g, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos);
+/* Drains every local rank.  COLLECTIVE when the ranks live in several processes: it ends with a one-word all-gather of the ranks' status, so
+ * every process of the run must call it (also one that has met an error -- it then reports -1 everywhere), or its peers block in that
+ * all-gather.  The same holds for bfcg_group_count_batch_*: every process submits every global batch (an empty share is fine). */
 int bfcg_group_sync(bfcg_group_t *g);
 int bfcg_group_stats(bfcg_group_t *g, uint64_t out[BFCG_ST_N]);   /* sums over the local ranks */
 /* progress without draining (as bfcg_progress, below): *batches = global batches submitted, *final = the last one complete on every local rank,

@@ -128,6 +128,20 @@ def test_c4_parameters(gpu_lib):
     g.close()
 
 
+@pytest.mark.skipif("c4e" not in BASE, reason="tests/golden/baseline.json has no c4e entry (make_baseline_goldens.py c4e: 1.7 h of one core)")
+def test_c4_eighth_full_geometry(gpu_lib):
+    """An EIGHTH of config c4 itself: 77.5 M reads of a 387.5 Mbp genome at 30x into c4's own geometry (`-s 3g`: k=33, -b37 --
+    16 GiB filter, 2^20 regions, 10+10 scatter levels, table segments that grow to 64 KiB), in calls of 16 M reads as scripts/c4_run.py and
+    bench.py's secondary `c4e` submit them: totals, distinct keys, both histograms and the filter's popcount + FNV-1a equal the reference's
+    (tests/golden/baseline.json[c4e]; the L1 digest of 470 M slots is left to the smaller shapes)."""
+    e = BASE["c4e"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 16_777_216)
+    _check_against(g, e, l1=False)
+    assert g.partition_info() == dict(one_pass=True, level2_one_pass=True, replayed_batches=0)
+    g.close()
+
+
 def test_c5_parameters(gpu_lib):
     """`-s 3g -k51 -1`: k=51, -b37, filter mode (two 16 GiB filters with both slices of a region in LDS, 20-byte records)."""
     e = BASE["c5s"]

@@ -116,15 +116,14 @@ def test_random_configuration_chunked_reservations(gpu_lib, seed, chunk, monkeyp
 
 
 @pytest.mark.parametrize("seed", range(30))
-def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch):
-    """BFCG_S1_WC=1 (opt-in, round 3): level 1 of the one-pass partition through write-combining LDS buffers (k_scatter1_wc: 16-record chunks
-    per bucket, dead records padding every workgroup's last chunks, all of a workgroup's records in its home XCD's slabs) on draws with
-    k > 32 and 12-byte records, forced onto tiny slabs (overflows are replayed through two passes) -- bit for bit the oracle's filter,
-    statistics and table, like every other draw (k = 33 and 35 put onto the draws; where 35 needs 16-byte records the default kernels run)."""
-    monkeypatch.setenv("BFCG_S1_WC", os.environ.get("BFC_TEST_S1_WC", "1"))  # 2: the launcher says on stderr when the variant runs
+def test_random_configuration_k33_on_tiny_slabs(gpu_lib, seed, monkeypatch):
+    """The default path's own geometry -- k > 32 with 12-byte records (k = 33 and 35 put onto the draws; where 35 needs 16-byte records the
+    generic kernels run): K1 on 32-bit halves, the 32-bit decode of k_bloom3 with its block marks and worklists, the hand-over log -- forced
+    onto tiny slabs (overflows are replayed through two passes): bit for bit the oracle's filter, statistics and table.  (Round 3 ran this
+    family through the write-combining level-1 variant k_scatter1_wc, which round 4 removed: level with the tile kernel, never the default.)"""
     monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
     prm, seq, qual, off, cuts, kw = _draw(48000 + seed, scale=12, b_range=(26, 33))
-    prm = dict(prm, k=35 if seed % 5 == 4 else 33)  # the geometries the variant serves (12-byte records need k <= 31 + F1 / 2)
+    prm = dict(prm, k=35 if seed % 5 == 4 else 33)
     _check(gpu_lib, prm, seq, qual, off, cuts, kw)
 
 

@@ -163,6 +163,44 @@ def test_group_level2_slab_overflow_is_replayed(gpu_lib, n_ranks, fm):
     grp.close(); oc.close()
 
 
+@pytest.mark.parametrize("n_ranks", [2, 4])
+@pytest.mark.parametrize("fm", [0, 1])
+def test_group_level1_slab_overflow_falls_back_to_two_passes(gpu_lib, n_ranks, fm):
+    """Stage A of a rank is one pass into slabs (round 4).  First a clean global batch (100 000 reads of a 50 Mbp genome: slab mode stays on), then
+    200 000 reads of a 400-base genome -- few, often repeated k-mers overflow a level-1 slab on some rank: EVERY rank repeats its stage A of
+    that batch through the two-pass partition (its k-mers are not counted twice), the exchange carries exact bucket sizes again, the run stays
+    with two passes until the reset -- and a third, clean batch behind it: the oracle's filter(s), statistics and table throughout."""
+    rng = np.random.default_rng(900 + n_ranks + fm)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L = 150
+    def reads(G, n, err):
+        genome = rng.choice(acgt, G + L)
+        s = genome[(rng.integers(0, G, n)[:, None] + np.arange(L)[None, :])].astype(np.uint8)
+        if err:
+            m = rng.random(s.shape) < err
+            s[m] = acgt[rng.integers(0, 4, int(m.sum()))]
+        return s.reshape(-1)
+    parts = [reads(50_000_000, 100_000, 0), reads(400, 200_000, 0.01), reads(50_000_000, 100_000, 0)]
+    seq = np.concatenate(parts)
+    n = len(seq) // L
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    k, b = 31, 30
+    oc = _oracle(k, b, seq, qual, off, filter_mode=fm)
+    grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=200_000 * (L + 1) // n_ranks + 4096, filter_mode=fm)
+    assert grp.info()["slab_mode"]
+    o = 0
+    for i, p in enumerate(parts):
+        e = o + len(p)
+        grp.count_host(gen.to_stream(seq[o:e], L, 10), gen.to_stream(qual[o:e], L, 33))
+        assert grp.info()["slab_mode"] == (i == 0), (i, grp.info())
+        o = e
+    _compare(grp, oc, fm)
+    grp.reset()
+    assert grp.info()["slab_mode"]  # the next data set starts in one pass again
+    grp.close(); oc.close()
+
+
 @pytest.mark.parametrize("fm", [0, 1])
 def test_group_overloaded_ranks_process_sources_in_groups(gpu_lib, g1, fm):
     """-b24 over 4 ranks: 32 bloom regions per rank take ~80 000 k-mers per pass at full speed, a global batch brings each rank 200 000.  The

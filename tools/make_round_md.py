@@ -9,13 +9,13 @@ import json
 import os
 import sys
 
-ROUND = os.environ.get("ROUND", "3")
+ROUND = os.environ.get("ROUND", "4")
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_profile_md import kernel_rows, pmc_rows, short  # noqa: E402
 
 STAGE = {"k_seg_setup": "scatter1", "k_hist1": "hist1", "k_colsum": "hist1", "k_scan_top": "hist1", "k_apply": "hist1", "k_scatter1": "scatter1",
-         "k_hist2": "level2", "k_scan2": "level2", "k_scatter2": "level2", "k_bloom": "bloom",
+         "k_hist2": "level2", "k_scan2": "level2", "k_scatter2": "level2", "k_bloom": "bloom", "k_bloom3": "bloom",
          "k_commit": "commit", "k_commit_stream": "commit", "k_commit_seg": "commit"}
 
 
@@ -57,7 +57,8 @@ def main(d, workload):
     if not pm:
         return
     jp = bench_line(os.path.join(d, "pmc_fetch.log")) or j
-    n_batches = max(pm.get("k_bloom", {}).get("FETCH_SIZE", (1, 0))[0], 1)
+    # a batch = one launch of the bloom insert: k_bloom3, or k_bloom for a batch into an empty filter (copies resolved by class)
+    n_batches = max(pm.get("k_bloom", {}).get("FETCH_SIZE", (0, 0))[0] + pm.get("k_bloom3", {}).get("FETCH_SIZE", (0, 0))[0], 1)
     print("\n## PMC counters (separate passes, BFCG_SYNC_BATCHES=1); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; per launch of the kernel\n")
     print("| kernel | launches | read GB (FETCH_SIZE x2) | write GB | L2 hit % | SQ_WAIT_ANY / SQ_WAVE_CYCLES | LDS bank conflict cycles / LDS instruction |")
     print("|---|---|---|---|---|---|---|")
