@@ -786,7 +786,10 @@ struct OnePass2 { uint32_t *cnt2; uint32_t cap2; uint32_t *flags; };
 // last kernel of a one-pass batch's stage B: a batch that overflowed a slab (level 1: flags[0], level 2: flags[2]) poisons the run
 __global__ void k_seal(const uint32_t *flags, uint32_t *sticky) { if (flags[0] | flags[2]) *sticky = 1; }
 
-template <typename W, int RW, int TILE, int BT, bool ONEPASS2 = false>
+// FAST2 (12-byte records whose region is a bit field of their first word -- scatter2_fast: k >= bf_shift - 9, so the block id is y0's low bits,
+// and the bits below rec_lo = R + F2 are stored as they are): the level-2 bucket is (d[0] >> R) & (2^F2 - 1), no record is unpacked, no hash
+// recomputed -- twice per record in the generic code (ranking and copy-out).
+template <typename W, int RW, int TILE, int BT, bool ONEPASS2 = false, bool FAST2 = false>
 __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__restrict__ in, const uint32_t *__restrict__ seg_beg,
                                                  const uint32_t *__restrict__ seg_end, int n_seg, int segs_per_bucket,
                                                  const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ rows2,
@@ -821,8 +824,9 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 			uint64_t y0, y1; uint32_t idx; bool hi;
 			w[j] = rec_load<RW>(in + i * RW);
 			if (!rec_dead<RW>(w[j])) { // (what a level-1 workgroup left unused of its last chunk -- OnePass)
-				Rec<RW>::unpack(w[j], RG, imp, y0, y1, idx, hi);
-				uint32_t b = fine_id<W>(P, y0, y1) & (nb2 - 1);
+				uint32_t b;
+				if constexpr (FAST2) b = (w[j].d[0] >> P.R) & (uint32_t)(nb2 - 1);
+				else { Rec<RW>::unpack(w[j], RG, imp, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) & (nb2 - 1); }
 				br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
 			}
 		}
@@ -866,6 +870,7 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		for (int t = 0; t < RW; ++t) rec.d[t] = stage[(size_t)pos * RW + t];
 		uint32_t b;
 		if (KEEP_BK) b = sbk[pos];
+		else if constexpr (FAST2) b = (rec.d[0] >> P.R) & (uint32_t)(nb2 - 1);
 		else { uint64_t y0, y1; uint32_t idx; bool hi; Rec<RW>::unpack(rec, RG, imp, y0, y1, idx, hi); b = fine_id<W>(P, y0, y1) & (uint32_t)(nb2 - 1); }
 		const uint64_t dst = (uint32_t)(pos + gdelta[b]);
 		rec_store<RW>(out + dst * RW, rec);
@@ -2205,6 +2210,13 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	if (ev) hipEventRecord(ev[2], st);
 }
 
+// k_scatter2<..., FAST2>: the region's low F2 bits are bits [R, R + F2) of a 12-byte record's first word
+static inline bool scatter2_fast(const KParams &P)
+{
+	const int a = P.k - P.rec_n;
+	return P.k >= P.bf_shift - 9 && P.F2 > 0 && P.R + P.F2 <= 31 && a >= P.R + P.F2 && P.rec_lo == P.R + P.F2 && !getenv("BFCG_NO_FAST_S2");
+}
+
 // k_bloom<..., F3>: dec3_geom's conditions, on the host
 static inline bool bloom_fast3(const KParams &P)
 {
@@ -2247,6 +2259,10 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
 		if (B.cap2) { // one pass: region slabs and cursors
 			hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
+			if (RW == 3 && scatter2_fast(P))
+				hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true, RW == 3>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+				                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
+			else
 			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
 			                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
 		} else {
@@ -2365,6 +2381,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	}
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
+	if (RW == 3) { e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true, RW == 3>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e; }
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
