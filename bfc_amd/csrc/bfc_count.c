@@ -167,6 +167,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	prm.max_batch_pos = cap;
 	timing = getenv("BFC_GPU_TIMING") != 0; /* phase times on stderr */
 	tt = now_real();
+	if (timing) fprintf(stderr, "[T::bfc_count] entered %.3f s after the process started\n", tt - t0);
 	n_dev = bfcg_env_devices(devs, 64);
 	if (n_dev > 1 && (n_dev & (n_dev - 1))) { fprintf(stderr, "[E::%s] BFC_GPU_DEVICES names %d devices: the bloom regions are dealt to a power of two of GPUs\n", __func__, n_dev); abort(); }
 	if (n_dev > 1) prm.max_batch_pos = cap / (uint64_t)n_dev + cap / 64 + (1u << 16); /* every rank takes 1/n of each batch (cut at read boundaries: shares differ by a read or two) */
@@ -253,10 +254,17 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	                            : (void*)bfcg_export_table(ctx);
 	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
+	/* (Round 4 tried to take the clean-up off the path -- buffers pinned by four threads, buffers and input released by a thread of its own under
+	 * the export, large tables freed by a detached thread: every one of these contends with the export's own allocations and page faults for the
+	 * same locks; the process' wall time did not move: profiles/round4_e2e.md) */
+	tt = now_real();
 	for (i = 0; i < 2; ++i) { if (pin) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); } else { free(pp.b[i].seq); free(pp.b[i].qual); } free(pp.b[i].kind_cut); }
 	pthread_mutex_destroy(&pp.mtx); pthread_cond_destroy(&pp.cv);
+	t_wait = now_real() - tt; tt = now_real();
 	ingest_close(&ps);
+	t_submit = now_real() - tt; tt = now_real();
 	if (grp) bfcg_group_destroy(grp); else bfcg_destroy(ctx); /* the first bloom filter dies here, as in count.c:155 */
+	if (timing) fprintf(stderr, "[T::bfc_count] clean-up: host buffers %.3f s, input closed %.3f s, GPU context%s destroyed %.3f s; left %.3f s after the process started\n", t_wait, t_submit, grp ? "s" : "", now_real() - tt, now_real() - t0);
 	return ret;
 }
 

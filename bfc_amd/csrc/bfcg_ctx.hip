@@ -23,6 +23,7 @@ using namespace bfcg;
 static thread_local char g_err[512] = "";
 enum { HO_MAX_PAGES = 8 };
 enum { OP_FLAG_WORDS = 12, OP_STICKY = 8 }; // bfcg_ctx.op_flags: two slots of four words, the sticky poison word
+static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static int set_err(const char *fmt, ...)
 {
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -122,7 +123,10 @@ static int clamp_lpre(int k, int l_pre) // htab.c:24-26
 extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 {
 	int ndev = 0;
+	const bool timing = getenv("BFC_GPU_TIMING") != 0; // (phase times on stderr, as bfc_count's)
+	const double t_c0 = dbg_now();
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("no HIP device available: the counting path has no CPU fallback"); return NULL; }
+	const double t_c1 = dbg_now();
 	if (prm->device < 0 || prm->device >= ndev) { set_err("device %d out of range (%d devices)", prm->device, ndev); return NULL; }
 	if (prm->k < 1 || prm->k > 63) { set_err("k=%d outside [1,63] (bfc.h:8, htab.c:23)", prm->k); return NULL; }
 	if (prm->bf_shift < 9 + 0 || prm->bf_shift > 37) { set_err("bf_shift=%d outside [9,37] (bbf.c:9, bfc.h:9)", prm->bf_shift); return NULL; }
@@ -383,8 +387,11 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	c->d_seq = c->d_seq2[0]; c->d_qual = c->d_qual2[0];
 	HIPCKN(hipHostMalloc(&c->h_stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 2)));
 	for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_snap[b], sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1)));
+	const double t_c2 = dbg_now();
 	HIPCKN(set_bloom_lds_attr(P));
+	const double t_c3 = dbg_now();
 	if (bfcg_reset(c) != 0) { bfcg_destroy(c); return NULL; }
+	if (timing) fprintf(stderr, "[T::bfcg_create] HIP runtime up %.3f s, device buffers %.3f s, kernel attributes %.3f s, filter and table cleared %.3f s\n", t_c1 - t_c0, t_c2 - t_c1, t_c3 - t_c2, dbg_now() - t_c3);
 	return c;
 }
 
@@ -430,7 +437,6 @@ static void warm_tables(const bfcg_ctx_t *c, KParams &Pt)
 }
 static int dedupe_hint(const bfcg_ctx_t *c) { return (c->n_batches == 0 || (c->cold && c->seen_per_pos < 0.15)) && !getenv("BFCG_NO_DEDUPE"); }
 
-static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 extern "C" int bfcg_reset(bfcg_ctx_t *c)
 {
 	const double t_dbg = dbg_now();
@@ -519,7 +525,7 @@ static void fold_snapshot(bfcg_ctx_t *c, int b)
 static int table_maintain(bfcg_ctx_t *c);
 static int seg_maintain(bfcg_ctx_t *c);
 static int seg_target_shift(const bfcg_ctx_t *c);
-static int seg_to_legacy(bfcg_ctx_t *c);
+static int seg_to_legacy(bfcg_ctx_t *c, int for_export = 0);
 static void note_growth(bfcg_ctx_t *c);
 static int finalise_previous(bfcg_ctx_t *c, int b);
 static int table_target_cshift(const bfcg_ctx_t *c);
@@ -770,14 +776,19 @@ static int seg_maintain(bfcg_ctx_t *c)
 
 // The table in the host's layout (2^l_pre sub-tables, htab.c:45-58) from the segments: for export, for the k-mer coverage kernels, and
 // for runs whose segments outgrow LDS.  The device must be idle.  Afterwards the context counts on in that layout until bfcg_reset.
-static int seg_to_legacy(bfcg_ctx_t *c)
+// for_export: the table is about to leave for the host (bfcg_export_table: normally the end of the count).  Every byte of it is allocated,
+// cleared, copied over PCIe into fresh host pages and freed again -- 10 ms per GB each in the driver alone -- so it is sized for a load of
+// at most 4/7 there, not for another batch's keys (a context that does count on grows it like any table: table_maintain); the export of a
+// chr1-sized genome's 249 M keys moved 8 GiB before, 4 GiB now.
+static int seg_to_legacy(bfcg_ctx_t *c, int for_export)
 {
 	KParams &P = c->P; BatchBufs &B = c->B;
 	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
 	const uint64_t keys = c->h_stats[ST_KEYS];
 	if (c->seg_spare) { HIPCK(hipFree(c->seg_spare)); c->seg_spare = 0; }
 	int cs = c->prm.tab_cshift > 0 ? c->prm.tab_cshift : 2;
-	while ((1ULL << (P.l_pre + cs)) < 2 * keys + (c->prm.max_batch_pos / 4) && P.l_pre + cs < 36) ++cs;
+	const uint64_t want = for_export ? keys + keys * 3 / 4 : 2 * keys + (c->prm.max_batch_pos / 4);
+	while ((1ULL << (P.l_pre + cs)) < want && P.l_pre + cs < 36) ++cs;
 	{ // as much as memory allows (the segments live until the table is filled)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -797,6 +808,7 @@ static int seg_to_legacy(bfcg_ctx_t *c)
 	HIPCK(set_bloom_lds_attr(P)); // the aggregation table is back in the bloom kernel's LDS footprint
 	if (fetch_stats(c) != 0) return -1;
 	c->keys_last = c->h_stats[ST_KEYS];
+	if (for_export && c->h_stats[ST_TAB_OVF] == 0) return 0; // (no head room for a forecast batch: the next batch's check_health grows the table if there is one)
 	return table_maintain(c);
 }
 
@@ -1438,13 +1450,19 @@ extern "C" bfc_bf_t *bfcg_export_bloom_resident(bfcg_ctx_t *c, int which)
 extern "C" bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c)
 {
 	if (c->P.filter_mode) { set_err("no count table in filter mode"); return NULL; }
+	const double t_e0 = dbg_now();
 	if (drain(c) != 0) return NULL;
-	if (c->P.seg && seg_to_legacy(c) != 0) return NULL; // the host's (sub-table, key) layout is made now
+	const double t_e1 = dbg_now();
+	if (c->P.seg && seg_to_legacy(c, 1) != 0) return NULL; // the host's (sub-table, key) layout is made now
 	bfc_ch_t *ch = bfc_ch_alloc_raw(c->P.k, c->P.l_pre, c->P.tab_cshift);
 	if (!ch) { set_err("host allocation of the count table failed"); return NULL; }
-	if (hipStreamSynchronize(c->st) != hipSuccess || d2h_parallel(c->prm.device, bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift)) != 0) {
+	if (hipStreamSynchronize(c->st) != hipSuccess) { set_err("the conversion of the table segments failed"); bfc_ch_destroy(ch); return NULL; }
+	const double t_e2 = dbg_now();
+	if (d2h_parallel(c->prm.device, bfc_ch_raw_slots(ch), c->B.table, 8ULL << (c->P.l_pre + c->P.tab_cshift)) != 0) {
 		set_err("D2H copy of the count table failed"); bfc_ch_destroy(ch); return NULL;
 	}
+	if (getenv("BFC_GPU_TIMING")) fprintf(stderr, "[T::bfcg_export_table] batches in flight finished %.3f s, segments -> host layout (2^%d slots) %.3f s, device -> host %.3f s\n",
+	                                      t_e1 - t_e0, c->P.l_pre + c->P.tab_cshift, t_e2 - t_e1, dbg_now() - t_e2);
 	if (c->B.tab_first) { // order stamps travel with the table (with several ranks: into bfc_ch_union): bfc_ch_dump can then reproduce khash's layout byte for byte
 		uint64_t *hf = 0, *hl = 0;
 		if (bfc_ch_raw_order(ch, &hf, &hl) != 0 ||

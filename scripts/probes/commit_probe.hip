@@ -52,13 +52,17 @@ __device__ __forceinline__ int seg_upsert(unsigned long long *seg, uint32_t mask
 	return -1;
 }
 
-// V0 and its ablations (MODE 0: all, 1: no upserts, 2: no stream)
+// V0 and its ablations (MODE 0: all, 1: no upserts, 2: no stream, 3: all, six entries per thread requested before the segment)
 template <int BT, int MODE>
 __global__ __launch_bounds__(BT) void k_v0(Args A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
 	__shared__ uint32_t s_new[8], s_mark[8];
 	const uint32_t f = blockIdx.x, pages = A.pages;
+	if (MODE >= 4 && blockIdx.x < 512u && (blockIdx.x & 1u)) { // the first workgroups to become resident: every second one waits (MODE - 3) x 3 us
+		const long long t0 = wall_clock64();
+		while (wall_clock64() - t0 < (long long)(MODE - 3) * 300) __builtin_amdgcn_s_sleep(8); // (100 MHz counter)
+	}
 	const uint32_t n = A.mark[(size_t)(pages - 1) * A.mark_stride + f];
 	const unsigned long long *recs = A.log + (uint64_t)f * A.log_stride;
 	const uint32_t slots = 1u << A.seg_shift, mask = slots - 1;
@@ -66,6 +70,8 @@ __global__ __launch_bounds__(BT) void k_v0(Args A)
 	if (threadIdx.x < 8) { s_new[threadIdx.x] = 0; s_mark[threadIdx.x] = threadIdx.x < pages ? A.mark[(size_t)threadIdx.x * A.mark_stride + f] : n; }
 	uint32_t j = threadIdx.x;
 	const unsigned long long pre0 = j < n ? recs[j] : 0ULL, pre1 = j + BT < n ? recs[j + BT] : 0ULL;
+	unsigned long long pre2 = 0, pre3 = 0, pre4 = 0, pre5 = 0;
+	if (MODE == 3) { pre2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL; pre3 = j + 3 * BT < n ? recs[j + 3 * BT] : 0ULL; pre4 = j + 4 * BT < n ? recs[j + 4 * BT] : 0ULL; pre5 = j + 5 * BT < n ? recs[j + 5 * BT] : 0ULL; }
 	if (MODE != 2) {
 		const uint4 *src = reinterpret_cast<const uint4 *>(gseg);
 		uint4 *dst = reinterpret_cast<uint4 *>(lseg);
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(BT) void k_v0(Args A)
 		const uint32_t end = s_mark[pg];
 		uint32_t n_new = 0;
 		if (MODE != 1) for (; j < end; j += BT, ++k) {
-			const unsigned long long v = k == 0 ? pre0 : k == 1 ? pre1 : recs[j];
+			const unsigned long long v = k == 0 ? pre0 : k == 1 ? pre1 : MODE == 3 && k == 2 ? pre2 : MODE == 3 && k == 3 ? pre3 : MODE == 3 && k == 4 ? pre4 : MODE == 3 && k == 5 ? pre5 : recs[j];
 			const int r = seg_upsert(lseg, mask, v >> 1, 1u, (uint32_t)(v & 1));
 			if (r > 0) ++n_new;
 		}
@@ -160,6 +166,73 @@ __global__ __launch_bounds__(BT) void k_v1(Args A)
 	}
 }
 
+
+// V2: persistent workgroups of 16 waves, two 64 KiB buffers, roles by wave: the lower half moves segments (store the previous region, load the
+// next one: global -> registers -> LDS at once, nothing held across a phase), the upper half applies the current region's pages.  One barrier
+// per page and round.
+template <int BT>
+__global__ __launch_bounds__(BT) void k_v2(Args A)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned long long lbuf[];
+	__shared__ uint32_t s_new[2][8], s_mark[2][8];
+	constexpr int HT = BT / 2;
+	const uint32_t pages = A.pages, slots = 1u << A.seg_shift, mask = slots - 1;
+	const bool mover = threadIdx.x < HT;
+	const uint32_t t = mover ? threadIdx.x : threadIdx.x - HT;
+	uint32_t f = blockIdx.x;
+	if (f >= A.n_fine) return;
+	auto load_seg = [&](uint32_t ff, int b) {
+		const uint4 *src = reinterpret_cast<const uint4 *>(A.seg + ((uint64_t)ff << A.seg_shift));
+		uint4 *dst = reinterpret_cast<uint4 *>(lbuf + (size_t)b * slots);
+		for (uint32_t i = t; i < slots / 2; i += HT) dst[i] = src[i];
+	};
+	auto store_seg = [&](uint32_t ff, int b) {
+		uint4 *dst = reinterpret_cast<uint4 *>(A.seg + ((uint64_t)ff << A.seg_shift));
+		const uint4 *src = reinterpret_cast<const uint4 *>(lbuf + (size_t)b * slots);
+		for (uint32_t i = t; i < slots / 2; i += HT) dst[i] = src[i];
+	};
+	auto marks = [&](uint32_t ff, int b) { // (by the movers' first lanes)
+		if (t < 8) { const uint32_t n = A.mark[(size_t)(pages - 1) * A.mark_stride + ff]; s_new[b][t] = 0; s_mark[b][t] = t < pages ? A.mark[(size_t)t * A.mark_stride + ff] : n; }
+	};
+	if (mover) { load_seg(f, 0); marks(f, 0); }
+	int cur = 0;
+	uint32_t prev = 0xffffffffu;
+	for (;;) {
+		__syncthreads(); // buffer cur holds region f; buffer cur ^ 1 holds region prev, its pages applied
+		const uint32_t fn = f + gridDim.x;
+		const bool more = fn < A.n_fine;
+		if (mover) {
+			if (prev != 0xffffffffu) {
+				store_seg(prev, cur ^ 1);
+				if (t < pages && s_new[cur ^ 1][t]) atomicAdd(&A.stats[(size_t)(prev & 255) * 8 + t], (unsigned long long)s_new[cur ^ 1][t]);
+			}
+		}
+		if (mover && more) { __builtin_amdgcn_s_waitcnt(0); /* (the LDS reads of the store are done before the buffer is overwritten) */ }
+		if (!mover) {
+			unsigned long long *lseg = lbuf + (size_t)cur * slots;
+			const unsigned long long *recs = A.log + (uint64_t)f * A.log_stride;
+			uint32_t j = t;
+			for (uint32_t pg = 0; pg < pages; ++pg) {
+				const uint32_t end = s_mark[cur][pg];
+				uint32_t n_new = 0;
+				for (; j < end; j += HT) { const unsigned long long v = recs[j]; if (seg_upsert(lseg, mask, v >> 1, 1u, (uint32_t)(v & 1)) > 0) ++n_new; }
+				for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+				if ((t & 63) == 0 && n_new) atomicAdd(&s_new[cur][pg], n_new);
+				// (pages of one region are applied by the upper half alone: its waves meet at the round's barrier only -- per-page key counts
+				// would need a barrier among them; the probe counts per round)
+			}
+		} else if (more) { load_seg(fn, cur ^ 1); marks(fn, cur ^ 1); }
+		prev = f;
+		if (!more) break;
+		f = fn; cur ^= 1;
+	}
+	__syncthreads();
+	if (mover) {
+		store_seg(prev, cur);
+		if (t < pages && s_new[cur][t]) atomicAdd(&A.stats[(size_t)(prev & 255) * 8 + t], (unsigned long long)s_new[cur][t]);
+	}
+}
+
 __global__ void k_digest(const unsigned long long *seg, uint64_t n, unsigned long long *out)
 {
 	unsigned long long s = 0, c = 0;
@@ -184,6 +257,11 @@ int main(int argc, char **argv)
 	CK(hipFuncSetAttribute((const void *)k_v0<1024, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	CK(hipFuncSetAttribute((const void *)k_v0<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	CK(hipFuncSetAttribute((const void *)k_v0<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	CK(hipFuncSetAttribute((const void *)k_v0<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	CK(hipFuncSetAttribute((const void *)k_v0<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	CK(hipFuncSetAttribute((const void *)k_v0<1024, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	CK(hipFuncSetAttribute((const void *)k_v0<1024, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	CK(hipFuncSetAttribute((const void *)k_v2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
 	CK(hipFuncSetAttribute((const void *)k_v0<512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	CK(hipFuncSetAttribute((const void *)k_v1<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
 	CK(hipFuncSetAttribute((const void *)k_v1<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
@@ -206,8 +284,12 @@ int main(int argc, char **argv)
 #define RUN(name, launch) do { rebuild(); CK(hipEventRecord(e0, 0)); launch; CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); float ms_; CK(hipEventElapsedTime(&ms_, e0, e1)); report(name, ms_); } while (0)
 	for (int rep = 0; rep < 2; ++rep) {
 		RUN("V0 shipped structure, 1024 thr", hipLaunchKernelGGL((k_v0<1024, 0>), dim3(NF), dim3(1024), lds, 0, A));
+		RUN("V0p six entries ahead, 1024 thr", hipLaunchKernelGGL((k_v0<1024, 3>), dim3(NF), dim3(1024), lds, 0, A));
+		RUN("V0 staggered by 3 us", hipLaunchKernelGGL((k_v0<1024, 4>), dim3(NF), dim3(1024), lds, 0, A));
+		RUN("V0 staggered by 6 us", hipLaunchKernelGGL((k_v0<1024, 5>), dim3(NF), dim3(1024), lds, 0, A));
+		RUN("V0 staggered by 9 us", hipLaunchKernelGGL((k_v0<1024, 6>), dim3(NF), dim3(1024), lds, 0, A));
+		if (2 * lds <= 160 * 1024 - 2048) RUN("V2 loader waves + upsert waves", hipLaunchKernelGGL((k_v2<1024>), dim3(n_cu), dim3(1024), 2 * lds, 0, A));
 		RUN("V0s stream only", hipLaunchKernelGGL((k_v0<1024, 1>), dim3(NF), dim3(1024), lds, 0, A));
-		RUN("V0u upserts only", hipLaunchKernelGGL((k_v0<1024, 2>), dim3(NF), dim3(1024), lds, 0, A));
 		RUN("V0 512 thr", hipLaunchKernelGGL((k_v0<512, 0>), dim3(NF), dim3(512), lds, 0, A));
 		if (2 * lds <= 160 * 1024 - 2048) {
 			RUN("V1 persistent 2 buffers, 1024 thr", hipLaunchKernelGGL((k_v1<1024, 4>), dim3(n_cu), dim3(1024), 2 * lds, 0, A));
