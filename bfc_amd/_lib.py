@@ -65,6 +65,9 @@ SYMBOLS = {
     "bfcg_reset": (C.c_int, [C.c_void_p]),
     "bfcg_count_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bfcg_plane_words": (C.c_uint64, [C.c_uint64]),
+    "bfcg_pack_planes": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]),
+    "bfcg_count_batch_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
     "bfcg_sync": (C.c_int, [C.c_void_p]),
     "bfcg_mg_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "bfcg_batch_limit": (C.c_uint64, [C.c_void_p]),

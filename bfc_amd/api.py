@@ -191,6 +191,22 @@ def bfc_count(fn, opt):
     return HostTable(p)
 
 
+def pack_planes(seq_stream, qual_stream, q, n_threads=1):
+    """The four bit planes of a byte-stream batch (bfcg_pack_planes; no GPU involved): uint32 array [4, bfcg_plane_words(n)]."""
+    L = _lib.load()
+    seq_stream = np.ascontiguousarray(seq_stream, dtype=np.uint8)
+    qs = np.ascontiguousarray(qual_stream, dtype=np.uint8) if qual_stream is not None else None
+    n = len(seq_stream)
+    pw = int(L.bfcg_plane_words(n))
+    planes = np.zeros((4, pw), dtype=np.uint32)
+    if qs is None:
+        planes[3, :] = 0xffffffff
+    step = ((n + n_threads - 1) // n_threads + 31) // 32 * 32 if n_threads > 1 else max(n, 32)
+    for lo in range(0, n, max(step, 32)):
+        L.bfcg_pack_planes(seq_stream.ctypes.data, qs.ctypes.data if qs is not None else None, lo, min(n, lo + max(step, 32)), n, q, planes.ctypes.data, pw)
+    return planes
+
+
 class GpuCounter:
     """Device-level counting context (bfcg_ctx_t)."""
 
@@ -240,6 +256,12 @@ class GpuCounter:
         seq_stream = np.ascontiguousarray(seq_stream, dtype=np.uint8)
         q = np.ascontiguousarray(qual_stream, dtype=np.uint8) if qual_stream is not None else None
         self._ck(self.L.bfcg_count_batch_host(self.ctx, seq_stream.ctypes.data, q.ctypes.data if q is not None else None, len(seq_stream)))
+
+    def count_planes(self, planes, first_pos, n_pos, has_qual=True):
+        """positions [first_pos, first_pos + n_pos) of a plane set made by pack_planes (4 bits per position over PCIe instead of 16)"""
+        planes = np.ascontiguousarray(planes, dtype=np.uint32)
+        assert planes.ndim == 2 and planes.shape[0] == 4
+        self._ck(self.L.bfcg_count_batch_planes(self.ctx, planes.ctypes.data, planes.shape[1], first_pos, n_pos, 1 if has_qual else 0))
 
     def count_dev(self, d_seq, d_qual, n_pos):
         self._ck(self.L.bfcg_count_batch_dev(self.ctx, d_seq, d_qual, n_pos))

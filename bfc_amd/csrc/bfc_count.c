@@ -41,6 +41,21 @@ static double now_cpu(void)
 
 #include "bfc_ingest.h"
 
+/* Plain (unpinned) batch buffers: 2 MiB-aligned and advised to use huge pages -- 64 parser threads touching 1.6 GB of fresh 4 KiB pages take the
+ * address space's lock 400 000 times beside the context's hipMalloc calls (device buffers 0.4 -> 1.0 s when they did), and giving such pages back
+ * costs as much as unpinning them.  Advisory: where transparent huge pages are off this is a plain aligned allocation. */
+#include <sys/mman.h>
+static void *big_alloc(uint64_t bytes)
+{
+	void *p = 0;
+	const uint64_t rounded = (bytes + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+	if (posix_memalign(&p, 2u << 20, rounded) != 0) return 0;
+#ifdef MADV_HUGEPAGE
+	(void)madvise(p, rounded, MADV_HUGEPAGE);
+#endif
+	return p;
+}
+
 /* ------------------------------------------------------------------ reader thread, one batch ahead */
 
 typedef struct {
@@ -49,7 +64,34 @@ typedef struct {
 	int ready[2];   /* filled and not yet consumed */
 	int done;
 	pthread_mutex_t mtx; pthread_cond_t cv;
+	/* one GPU: a filled batch is packed into its four bit planes (bfcg_pack_planes: 4 bits per position cross PCIe instead of 16) by the
+	 * parser's own threads, and only the planes' buffers are pinned -- an eighth of the bytes the two streams take */
+	uint32_t *planes[2]; uint64_t plane_words; int q, pack_threads;
+	bfc_pool_t *pack_pool; /* the submitting thread packs batch t with workers of its own while the reader's threads parse batch t + 1 */
 } pipe_t;
+
+typedef struct { const batch_t *b; uint32_t *planes; uint64_t plane_words, lo, hi; int q; } pack_job_t;
+static void *pack_main(void *arg)
+{
+	pack_job_t *j = (pack_job_t*)arg;
+	bfcg_pack_planes(j->b->seq, j->b->has_qual ? j->b->qual : 0, j->lo, j->hi, j->b->n_pos, j->q, j->planes, j->plane_words);
+	return 0;
+}
+static void pack_batch(pipe_t *pp, int i)
+{
+	pack_job_t job[64];
+	const batch_t *b = &pp->b[i];
+	int t, T = pp->pack_threads < 1 ? 1 : pp->pack_threads > 64 ? 64 : pp->pack_threads;
+	uint64_t per;
+	if (b->n_pos == 0) return;
+	if (b->n_pos < ((uint64_t)T << 16)) T = 1;
+	per = ((b->n_pos + T - 1) / T + 31) & ~(uint64_t)31; /* threads pack disjoint words */
+	for (t = 0; t < T; ++t) {
+		job[t].b = b; job[t].planes = pp->planes[i]; job[t].plane_words = pp->plane_words; job[t].q = pp->q;
+		job[t].lo = per * t < b->n_pos ? per * t : b->n_pos; job[t].hi = per * (t + 1) < b->n_pos ? per * (t + 1) : b->n_pos;
+	}
+	bfc_pool_run(pp->pack_pool, pack_main, job, sizeof(pack_job_t), T);
+}
 
 static void *reader_main(void *arg)
 {
@@ -133,8 +175,8 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	const char *env;
 	double t0 = (&bfc_real_time && bfc_real_time > 0.) ? bfc_real_time : now_real();
 	uint64_t cap, bases;
-	int i, cur = 0, io_threads, timing, small_input = 0, pin;
-	double tt, t_wait = 0, t_submit = 0;
+	int i, cur = 0, io_threads, timing, small_input = 0, pin, use_planes;
+	double tt, t_wait = 0, t_submit = 0, t_pack = 0;
 	uint64_t pend_call[64]; int pend_seqs[64]; unsigned n_pend_lo = 0, n_pend_hi = 0; /* reader batches submitted, their progress line not printed yet */
 
 	bfcg_params_default(&prm);
@@ -181,15 +223,21 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	if (ingest_open(&ps, fn, bases, io_threads, opt->no_mt_io ? 1 : 2) != 0) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, fn ? fn : "-"); abort(); }
 
 	pin = (env = getenv("BFC_GPU_PIN")) ? atoi(env) != 0 : !small_input;
+	/* one GPU: batches cross PCIe as bit planes (BFC_GPU_PLANES=0: as byte streams); several GPUs: every rank takes its share of the streams */
+	use_planes = n_dev <= 1 && !((env = getenv("BFC_GPU_PLANES")) && atoi(env) == 0);
 	memset(&pp, 0, sizeof(pp));
 	pp.ps = &ps;
+	pp.q = opt->q; pp.pack_threads = io_threads > 32 ? 32 : io_threads > 1 ? io_threads : 1; pp.plane_words = bfcg_plane_words(cap);
+	if (use_planes && pp.pack_threads > 1) pp.pack_pool = bfc_pool_create(pp.pack_threads);
 	pthread_mutex_init(&pp.mtx, 0); pthread_cond_init(&pp.cv, 0);
 	for (i = 0; i < 2; ++i) {
 		pp.b[i].cap = cap;
-		/* pinning costs ~0.35 ms per MB (4 buffers of a batch each): it pays from a few GB of input on; below, plain memory and staged copies */
-		if (pin) { pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap); }
-		else { pp.b[i].seq = (uint8_t*)malloc(cap); pp.b[i].qual = (uint8_t*)malloc(cap); }
-		if (!pp.b[i].seq || !pp.b[i].qual) { fprintf(stderr, "[E::%s] cannot pin %llu bytes of host memory\n", __func__, (unsigned long long)cap); abort(); }
+		/* pinning costs ~0.35 ms per MB: it pays from a few GB of input on; below, plain memory and staged copies.  With planes only THEY are
+		 * copied to the device: a quarter of a stream's bytes each */
+		if (pin && !use_planes) { pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap); }
+		else { pp.b[i].seq = (uint8_t*)big_alloc(cap); pp.b[i].qual = (uint8_t*)big_alloc(cap); }
+		if (use_planes) pp.planes[i] = (uint32_t*)(pin ? bfcg_host_alloc(pp.plane_words * 16) : malloc(pp.plane_words * 16));
+		if (!pp.b[i].seq || !pp.b[i].qual || (use_planes && !pp.planes[i])) { fprintf(stderr, "[E::%s] cannot pin %llu bytes of host memory\n", __func__, (unsigned long long)cap); abort(); }
 	}
 	if (timing) fprintf(stderr, "[T::bfc_count] input opened (%s), pinned buffers: %.3f s\n", ps.fast.active ? "mapped, multi-threaded fast path" : "serial parser", now_real() - tt);
 	if (!opt->no_mt_io) pthread_create(&tid, 0, reader_main, &pp);
@@ -208,6 +256,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 			pthread_mutex_unlock(&pp.mtx);
 		}
 		t_wait += now_real() - tt; tt = now_real();
+		if (use_planes) { pack_batch(&pp, cur); t_pack += now_real() - tt; tt = now_real(); }
 		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs); /* count.c:99, once per bseq_read call */
 		if (b->n_seqs) {
 			int rc = 0;
@@ -218,10 +267,12 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 				for (j = 0; j <= b->n_cut && rc == 0; ++j, kind = !kind) {
 					const uint64_t e = j < b->n_cut ? b->kind_cut[j] : b->n_pos;
 					if (e > o) rc = grp ? bfcg_group_count_batch_host(grp, b->seq + o, kind ? b->qual + o : 0, e - o)
+					              : use_planes ? bfcg_count_batch_planes(ctx, pp.planes[cur], pp.plane_words, o, e - o, kind)
 					                    : bfcg_count_batch_host(ctx, b->seq + o, kind ? b->qual + o : 0, e - o);
 					o = e;
 				}
 			} else rc = grp ? bfcg_group_count_batch_host(grp, b->seq, b->has_qual ? b->qual : 0, b->n_pos)
+			          : use_planes ? bfcg_count_batch_planes(ctx, pp.planes[cur], pp.plane_words, 0, b->n_pos, b->has_qual)
 			                : bfcg_count_batch_host(ctx, b->seq, b->has_qual ? b->qual : 0, b->n_pos);
 			if (rc != 0) { fprintf(stderr, "[E::%s] GPU counting failed: %s\n", __func__, bfcg_last_error()); abort(); }
 			{ /* the line of count.c:110-114 is printed when the batch is COMPLETE on the GPU(s) -- without waiting for it here: the kernels of
@@ -252,13 +303,18 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	                                : (void*)bfcg_group_export_table(grp);
 	else ret = opt->filter_mode ? (void*)(getenv("BFC_GPU_NO_RESIDENT") ? bfcg_export_bloom(ctx, 1) : bfcg_export_bloom_resident(ctx, 1)) /* bf_high also stays in HBM for the trim pass (bfc_trim.c) */
 	                            : (void*)bfcg_export_table(ctx);
-	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
+	if (timing) fprintf(stderr, "[T::bfc_count] waited for the parser %.3f s, packed bit planes %.3f s, submitted batches %.3f s, result to the host %.3f s (%d fast / %d serial batches)\n", t_wait, t_pack, t_submit, now_real() - tt, ps.fast_batches, ps.serial_batches);
 	if (ret == 0) { fprintf(stderr, "[E::%s] cannot bring the result to the host: %s\n", __func__, bfcg_last_error()); abort(); }
 	/* (Round 4 tried to take the clean-up off the path -- buffers pinned by four threads, buffers and input released by a thread of its own under
 	 * the export, large tables freed by a detached thread: every one of these contends with the export's own allocations and page faults for the
 	 * same locks; the process' wall time did not move: profiles/round4_e2e.md) */
 	tt = now_real();
-	for (i = 0; i < 2; ++i) { if (pin) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); } else { free(pp.b[i].seq); free(pp.b[i].qual); } free(pp.b[i].kind_cut); }
+	for (i = 0; i < 2; ++i) {
+		if (pin && !use_planes) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); } else { free(pp.b[i].seq); free(pp.b[i].qual); }
+		if (pp.planes[i]) { if (pin) bfcg_host_free(pp.planes[i]); else free(pp.planes[i]); }
+		free(pp.b[i].kind_cut);
+	}
+	bfc_pool_destroy(pp.pack_pool);
 	pthread_mutex_destroy(&pp.mtx); pthread_cond_destroy(&pp.cv);
 	t_wait = now_real() - tt; tt = now_real();
 	ingest_close(&ps);

@@ -44,6 +44,8 @@ struct bfcg_ctx {
 	hipEvent_t evA[2], evB[2], evCopy; // stage A done / stage B done (buffer set reusable) / host batch copied
 	uint32_t *rows1[2], *chunk1[2], *start1[2]; uint64_t *recs1[2]; // double-buffered stage-A outputs
 	uint8_t *d_seq2[2], *d_qual2[2]; // staging for host batches (one per in-flight batch)
+	uint32_t *d_planes[2];       // the same for batches that arrive as bit planes (4 planes of plane_cap words each; allocated at the first such batch)
+	uint64_t plane_cap;
 	int cur, pend;               // buffer set of the next batch; 1 if the previous batch is not finalised yet
 	int used[2];
 	uint8_t *d_seq, *d_qual;     // = d_seq2[0], d_qual2[0]
@@ -400,7 +402,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	if (!c) return;
 	(void)hipSetDevice(c->prm.device);
 	(void)hipDeviceSynchronize();
-	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); if (b == 0 || c->recs1[1] != c->recs1[0]) (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); }
+	for (int b = 0; b < 2; ++b) { (void)hipFree(c->rows1[b]); (void)hipFree(c->chunk1[b]); (void)hipFree(c->start1[b]); if (b == 0 || c->recs1[1] != c->recs1[0]) (void)hipFree(c->recs1[b]); (void)hipFree(c->d_seq2[b]); (void)hipFree(c->d_qual2[b]); (void)hipFree(c->d_planes[b]); }
 	(void)hipFree(c->B.rows2); (void)hipFree(c->B.start2); (void)hipFree(c->B.recs2);
 	(void)hipFree(c->B.bloom); (void)hipFree(c->B.bloom_hi); (void)hipFree(c->B.table); (void)hipFree(c->B.stats); (void)hipFree(c->B.tab_first); (void)hipFree(c->B.sub_last);
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
@@ -1280,6 +1282,98 @@ extern "C" int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const 
 	HIPCK(hipEventRecord(c->evCopy, c->stA));
 	int rc = enqueue_batch(c, c->d_seq2[b], h_qual ? c->d_qual2[b] : NULL, n_pos, 1, 0);
 	HIPCK(hipEventSynchronize(c->evCopy)); // the caller may reuse its host buffers now
+	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c);
+	return rc;
+}
+
+
+// ---- batches that arrive as bit planes (include/bfc_gpu.h: bfcg_count_batch_planes) --------------------------------------------------
+// 4 bits per position cross PCIe instead of 16; on the device the planes are expanded into the byte streams the stage-A kernels read (one
+// streaming pass: 0.5 B read + 2 B written per position, ~0.4 ms per 10^9 positions at the copy rate) with bytes that reproduce exactly what
+// count.c:72-89 would see: 'A' 'C' 'G' 'T' by code, '\n' where the position is not a base, and for the quality 0x7f (a signed char of 127:
+// 127 - 33 >= q for every q <= 94) or 0x80 (-128: never >= q for q > -161).  For thresholds outside (-161, 94] no real byte can (q > 94) or
+// every byte does (q <= -161) pass, so the plane is constant and the two bytes give that constant too.
+__global__ __launch_bounds__(256) void k_expand_planes(const uint32_t *__restrict__ pl, uint64_t pw, uint32_t bit_off, uint64_t n_pos, int has_qual,
+                                                        uint8_t *__restrict__ seq, uint8_t *__restrict__ qual)
+{
+	const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+	if (i0 >= n_pos) return;
+	const uint64_t s = i0 + bit_off, k = s >> 5;
+	const uint32_t sh = (uint32_t)s & 31u;
+	auto take = [&](int p) -> uint32_t { // 16 bits of plane p from bit s on
+		const uint32_t *w = pl + (uint64_t)p * pw + k;
+		const unsigned long long v = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+		return (uint32_t)(v >> sh) & 0xffffu;
+	};
+	const uint32_t m0 = take(0), m1 = take(1), mn = take(2), mq = has_qual ? take(3) : 0u;
+	auto spread = [](uint32_t nib) -> uint32_t { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }; // bit j of the nibble -> bit 0 of byte j
+	uint32_t sw[4], qw[4];
+#pragma unroll
+	for (int d = 0; d < 4; ++d) {
+		const uint32_t c0 = spread(m0 >> (4 * d)), c1 = spread(m1 >> (4 * d)), nn = spread(mn >> (4 * d)) * 0xFFu, hq = spread(mq >> (4 * d));
+		const uint32_t base = 0x41414141u + c0 * 2u + c1 * 6u + (c0 & c1) * 0x0bu; // A 0x41, C 0x43, G 0x47, T 0x54 (no carries between bytes)
+		sw[d] = (base & ~nn) | (0x0a0a0a0au & nn);
+		qw[d] = 0x80808080u - hq;
+	}
+	if (i0 + 16 <= n_pos) {
+		*reinterpret_cast<uint4 *>(seq + i0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+		if (has_qual) *reinterpret_cast<uint4 *>(qual + i0) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+	} else {
+		for (uint64_t i = i0; i < n_pos; ++i) {
+			const int j = (int)(i - i0);
+			seq[i] = (uint8_t)(sw[j >> 2] >> (8 * (j & 3)));
+			if (has_qual) qual[i] = (uint8_t)(qw[j >> 2] >> (8 * (j & 3)));
+		}
+	}
+}
+
+// last cut point in (lo, hi] of a plane set: the position just behind a set bit of the not-ACGT plane, searched backwards over at most 2^20 positions; 0 = none
+static uint64_t find_cut_planes(const uint32_t *np, uint64_t lo, uint64_t hi)
+{
+	const uint64_t stop = hi - lo < (1u << 20) ? lo : hi - (1u << 20);
+	for (uint64_t i = hi; i > stop; --i) {
+		const uint64_t p = i - 1;
+		if ((p & 31) == 31 && p >= stop + 32 && np[p >> 5] == 0) { i -= 31; continue; } // (a word without a separator)
+		if ((np[p >> 5] >> (p & 31)) & 1u) return p + 1 > lo ? p + 1 : 0;
+	}
+	return 0;
+}
+
+extern "C" int bfcg_count_batch_planes(bfcg_ctx_t *c, const uint32_t *h_planes, uint64_t plane_words, uint64_t first_pos, uint64_t n_pos, int has_qual)
+{
+	if (c->n_ranks > 1) return set_err("this context is one of %d ranks: use bfcg_mg_scatter / bfcg_mg_process", c->n_ranks);
+	if (n_pos == 0) return 0;
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	if ((first_pos + n_pos + 31) / 32 > plane_words) return set_err("positions [%llu, %llu) lie outside planes of %llu words", (unsigned long long)first_pos, (unsigned long long)(first_pos + n_pos), (unsigned long long)plane_words);
+	HIPCK(hipSetDevice(c->prm.device));
+	if (!c->d_planes[0]) { // (first batch of this kind)
+		c->plane_cap = c->prm.max_batch_pos / 32 + 4;
+		for (int b = 0; b < 2; ++b) HIPCK(hipMalloc(&c->d_planes[b], c->plane_cap * 4 * sizeof(uint32_t)));
+	}
+	uint64_t from, lim;
+	split_rule(c, &from, &lim);
+	struct depth_guard { bfcg_ctx_t *c; depth_guard(bfcg_ctx_t *c_) : c(c_) { if (c->call_depth++ == 0) ++c->call_no; } ~depth_guard() { --c->call_depth; } } guard(c);
+	if (!c->B.seen_out && n_pos > from) { // oversized for this filter: equal sub-batches of at most `lim` positions (see bfcg_count_batch_dev)
+		const uint64_t target = n_pos / ((n_pos + lim - 1) / lim) + 1;
+		uint64_t o = 0;
+		while (n_pos - o > target + target / 8) {
+			const uint64_t cut = find_cut_planes(h_planes + 2 * plane_words, first_pos + o, first_pos + o + target);
+			if (cut == 0) break;
+			if (bfcg_count_batch_planes(c, h_planes, plane_words, first_pos + o, cut - (first_pos + o), has_qual) != 0) return -1;
+			o = cut - first_pos;
+		}
+		if (o) return o < n_pos ? bfcg_count_batch_planes(c, h_planes, plane_words, first_pos + o, n_pos - o, has_qual) : 0;
+	}
+	const int b = c->cur;
+	const uint64_t w0 = first_pos >> 5, nw = ((first_pos + n_pos + 31) >> 5) - w0 + 1; // (+ the word the expansion reads ahead: a spare one at the planes' end)
+	const uint64_t nw_c = w0 + nw <= plane_words ? nw : plane_words - w0;
+	for (int p = 0; p < (has_qual ? 4 : 3); ++p) // ordered behind stage A of two batches ago (same stream), as the byte streams of bfcg_count_batch_host are
+		HIPCK(hipMemcpyAsync(c->d_planes[b] + (uint64_t)p * c->plane_cap, h_planes + (uint64_t)p * plane_words + w0, nw_c * sizeof(uint32_t), hipMemcpyHostToDevice, c->stA));
+	hipLaunchKernelGGL(k_expand_planes, dim3((unsigned)((n_pos + 4095) / 4096)), dim3(256), 0, c->stA, c->d_planes[b], c->plane_cap, (uint32_t)(first_pos & 31), n_pos, has_qual,
+	                   c->d_seq2[b], c->d_qual2[b]);
+	HIPCK(hipEventRecord(c->evCopy, c->stA)); // (behind the expansion: where the batches' kernels run on the other stream they wait for this)
+	int rc = enqueue_batch(c, c->d_seq2[b], has_qual ? c->d_qual2[b] : NULL, n_pos, 1, 0);
+	HIPCK(hipEventSynchronize(c->evCopy)); // the caller may reuse its planes now
 	if (rc == 0 && (c->B.seen_out || getenv("BFCG_SYNC_BATCHES"))) rc = drain(c);
 	return rc;
 }

@@ -118,6 +118,19 @@ int bfcg_reset(bfcg_ctx_t *c);
  * asynchronously.  Both return 0 or a negative error. */
 int bfcg_count_batch_dev(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos);
 int bfcg_count_batch_host(bfcg_ctx_t *c, const uint8_t *h_seq, const uint8_t *h_qual, uint64_t n_pos);
+/* The same batch as FOUR BIT PLANES (bit i of a plane = stream position i, 32 positions per word): all that count.c:72-89 reads of a position
+ * is its base code (seq_nt6_table minus one: A C G T = 0 1 2 3, bseq.c:9-26, count.c:82), whether it is a base at all (count.c:83,88) and
+ * whether `qual - 33 >= q` (count.c:85, a signed char) -- 4 bits instead of the 16 that cross PCIe with bfcg_count_batch_host, whose rate is
+ * the link's (17 G k-mers/s at 45 GB/s).  Plane p starts at planes + p * plane_words: [0] low code bit, [1] high code bit, [2] not ACGTacgt
+ * (separators included; positions beyond the batch's end in the last word too), [3] quality - 33 >= q.
+ *   bfcg_plane_words(n)     words per plane for n positions
+ *   bfcg_pack_planes        positions [lo, hi) of a byte-stream batch into its planes; lo a multiple of 32 (threads pack disjoint word ranges),
+ *                           hi a multiple of 32 or the batch's end n_pos; qual NULL: no quality plane is written
+ *   bfcg_count_batch_planes counts positions [first_pos, first_pos + n_pos) of the plane set; has_qual = 0: the records carry no qualities
+ *                           (every base is high quality, count.c:85) and plane [3] is not read.  Same results as the byte streams, bit for bit. */
+uint64_t bfcg_plane_words(uint64_t n_pos);
+void bfcg_pack_planes(const uint8_t *seq, const uint8_t *qual, uint64_t lo, uint64_t hi, uint64_t n_pos, int q, uint32_t *planes, uint64_t plane_words);
+int bfcg_count_batch_planes(bfcg_ctx_t *c, const uint32_t *h_planes, uint64_t plane_words, uint64_t first_pos, uint64_t n_pos, int has_qual);
 int bfcg_sync(bfcg_ctx_t *c);
 
 /* Multi-GPU (one process per GPU; SURVEY 8e partitioning B, "owner computes"): rank r owns 1/n_ranks of the bloom

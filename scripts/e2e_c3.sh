@@ -10,5 +10,5 @@ rs.fastq('/dev/shm/c3e.fq', 0, min($READS, rs.n_reads)); print('reads', min($REA
 PY
 ls -l /dev/shm/c3e.fq
 export BFC_GPU_TIMING=1
-for i in 1 2 3; do ( time oracle/_ref/bfc-dropin -E -s 250m -k 33 -t64 /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -16; echo; done
+for pl in ${PLANES:-1 0 1 0}; do echo "== BFC_GPU_PLANES=$pl"; ( time BFC_GPU_PLANES=$pl oracle/_ref/bfc-dropin -E -s 250m -k 33 -t64 /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -16; echo; done
 rm -f /dev/shm/c3e.fq

@@ -263,11 +263,14 @@ def test_dropin_gpu_trim_binary(g1_fq, tmp_path):
 
 
 @needs_dropin
-def test_dropin_exact_dump_md5(g1_fq, tmp_path):
-    """`bfc -E -d` through the unmodified main(): with BFC_GPU_EXACT_DUMP=1 the dump file is byte-identical to the reference's."""
+@pytest.mark.parametrize("planes", ["1", "0"])
+@pytest.mark.parametrize("threads", ["1", "8"])
+def test_dropin_exact_dump_md5(g1_fq, tmp_path, planes, threads):
+    """`bfc -E -d` through the unmodified main(): with BFC_GPU_EXACT_DUMP=1 the dump file is byte-identical to the reference's -- with the batches
+    handed to the GPU as bit planes (the default on one GPU: bfcg_count_batch_planes) and as byte streams (BFC_GPU_PLANES=0)."""
     dump = str(tmp_path / "g1.hash")
-    r = subprocess.run([DROPIN, "-E", "-k", "31", "-b", "26", "-L", "300000", "-d", dump, g1_fq], capture_output=True, timeout=600,
-                       env=dict(os.environ, BFC_GPU_EXACT_DUMP="1"))
+    r = subprocess.run([DROPIN, "-E", "-k", "31", "-b", "26", "-L", "300000", "-t", threads, "-d", dump, g1_fq], capture_output=True, timeout=600,
+                       env=dict(os.environ, BFC_GPU_EXACT_DUMP="1", BFC_GPU_PLANES=planes))
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert oracle.md5_file(dump) == "d686549d10dd4c71243269013119784a"
 
@@ -498,7 +501,11 @@ def test_mixed_fasta_fastq_at_q94(tmp_path, devices):
     env = dict(os.environ, BFC_GPU_EXACT_DUMP="1")
     if devices:
         env["BFC_GPU_DEVICES"] = devices
-    for chunk in ("100000000", "60000"):
+    for chunk in ("100000000", "60000", "60000:bytes"):
+        if chunk.endswith(":bytes"):  # (one GPU hands its batches over as bit planes by default; once more as byte streams)
+            if devices:
+                continue
+            chunk = chunk.split(":")[0]; env["BFC_GPU_PLANES"] = "0"
         ref_dump, gpu_dump = str(tmp_path / "ref.hash"), str(tmp_path / "gpu.hash")
         r = subprocess.run([REFBIN, "-E", "-k", "21", "-b", "26", "-q", "94", "-t", "1", "-L", chunk, "-d", ref_dump, fn], capture_output=True, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-800:]

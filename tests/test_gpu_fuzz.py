@@ -56,13 +56,19 @@ def _draw(seed, scale=1, b_range=(10, 28)):
     return dict(k=k, b=b, nh=nh, l_pre=l_pre, q=q, fm=fm), seq, qual, off, cuts, kw
 
 
-def _check(gpu_lib, prm, seq, qual, off, cuts, kw):
+def _check(gpu_lib, prm, seq, qual, off, cuts, kw, planes=False):
     n = len(off) - 1
     oc = oracle.Counter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"])
     oc.count(seq, qual, off)
     cap = len(seq) + n + 64
     g = gpu_lib.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"], max_batch_pos=cap, **kw)
+    if planes:  # the whole input as ONE set of bit planes (bfcg_pack_planes, three packing threads' ranges), its pieces counted at their bit offsets
+        pl = gpu_lib.pack_planes(gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off) if qual is not None else None, prm["q"], n_threads=3)
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            g.count_planes(pl, int(off[a]) + a, int(off[e]) + e - int(off[a]) - a, has_qual=qual is not None)
     for a, e in zip(cuts[:-1], cuts[1:]):
+        if planes:
+            break
         o = off[a:e + 1] - off[a]
         s = gpu_lib.to_stream(seq[int(off[a]):int(off[e])], o)
         qq = gpu_lib.to_stream(qual[int(off[a]):int(off[e])], o) if qual is not None else None
@@ -83,6 +89,21 @@ def _check(gpu_lib, prm, seq, qual, off, cuts, kw):
 @pytest.mark.parametrize("seed", range(120))
 def test_random_configuration(gpu_lib, seed):
     _check(gpu_lib, *_draw(1000 + seed))
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_configuration_through_bit_planes(gpu_lib, seed):
+    """the same draws handed over as bit planes (bfcg_count_batch_planes: 4 bits per position over PCIe): any byte value in sequence and quality,
+    thresholds from -50 to 100 (beyond what a signed char can reach on either side), records without qualities, pieces that begin at any bit"""
+    _check(gpu_lib, *_draw(1000 + seed), planes=True)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bit_planes_oversized_batches_are_cut(gpu_lib, seed):
+    """a plane set far larger than its filter takes at full speed is cut at separators found in the not-ACGT plane"""
+    prm, seq, qual, off, cuts, kw = _draw(52000 + seed, scale=6, b_range=(14, 18))
+    kw.pop("region_shift", None)
+    _check(gpu_lib, prm, seq, qual, off, [0, len(off) - 1], kw, planes=True)
 
 
 @pytest.mark.parametrize("seed", range(16))
