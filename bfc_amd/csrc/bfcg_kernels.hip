@@ -1782,13 +1782,29 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 				if (j < end) {
 					const uint64_t id = v0 >> 1;
 					const uint32_t hi = (uint32_t)(v0 & 1);
-					unsigned long long cur = lseg[p];
+					const unsigned long long fresh = (id << 14) | 1ULL | ((unsigned long long)hi << 8); // (the creating call is the slot's count 1)
 					bool done = false;
+					// An even slot is read together with its neighbour (one 16-byte LDS read): the probe sequence is the same, a step that would only
+					// have found another key in slot p goes on to p + 1 at once (scripts/probes/commit_probe.hip on c3's shape: 12.5 -> 11.6 ms per pass).
+					// A zero that went stale meanwhile is examined again by the compare-and-swap; a slot that holds a key keeps it.
+					unsigned long long cur, nxt = 0;
+					const bool pair = !(p & 1u);
+					if (pair) { const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(&lseg[p]); cur = pr.x; nxt = pr.y; }
+					else cur = lseg[p];
 					if (cur == 0) {
-						cur = atomicCAS(&lseg[p], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); // (the creating call is the slot's count 1)
+						cur = atomicCAS(&lseg[p], 0ULL, fresh);
 						if (cur == 0) { ++n_new; done = true; }
 					}
 					if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+					if (!done && pair) { // (p + 1 <= mask: p is even)
+						++probes;
+						if (nxt == 0) {
+							nxt = atomicCAS(&lseg[p + 1], 0ULL, fresh);
+							if (nxt == 0) { ++n_new; done = true; }
+						}
+						if (!done && (nxt >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p + 1], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+						if (!done) p += 1;
+					}
 					if (!done) {
 						p = (p + 1) & mask;
 						if (++probes > mask) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); done = true; } // (the segment is full)

@@ -233,6 +233,167 @@ __global__ __launch_bounds__(BT) void k_v2(Args A)
 	}
 }
 
+// ---- c3's shape: segments of 2^11 slots, a 32-bit counter pair per slot behind the segment in LDS (k_commit_seg's use_cnt path), 256 threads ----
+// VAR 0: the shipped loop (one entry per lane at a time, entries and probes in one loop); VAR 1: two independent entry streams per lane (two LDS
+// reads in flight); VAR 2: slots read in aligned PAIRS (one 16-byte LDS read covers the home slot and its neighbour when the home is even)
+template <int BT, int VAR>
+__global__ __launch_bounds__(BT) void k_c3(Args A)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
+	__shared__ uint32_t s_new[8], s_mark[8];
+	const uint32_t f = blockIdx.x, pages = A.pages;
+	const uint32_t n = A.mark[(size_t)(pages - 1) * A.mark_stride + f];
+	const unsigned long long *recs = A.log + (uint64_t)f * A.log_stride;
+	const uint32_t slots = 1u << A.seg_shift, mask = slots - 1;
+	unsigned long long *gseg = A.seg + ((uint64_t)f << A.seg_shift);
+	unsigned int *lcnt = reinterpret_cast<unsigned int *>(lseg + slots);
+	if (threadIdx.x < 8) { s_new[threadIdx.x] = 0; s_mark[threadIdx.x] = threadIdx.x < pages ? A.mark[(size_t)threadIdx.x * A.mark_stride + f] : n; }
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(gseg);
+		uint4 *dst = reinterpret_cast<uint4 *>(lseg);
+		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
+		for (uint32_t i = threadIdx.x; i < slots; i += BT) lcnt[i] = 0;
+	}
+	__syncthreads();
+	// VAR 4: a page goes through LDS in tiles of TE entries (staged by all threads, home slots computed there: every lane busy), and the lanes of a
+	// wave DRAW entries from the wave's share of the tile as they finish (ballot + prefix count: no atomics) instead of owning every BT-th entry:
+	// a wave runs (its probes / 64) steps, not its busiest lane's; the probe loop carries no loads, no hash, no entry rotation
+	constexpr int TE = 1024;
+	__shared__ unsigned long long t_v[VAR == 4 ? TE : 1];
+	__shared__ unsigned short t_h[VAR == 4 ? TE : 1];
+	if (VAR == 4) {
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		constexpr int NW = BT / 64;
+		uint32_t beg = 0;
+		for (uint32_t pg = 0; pg < pages; ++pg) {
+			const uint32_t end = s_mark[pg];
+			uint32_t n_new = 0;
+			for (uint32_t t0 = beg; t0 < end; t0 += TE) {
+				const uint32_t nt = end - t0 < TE ? end - t0 : TE;
+				for (uint32_t i = threadIdx.x; i < nt; i += BT) { const unsigned long long v = recs[t0 + i]; t_v[i] = v; t_h[i] = (unsigned short)(seg_home(v >> 1) & mask); }
+				__syncthreads();
+				const uint32_t per = (nt + NW - 1) / NW, lo = per * wave < nt ? per * wave : nt, hi = lo + per < nt ? lo + per : nt;
+				uint32_t cursor = lo + 64; // (wave-uniform) the next entry nobody has drawn
+				uint32_t idx = lo + lane;
+				bool have = idx < hi;
+				unsigned long long v = have ? t_v[idx] : 0ULL;
+				uint32_t p = have ? t_h[idx] : 0u, probes = 0;
+				while (__any(have)) {
+					bool done = false;
+					if (have) {
+						const uint64_t id = v >> 1;
+						const uint32_t hq = (uint32_t)(v & 1);
+						unsigned long long cur = lseg[p];
+						if (cur == 0) { cur = atomicCAS(&lseg[p], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hq << 8)); if (cur == 0) { ++n_new; done = true; } }
+						if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hq << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+						if (!done) { p = (p + 1) & mask; if (++probes > mask) done = true; }
+					}
+					const unsigned long long b = __ballot(done);
+					if (b) {
+						const uint32_t mine = cursor + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+						cursor += (uint32_t)__popcll(b);
+						if (done) { have = mine < hi; if (have) { v = t_v[mine]; p = t_h[mine]; probes = 0; } }
+					}
+				}
+				__syncthreads(); // (the tile's buffer is free again; at a page's last tile: the page is applied)
+			}
+			for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+			if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new[pg], n_new);
+			beg = end;
+		}
+		__syncthreads();
+	}
+	__shared__ unsigned long long s_ent[BT * 3];
+	if (VAR == 3) { for (uint32_t i = threadIdx.x; i < BT * 3; i += BT) s_ent[i] = i < n ? recs[i] : 0ULL; __syncthreads(); }
+	if (VAR == 0 || VAR == 2 || VAR == 3) {
+		uint32_t j = threadIdx.x;
+		unsigned long long v0 = j < n ? recs[j] : 0ULL, v1 = j + BT < n ? recs[j + BT] : 0ULL, v2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL;
+		uint32_t p = seg_home(v0 >> 1) & mask, probes = 0;
+		for (uint32_t pg = 0; pg < pages; ++pg) {
+			const uint32_t end = s_mark[pg];
+			uint32_t n_new = 0;
+			while (__any(j < end)) {
+				if (j < end) {
+					const uint64_t id = v0 >> 1;
+					const uint32_t hi = (uint32_t)(v0 & 1);
+					bool done = false;
+					if (VAR == 2 && !(p & 1u)) { // the aligned pair (p, p + 1) in one read
+						const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(&lseg[p]);
+						unsigned long long cur = pr.x;
+						if (cur == 0) { cur = atomicCAS(&lseg[p], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); if (cur == 0) { ++n_new; done = true; } }
+						if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+						if (!done) {
+							cur = pr.y; // (a stale zero is re-examined by the CAS; a non-zero slot never changes its key)
+							if (cur == 0) { cur = atomicCAS(&lseg[p + 1], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); if (cur == 0) { ++n_new; done = true; } }
+							if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p + 1], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+							if (!done) { p = (p + 2) & mask; probes += 2; }
+						}
+					} else {
+						unsigned long long cur = lseg[p];
+						if (cur == 0) { cur = atomicCAS(&lseg[p], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); if (cur == 0) { ++n_new; done = true; } }
+						if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+						if (!done) { p = (p + 1) & mask; ++probes; }
+					}
+					if (!done && probes > mask) done = true;
+					if (done) { j += BT; v0 = v1; v1 = v2; v2 = VAR == 3 ? s_ent[(j + 2 * BT) % (BT * 3)] : j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL; p = seg_home(v0 >> 1) & mask; probes = 0; }
+				}
+			}
+			for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+			if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new[pg], n_new);
+			__syncthreads();
+		}
+	} else if (VAR == 1) { // two streams per lane: entries j, j + 2 BT, ... and j + BT, j + 3 BT, ...
+		uint32_t ja = threadIdx.x, jb = threadIdx.x + BT;
+		unsigned long long a0 = ja < n ? recs[ja] : 0ULL, a1 = ja + 2 * BT < n ? recs[ja + 2 * BT] : 0ULL;
+		unsigned long long b0 = jb < n ? recs[jb] : 0ULL, b1 = jb + 2 * BT < n ? recs[jb + 2 * BT] : 0ULL;
+		uint32_t pa = seg_home(a0 >> 1) & mask, pb = seg_home(b0 >> 1) & mask, qa = 0, qb = 0;
+		for (uint32_t pg = 0; pg < pages; ++pg) {
+			const uint32_t end = s_mark[pg];
+			uint32_t n_new = 0;
+			while (__any(ja < end || jb < end)) {
+				const bool ona = ja < end, onb = jb < end;
+				unsigned long long ca = 0, cb = 0;
+				if (ona) ca = lseg[pa];
+				if (onb) cb = lseg[pb];
+				if (ona) {
+					const uint64_t id = a0 >> 1; const uint32_t hi = (uint32_t)(a0 & 1);
+					bool done = false;
+					if (ca == 0) { ca = atomicCAS(&lseg[pa], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); if (ca == 0) { ++n_new; done = true; } }
+					if (!done && (ca >> 14) == id) { __hip_atomic_fetch_add(&lcnt[pa], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+					if (!done) { pa = (pa + 1) & mask; if (++qa > mask) done = true; }
+					if (done) { ja += 2 * BT; a0 = a1; a1 = ja + 2 * BT < n ? recs[ja + 2 * BT] : 0ULL; pa = seg_home(a0 >> 1) & mask; qa = 0; }
+				}
+				if (onb) {
+					const uint64_t id = b0 >> 1; const uint32_t hi = (uint32_t)(b0 & 1);
+					bool done = false;
+					if (cb == 0) { cb = atomicCAS(&lseg[pb], 0ULL, (id << 14) | 1ULL | ((unsigned long long)hi << 8)); if (cb == 0) { ++n_new; done = true; } }
+					if (!done && (cb >> 14) == id) { __hip_atomic_fetch_add(&lcnt[pb], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+					if (!done) { pb = (pb + 1) & mask; if (++qb > mask) done = true; }
+					if (done) { jb += 2 * BT; b0 = b1; b1 = jb + 2 * BT < n ? recs[jb + 2 * BT] : 0ULL; pb = seg_home(b0 >> 1) & mask; qb = 0; }
+				}
+			}
+			for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+			if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new[pg], n_new);
+			__syncthreads();
+		}
+	}
+	for (uint32_t i = threadIdx.x; i < slots; i += BT) {
+		const uint32_t c = lcnt[i];
+		if (c) {
+			const unsigned long long v = lseg[i];
+			const uint32_t nc = (uint32_t)(v & 0xff) + (c & 0xffffu), nh = (uint32_t)((v >> 8) & 0x3f) + (c >> 16);
+			lseg[i] = (v & ~0x3fffULL) | (nc < 255 ? nc : 255) | ((unsigned long long)(nh < 63 ? nh : 63) << 8);
+		}
+	}
+	__syncthreads();
+	{
+		uint4 *dst = reinterpret_cast<uint4 *>(gseg);
+		const uint4 *src = reinterpret_cast<const uint4 *>(lseg);
+		for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = src[i];
+	}
+	if (threadIdx.x < pages && s_new[threadIdx.x]) atomicAdd(&A.stats[(size_t)(f & 255) * 8 + threadIdx.x], (unsigned long long)s_new[threadIdx.x]);
+}
+
 __global__ void k_digest(const unsigned long long *seg, uint64_t n, unsigned long long *out)
 {
 	unsigned long long s = 0, c = 0;
@@ -282,6 +443,28 @@ int main(int argc, char **argv)
 		printf("%-34s %8.3f ms  segments %.2f TB/s  %.1f ps per upsert  (x 2^%d regions: %.1f ms)  keys %llu digest %016llx\n", name, ms, gb / ms, ms * 1e9 / ups, 20 - lf, ms * (1 << (20 - lf)), h[1], h[0]);
 	};
 #define RUN(name, launch) do { rebuild(); CK(hipEventRecord(e0, 0)); launch; CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); float ms_; CK(hipEventElapsedTime(&ms_, e0, e1)); report(name, ms_); } while (0)
+	if (S <= 12) { // config c3's shape: the counter-pair path
+		const size_t l3 = (size_t)slots * 12;
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		for (int rep = 0; rep < 2; ++rep) {
+			RUN("c3 shipped loop, 256 thr", hipLaunchKernelGGL((k_c3<256, 0>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 two streams per lane, 256 thr", hipLaunchKernelGGL((k_c3<256, 1>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 slots read in pairs, 256 thr", hipLaunchKernelGGL((k_c3<256, 2>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 entries drawn from LDS tiles, 256", hipLaunchKernelGGL((k_c3<256, 4>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 entries drawn from LDS tiles, 512", hipLaunchKernelGGL((k_c3<512, 4>), dim3(NF), dim3(512), l3, 0, A));
+			RUN("c3 TIMING ONLY: no loads in the loop", hipLaunchKernelGGL((k_c3<256, 3>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 shipped loop, 512 thr", hipLaunchKernelGGL((k_c3<512, 0>), dim3(NF), dim3(512), l3, 0, A));
+			RUN("c3 two streams per lane, 512 thr", hipLaunchKernelGGL((k_c3<512, 1>), dim3(NF), dim3(512), l3, 0, A));
+		}
+		return 0;
+	}
 	for (int rep = 0; rep < 2; ++rep) {
 		RUN("V0 shipped structure, 1024 thr", hipLaunchKernelGGL((k_v0<1024, 0>), dim3(NF), dim3(1024), lds, 0, A));
 		RUN("V0p six entries ahead, 1024 thr", hipLaunchKernelGGL((k_v0<1024, 3>), dim3(NF), dim3(1024), lds, 0, A));
