@@ -1772,8 +1772,8 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 		// Entries and probes in ONE loop (round 4): a lane whose entry is done takes its next one while its neighbours still probe, so a wave runs
 		// as many probe steps as its busiest LANE needs for all its entries, not the sum over entries of the longest probe among 64 lanes (at 60 %
 		// load a key sits 2 slots from home on average, but the longest of 64 probes is 8 - 10: the counter passes showed 130 lane-instructions
-		// per upsert).  The entries two and three ahead are already requested (v1, v2): a lane never waits for memory inside the loop.
-		unsigned long long v0 = pre0, v1 = pre1, v2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL;
+		// per upsert).  The next entry is already requested (v1).
+		unsigned long long v0 = pre0, v1 = pre1;
 		uint32_t p = seg_home(v0 >> 1) & mask, probes = 0;
 		for (uint32_t pg = 0; pg < pages; ++pg) {
 			const uint32_t end = s_mark[pg];
@@ -1810,8 +1810,8 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 						if (++probes > mask) { uint64_t y0, y1; seg_unpack(G, (uint64_t)P.f_base + f, id, y0, y1); seg_park(A, y0, y1, 1u, hi); done = true; } // (the segment is full)
 					}
 					if (done) { // this lane's next entry
-						j += BT; v0 = v1; v1 = v2;
-						v2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL;
+						j += BT; v0 = v1;
+						v1 = j + BT < n ? recs[j + BT] : 0ULL; // (one entry ahead: two ahead cost more register copies per step than the load's latency, which the CU's other waves cover: 11.7 -> 10.9 ms per pass in the probe)
 						p = seg_home(v0 >> 1) & mask; probes = 0;
 					}
 				}

@@ -305,6 +305,43 @@ __global__ __launch_bounds__(BT) void k_c3(Args A)
 	}
 	__shared__ unsigned long long s_ent[BT * 3];
 	if (VAR == 3) { for (uint32_t i = threadIdx.x; i < BT * 3; i += BT) s_ent[i] = i < n ? recs[i] : 0ULL; __syncthreads(); }
+	if (VAR == 5 || VAR == 6) { // pair reads; the next entry is loaded where the lane advances (5) or one entry ahead (6): no three-deep rotation
+		uint32_t j = threadIdx.x;
+		unsigned long long v0 = j < n ? recs[j] : 0ULL, v1 = VAR == 6 && j + BT < n ? recs[j + BT] : 0ULL;
+		uint32_t p = seg_home(v0 >> 1) & mask, probes = 0;
+		for (uint32_t pg = 0; pg < pages; ++pg) {
+			const uint32_t end = s_mark[pg];
+			uint32_t n_new = 0;
+			while (__any(j < end)) {
+				if (j < end) {
+					const uint64_t id = v0 >> 1;
+					const uint32_t hi = (uint32_t)(v0 & 1);
+					const unsigned long long fresh = (id << 14) | 1ULL | ((unsigned long long)hi << 8);
+					bool done = false;
+					unsigned long long cur, nxt = 0;
+					const bool pair = !(p & 1u);
+					if (pair) { const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(&lseg[p]); cur = pr.x; nxt = pr.y; } else cur = lseg[p];
+					if (cur == 0) { cur = atomicCAS(&lseg[p], 0ULL, fresh); if (cur == 0) { ++n_new; done = true; } }
+					if (!done && (cur >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+					if (!done && pair) {
+						++probes;
+						if (nxt == 0) { nxt = atomicCAS(&lseg[p + 1], 0ULL, fresh); if (nxt == 0) { ++n_new; done = true; } }
+						if (!done && (nxt >> 14) == id) { __hip_atomic_fetch_add(&lcnt[p + 1], 1u | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); done = true; }
+						if (!done) p += 1;
+					}
+					if (!done) { p = (p + 1) & mask; if (++probes > mask) done = true; }
+					if (done) {
+						j += BT;
+						if (VAR == 6) { v0 = v1; v1 = j + BT < n ? recs[j + BT] : 0ULL; } else v0 = j < n ? recs[j] : 0ULL;
+						p = seg_home(v0 >> 1) & mask; probes = 0;
+					}
+				}
+			}
+			for (int o = 32; o; o >>= 1) n_new += __shfl_down(n_new, o);
+			if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&s_new[pg], n_new);
+			__syncthreads();
+		}
+	}
 	if (VAR == 0 || VAR == 2 || VAR == 3) {
 		uint32_t j = threadIdx.x;
 		unsigned long long v0 = j < n ? recs[j] : 0ULL, v1 = j + BT < n ? recs[j + BT] : 0ULL, v2 = j + 2 * BT < n ? recs[j + 2 * BT] : 0ULL;
@@ -450,6 +487,8 @@ int main(int argc, char **argv)
 		CK(hipFuncSetAttribute((const void *)k_c3<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
 		CK(hipFuncSetAttribute((const void *)k_c3<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
 		CK(hipFuncSetAttribute((const void *)k_c3<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+		CK(hipFuncSetAttribute((const void *)k_c3<256, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
 		CK(hipFuncSetAttribute((const void *)k_c3<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
 		CK(hipFuncSetAttribute((const void *)k_c3<512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
 		CK(hipFuncSetAttribute((const void *)k_c3<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
@@ -457,6 +496,8 @@ int main(int argc, char **argv)
 			RUN("c3 shipped loop, 256 thr", hipLaunchKernelGGL((k_c3<256, 0>), dim3(NF), dim3(256), l3, 0, A));
 			RUN("c3 two streams per lane, 256 thr", hipLaunchKernelGGL((k_c3<256, 1>), dim3(NF), dim3(256), l3, 0, A));
 			RUN("c3 slots read in pairs, 256 thr", hipLaunchKernelGGL((k_c3<256, 2>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 pairs, entry loaded at the advance", hipLaunchKernelGGL((k_c3<256, 5>), dim3(NF), dim3(256), l3, 0, A));
+			RUN("c3 pairs, one entry ahead", hipLaunchKernelGGL((k_c3<256, 6>), dim3(NF), dim3(256), l3, 0, A));
 			RUN("c3 entries drawn from LDS tiles, 256", hipLaunchKernelGGL((k_c3<256, 4>), dim3(NF), dim3(256), l3, 0, A));
 			RUN("c3 entries drawn from LDS tiles, 512", hipLaunchKernelGGL((k_c3<512, 4>), dim3(NF), dim3(512), l3, 0, A));
 			RUN("c3 TIMING ONLY: no loads in the loop", hipLaunchKernelGGL((k_c3<256, 3>), dim3(NF), dim3(256), l3, 0, A));

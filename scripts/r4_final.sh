@@ -2,7 +2,7 @@
 # rocprofv3 traces + PMC passes of c3 and c2 (summaries -> gpurun_out/, copied to profiles/ by hand).  PARTS="tests bench dist c4 c5 prof" selects.
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
 export TMPDIR=/tmp
-PARTS=${PARTS:-"tests bench dist c4 c5 prof"}
+PARTS=${PARTS:-"tests bench dist c4 c5 prof e2e"}
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 if has tests; then
   timeout 1800 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r4_gpu_tests.log; tail -8 gpurun_out/r4_gpu_tests.log
@@ -33,3 +33,4 @@ if has prof; then
   ROUND=4 python tools/make_round_md.py gpurun_out/prof_c2 c2 > gpurun_out/round4_c2.md; cp profiles/round4_c2_pmc.json gpurun_out/
   PROF_TIMEOUT=400 bash scripts/prof_sq.sh r4final > gpurun_out/r4_prof_sq.log 2>&1
 fi
+if has e2e; then READS=49600000 PLANES="1 0 1" bash scripts/e2e_c3.sh > gpurun_out/r4_e2e_c3_full.txt 2>&1; grep -E "==|Real time|^real|written" gpurun_out/r4_e2e_c3_full.txt | cut -c1-200; fi
