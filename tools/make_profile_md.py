@@ -21,8 +21,10 @@ def pmc_rows(path):
     q = ("select s.kernel_name, p.name, count(distinct d.id), sum(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
          "join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1, 2")
     out = {}
-    for k, c, n, v in db.execute(q):
-        out.setdefault(short(k), {})[c] = (n, v)
+    for k, c, n, v in db.execute(q):  # (instantiations of one kernel template share a row: launches and counters add up)
+        e = out.setdefault(short(k), {})
+        n0, v0 = e.get(c, (0, 0))
+        e[c] = (n0 + n, v0 + v)
     return out
 
 
