@@ -98,6 +98,7 @@ SYMBOLS = {
     "bfcg_stream_batches": (C.c_uint64, [C.c_void_p]),
     "bfc_ch_union": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
     "bfc_ingest_digest": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, u64p]),
+    "bfc_ingest_planes_digest": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p]),
     "bfc_pgz_digest": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, u64p]),
     "bfcg_kcov_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_uint64]),
     "bfcg_kcov_attach": (C.c_void_p, [C.c_void_p, C.c_uint64]),

@@ -234,10 +234,12 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 		pp.b[i].cap = cap;
 		/* pinning costs ~0.35 ms per MB: it pays from a few GB of input on; below, plain memory and staged copies.  With planes only THEY are
 		 * copied to the device: a quarter of a stream's bytes each */
-		if (pin && !use_planes) { pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap); }
+		if (use_planes) { /* the FASTQ fast path writes the planes straight from the mapped file; byte streams exist only if the serial parser is ever needed (bfc_ingest.h: batch_need_streams) */
+			pp.planes[i] = (uint32_t*)(pin ? bfcg_host_alloc(pp.plane_words * 16) : malloc(pp.plane_words * 16));
+			pp.b[i].planes = pp.planes[i]; pp.b[i].plane_words = pp.plane_words; pp.b[i].q = opt->q;
+		} else if (pin) { pp.b[i].seq = (uint8_t*)bfcg_host_alloc(cap); pp.b[i].qual = (uint8_t*)bfcg_host_alloc(cap); }
 		else { pp.b[i].seq = (uint8_t*)big_alloc(cap); pp.b[i].qual = (uint8_t*)big_alloc(cap); }
-		if (use_planes) pp.planes[i] = (uint32_t*)(pin ? bfcg_host_alloc(pp.plane_words * 16) : malloc(pp.plane_words * 16));
-		if (!pp.b[i].seq || !pp.b[i].qual || (use_planes && !pp.planes[i])) { fprintf(stderr, "[E::%s] cannot pin %llu bytes of host memory\n", __func__, (unsigned long long)cap); abort(); }
+		if ((!use_planes && (!pp.b[i].seq || !pp.b[i].qual)) || (use_planes && !pp.planes[i])) { fprintf(stderr, "[E::%s] cannot pin %llu bytes of host memory\n", __func__, (unsigned long long)cap); abort(); }
 	}
 	if (timing) fprintf(stderr, "[T::bfc_count] input opened (%s), pinned buffers: %.3f s\n", ps.fast.active ? "mapped, multi-threaded fast path" : "serial parser", now_real() - tt);
 	if (!opt->no_mt_io) pthread_create(&tid, 0, reader_main, &pp);
@@ -256,7 +258,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 			pthread_mutex_unlock(&pp.mtx);
 		}
 		t_wait += now_real() - tt; tt = now_real();
-		if (use_planes) { pack_batch(&pp, cur); t_pack += now_real() - tt; tt = now_real(); }
+		if (use_planes && !b->packed) { pack_batch(&pp, cur); t_pack += now_real() - tt; tt = now_real(); } /* (a batch of the serial parser: byte streams) */
 		fprintf(stderr, "[M::%s] read %d sequences\n", "bfc_count_cb", b->n_seqs); /* count.c:99, once per bseq_read call */
 		if (b->n_seqs) {
 			int rc = 0;
@@ -310,7 +312,7 @@ void *bfc_count(const char *fn, const bfc_opt_t *opt)
 	 * same locks; the process' wall time did not move: profiles/round4_e2e.md) */
 	tt = now_real();
 	for (i = 0; i < 2; ++i) {
-		if (pin && !use_planes) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); } else { free(pp.b[i].seq); free(pp.b[i].qual); }
+		if (pin && !use_planes) { bfcg_host_free(pp.b[i].seq); bfcg_host_free(pp.b[i].qual); } else { free(pp.b[i].seq); free(pp.b[i].qual); } /* (NULL where no batch ever needed them) */
 		if (pp.planes[i]) { if (pin) bfcg_host_free(pp.planes[i]); else free(pp.planes[i]); }
 		free(pp.b[i].kind_cut);
 	}
@@ -348,6 +350,43 @@ int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_t
 	}
 	out[3] = hs; out[4] = hq; out[5] = hb; out[6] = (uint64_t)in.fast_batches;
 	free(b.seq); free(b.qual); free(b.kind_cut);
+	ingest_close(&in);
+	return 0;
+}
+
+/* The batches' BIT PLANES (no GPU): `direct` = 1 lets the FASTQ fast path write them straight from the mapped file (batch_t.planes), 0 fills byte
+ * streams and packs them with bfcg_pack_planes -- the two must agree word for word.  out[0] batches, out[1] positions, out[2..5] FNV-1a over the
+ * words [0, ceil(n_pos / 32)) of planes 0..3 of every batch, out[6] batches that were packed directly. */
+int bfc_ingest_planes_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, int q, int direct, uint64_t out[7])
+{
+	ingest_t in;
+	batch_t b;
+	uint64_t h[4], pw = bfcg_plane_words(cap), w;
+	uint32_t *pl = (uint32_t*)malloc(pw * 16);
+	int p;
+	memset(out, 0, 7 * sizeof(uint64_t));
+	for (p = 0; p < 4; ++p) h[p] = 0xcbf29ce484222325ULL;
+	if (!pl || ingest_open(&in, fn, chunk_size, n_threads, 1) != 0) { free(pl); return -1; }
+	memset(&b, 0, sizeof(b));
+	b.cap = cap;
+	memset(pl, 0xa5, pw * 16); /* (stale words of an earlier batch must not show) */
+	if (direct) { b.planes = pl; b.plane_words = pw; b.q = q; }
+	for (;;) {
+		ingest_fill(&in, &b);
+		if (b.n_seqs) {
+			const uint64_t nw = (b.n_pos + 31) / 32;
+			++out[0]; out[1] += b.n_pos; out[6] += (uint64_t)b.packed;
+			if (!b.packed) bfcg_pack_planes(b.seq, b.has_qual ? b.qual : 0, 0, b.n_pos, b.n_pos, q, pl, pw);
+			for (p = 0; p < (b.has_qual ? 4 : 3); ++p) for (w = 0; w < nw; ++w) {
+				const uint32_t v = pl[(uint64_t)p * pw + w];
+				int k;
+				for (k = 0; k < 4; ++k) h[p] = (h[p] ^ ((v >> (8 * k)) & 0xff)) * 0x100000001b3ULL;
+			}
+		}
+		if (b.last) break;
+	}
+	for (p = 0; p < 4; ++p) out[2 + p] = h[p];
+	free(b.seq); free(b.qual); free(b.kind_cut); free(pl);
 	ingest_close(&in);
 	return 0;
 }

@@ -499,52 +499,22 @@ bfc_ch_t *bfc_ch_restore(const char *fn)
 }
 
 /* ---- bit planes of a byte-stream batch (include/bfc_gpu.h: bfcg_count_batch_planes) -- what count.c:72-89 reads of a position ---- */
+#include "bfc_planes.h"
 uint64_t bfcg_plane_words(uint64_t n_pos) { return (n_pos + 31) / 32 + 2; } /* (two spare words: the device reads a word ahead) */
 void bfcg_pack_planes(const uint8_t *seq, const uint8_t *qual, uint64_t lo, uint64_t hi, uint64_t n_pos, int q, uint32_t *planes, uint64_t plane_words)
 {
-	static const uint8_t code[256] = { /* bseq.c:9-26 minus one (count.c:82); 4 = not a base (count.c:83,88) */
-		4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
-		4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4, 4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4, 4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4, 4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4,
-		4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
-		4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4 };
+	const bfc_qthr_t t = bfc_qthr(q);
 	uint64_t w;
-	const int T = q + 33; /* qual - 33 >= q  <=>  (signed char)qual >= T */
-	const int swar_q = T >= 1 && T <= 127;
-	const uint64_t one = 0x0101010101010101ULL, addq = (uint64_t)(128 - (swar_q ? T : 1)) * one;
 	if (hi > n_pos) hi = n_pos;
 	for (w = lo >> 5; (w << 5) < hi; ++w) {
 		const uint64_t p0 = w << 5;
 		const int n = hi - p0 < 32 ? (int)(hi - p0) : 32;
-		uint32_t m0 = 0, m1 = 0, mn = n < 32 && hi == n_pos ? ~0u << n : 0u, mq = 0; /* beyond the batch's end: separators */
+		uint32_t m0 = 0, m1 = 0, mn = n < 32 && hi == n_pos ? ~0u << n : 0u, mq = 0, m[4]; /* beyond the batch's end: separators */
 		int b;
-		if (n == 32) { /* eight positions per step, bytes side by side in one register (the device's bases4x / quals4x on 64 bits): after folding
-		                * case a byte is A C G T iff bit 7 = 0, bit 6 = 1, bit 3 = 0 and (bit 4, bits 2..0) is (0,001) (0,011) (0,111) or (1,100); the
-		                * code's low bit is bit 1 ^ bit 2, its high bit is bit 2; a multiplication gathers bit 0 of the eight bytes into one byte */
-			int g;
-			for (g = 0; g < 4; ++g) {
-				uint64_t x, u, s1, s2, s3, s4, s6, s7, t1, t2, ok, bad;
-				memcpy(&x, seq + p0 + 8 * g, 8);
-				u = x & 0xDFDFDFDFDFDFDFDFULL; s1 = u >> 1; s2 = u >> 2; s3 = u >> 3; s4 = u >> 4; s6 = u >> 6; s7 = u >> 7;
-				t1 = u & (s1 | ~s2); t2 = s2 & ~s1 & ~u;
-				ok = (s4 & t2) | (~s4 & t1);
-				bad = (s7 | ~s6 | s3 | ~ok) & one;
-				m0 |= (uint32_t)((((s1 ^ s2) & one) * 0x0102040810204080ULL) >> 56) << (8 * g);
-				m1 |= (uint32_t)(((s2 & one) * 0x0102040810204080ULL) >> 56) << (8 * g);
-				mn |= (uint32_t)((bad * 0x0102040810204080ULL) >> 56) << (8 * g);
-				if (qual && swar_q) { /* (b & 0x7f) + (128 - T) carries into bit 7 iff (b & 0x7f) >= T; bytes above 0x7f are negative: never >= T */
-					uint64_t y;
-					memcpy(&y, qual + p0 + 8 * g, 8);
-					mq |= (uint32_t)((((((y & 0x7F7F7F7F7F7F7F7FULL) + addq) & ~y) >> 7 & one) * 0x0102040810204080ULL) >> 56) << (8 * g);
-				}
-			}
-			if (qual && !swar_q) for (b = 0; b < 32; ++b) mq |= (uint32_t)((int)(int8_t)qual[p0 + b] >= T) << b;
-			m0 &= ~mn; m1 &= ~mn; /* (code bits of non-bases: zero, as the table below gives them) */
+		if (n == 32) {
+			for (b = 0; b < 4; ++b) { bfc_planes8(seq + p0 + 8 * b, qual ? qual + p0 + 8 * b : 0, t, m); m0 |= m[0] << (8 * b); m1 |= m[1] << (8 * b); mn |= m[2] << (8 * b); mq |= m[3] << (8 * b); }
 		} else {
-			for (b = 0; b < n; ++b) {
-				const uint32_t c = code[seq[p0 + b]];
-				m0 |= (c & 1u) << b; m1 |= ((c >> 1) & 1u) << b; mn |= (c >> 2) << b;
-			}
-			if (qual) for (b = 0; b < n; ++b) mq |= (uint32_t)((int)(int8_t)qual[p0 + b] - 33 >= q) << b;
+			for (b = 0; b < n; ++b) { bfc_planes1(seq[p0 + b], qual ? qual + p0 + b : 0, t, m); m0 |= m[0] << b; m1 |= m[1] << b; mn |= m[2] << b; mq |= m[3] << b; }
 		}
 		planes[w] = m0; planes[plane_words + w] = m1; planes[2 * plane_words + w] = mn;
 		if (qual) planes[3 * plane_words + w] = mq;

@@ -63,6 +63,9 @@ static inline int rd_line(reader_t *r)
 	}
 }
 
+#include "bfc_planes.h"
+#include <sys/mman.h>
+
 /* ------------------------------------------------------------------ batches */
 
 typedef struct {
@@ -73,9 +76,28 @@ typedef struct {
 	 * Records without qualities are always high quality (count.c:85: qual == NULL), whatever -q says -- no in-band quality byte can
 	 * say that for every q, so bfc_count submits such a batch as its homogeneous runs (batch boundaries never change results). */
 	uint64_t *kind_cut; int n_cut, m_cut, n_noq, last_kind; /* last_kind: -1 none yet, 0 no qualities, 1 qualities */
+	/* planes != NULL: the caller wants the batch as bit planes (bfc_planes.h; 4 planes of plane_words words, threshold q).  The FASTQ fast path
+	 * then writes them straight from the mapped file -- packed = 1, seq / qual are not touched and need not exist --; a batch the serial
+	 * parser fills comes as byte streams (packed = 0; allocated here on first need), which the caller packs itself. */
+	uint32_t *planes; uint64_t plane_words; int q, packed;
 } batch_t;
 
-static inline void batch_clear(batch_t *b) { b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0; b->n_cut = 0; b->n_noq = 0; b->last_kind = -1; }
+static inline int batch_need_streams(batch_t *b)
+{
+	if (b->seq && b->qual) return 1;
+	{
+		void *p = 0, *r = 0;
+		const uint64_t rounded = (b->cap + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+		if (posix_memalign(&p, 2u << 20, rounded) != 0 || posix_memalign(&r, 2u << 20, rounded) != 0) { free(p); return 0; }
+#ifdef MADV_HUGEPAGE
+		(void)madvise(p, rounded, MADV_HUGEPAGE); (void)madvise(r, rounded, MADV_HUGEPAGE);
+#endif
+		b->seq = (uint8_t*)p; b->qual = (uint8_t*)r;
+	}
+	return 1;
+}
+
+static inline void batch_clear(batch_t *b) { b->n_pos = 0; b->n_seqs = 0; b->has_qual = 0; b->last = 0; b->n_cut = 0; b->n_noq = 0; b->last_kind = -1; b->packed = 0; }
 
 /* append one record to the batch; returns 0 if it does not fit */
 static inline int batch_put(batch_t *b, const uint8_t *s, const uint8_t *q, size_t l)
@@ -215,6 +237,7 @@ typedef struct {
 	fq_rec_t *rec; uint64_t n_rec, m_rec, bases; /* strict records whose '@' lies in the slice */
 	uint64_t start, end; int found, status;      /* where the walk began / stopped, and why (FQ_OK: ran into the slice end) */
 	uint8_t *oseq, *oqual; uint64_t n_copy;      /* copy phase */
+	uint32_t *pl; uint64_t pw, opos; int q;      /* ... or straight into bit planes: the job's records begin at stream position opos */
 } fq_job_t;
 
 static void *fq_scan(void *arg)
@@ -260,6 +283,49 @@ static void *fq_copy(void *arg)
 		memcpy(os, sq, l); os[l] = '\n'; os += l + 1;
 		memcpy(oq, ql, l); oq[l] = '!'; oq += l + 1;
 	}
+	return 0;
+}
+
+/* The same records as bit planes (bfc_planes.h), without the byte streams in between: a job appends its records' positions -- bases, then one
+ * separator per record -- at bit opos of the batch's four planes.  Words that a job shares with its neighbours (its first and its last) are
+ * OR-ed in atomically (the caller cleared them), the others are stored. */
+typedef struct { uint32_t *pl; uint64_t pw, w, w_first, w_last; int off; uint64_t a[4]; } bitw_t;
+static inline void bw_flush(bitw_t *s)
+{
+	int p;
+	if (s->w == s->w_first || s->w == s->w_last) { for (p = 0; p < 4; ++p) __atomic_fetch_or(&s->pl[(uint64_t)p * s->pw + s->w], (uint32_t)s->a[p], __ATOMIC_RELAXED); }
+	else for (p = 0; p < 4; ++p) s->pl[(uint64_t)p * s->pw + s->w] = (uint32_t)s->a[p];
+	for (p = 0; p < 4; ++p) s->a[p] >>= 32;
+	++s->w; s->off -= 32;
+}
+static inline void bw_put(bitw_t *s, const uint32_t m[4], int n)
+{
+	s->a[0] |= (uint64_t)m[0] << s->off; s->a[1] |= (uint64_t)m[1] << s->off; s->a[2] |= (uint64_t)m[2] << s->off; s->a[3] |= (uint64_t)m[3] << s->off;
+	s->off += n;
+	if (s->off >= 32) bw_flush(s);
+}
+static void *fq_pack(void *arg)
+{
+	fq_job_t *j = (fq_job_t*)arg;
+	const bfc_qthr_t t = bfc_qthr(j->q);
+	const uint32_t sep[4] = { 0, 0, 1, (uint32_t)((int)'!' >= t.T) }; /* (the byte streams carry '\n' and '!' there: the same bits) */
+	bitw_t s;
+	uint64_t i, n_pos = 0;
+	if (j->n_copy == 0) return 0;
+	for (i = 0; i < j->n_copy; ++i) n_pos += j->rec[i].len + 1;
+	s.pl = j->pl; s.pw = j->pw; s.w = j->opos >> 5; s.w_first = s.w; s.w_last = (j->opos + n_pos - 1) >> 5; s.off = (int)(j->opos & 31);
+	s.a[0] = s.a[1] = s.a[2] = s.a[3] = 0;
+	for (i = 0; i < j->n_copy; ++i) {
+		const uint8_t *sq = j->base + j->rec[i].hdr + j->rec[i].seq_delta;
+		const uint32_t l = j->rec[i].len;
+		const uint8_t *pl = sq + l + (sq[l] == '\r' ? 2 : 1);
+		const uint8_t *ql = fq_eol(pl, j->base + j->win_end) + 1;
+		uint32_t k = 0, m[4];
+		for (; k + 8 <= l; k += 8) { bfc_planes8(sq + k, ql + k, t, m); bw_put(&s, m, 8); }
+		for (; k < l; ++k) { bfc_planes1(sq[k], ql + k, t, m); bw_put(&s, m, 1); }
+		bw_put(&s, sep, 1);
+	}
+	if (s.off > 0) { s.off += 32; bw_flush(&s); } /* (the last, partial word) */
 	return 0;
 }
 
@@ -355,15 +421,27 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 		/* copy */
 		{
 			uint64_t o = 0, last_hdr = 0; const fq_job_t *lastj = 0;
+			const int to_planes = b->planes != 0;
+			if (!to_planes && !batch_need_streams(b)) return 0;
 			for (i = 0; i < n_used; ++i) {
 				fq_job_t *j = &f->job[i];
 				uint64_t k, bsum = 0;
-				j->oseq = b->seq + o; j->oqual = b->qual + o;
+				if (to_planes) { j->pl = b->planes; j->pw = b->plane_words; j->opos = o; j->q = b->q; }
+				else { j->oseq = b->seq + o; j->oqual = b->qual + o; }
 				if (j->n_copy == j->n_rec) bsum = j->bases; else for (k = 0; k < j->n_copy; ++k) bsum += j->rec[k].len;
+				if (to_planes && j->n_copy) { /* the words this job shares with its neighbours start out clear */
+					int p;
+					for (p = 0; p < 4; ++p) { b->planes[(uint64_t)p * b->plane_words + (o >> 5)] = 0; b->planes[(uint64_t)p * b->plane_words + ((o + bsum + j->n_copy - 1) >> 5)] = 0; }
+				}
 				o += bsum + j->n_copy;
 				if (j->n_copy) { lastj = j; last_hdr = j->rec[j->n_copy - 1].hdr; }
 			}
-			fq_run(f, fq_copy, n_used > 0 ? n_used : 1);
+			if (n_used == 0) f->job[0].n_copy = 0;
+			fq_run(f, to_planes ? fq_pack : fq_copy, n_used > 0 ? n_used : 1);
+			if (to_planes) {
+				if (o & 31) b->planes[2 * b->plane_words + (o >> 5)] |= ~0u << (o & 31); /* beyond the batch's end: separators */
+				b->packed = 1;
+			}
 			b->n_pos = o; b->n_seqs = (int)nseq; b->has_qual = nseq > 0; b->last_kind = nseq > 0 ? 1 : -1;
 			if (lastj) { /* the next batch starts after the last record taken */
 				const uint8_t *nx = 0;
@@ -470,7 +548,10 @@ static inline void ingest_fill(ingest_t *in, batch_t *b)
 			in->ps.rd.total = in->fast.pos; in->ps.rd.first_piece = RD_PIECE - (int)(in->fast.pos % RD_PIECE);
 		}
 	}
-	if (!done) { fill_batch(&in->ps, b); if (b->n_seqs) ++in->serial_batches; }
+	if (!done) {
+		if (!batch_need_streams(b)) { fprintf(stderr, "[E::bfc_count] cannot allocate %llu bytes of batch buffers\n", (unsigned long long)b->cap); abort(); }
+		fill_batch(&in->ps, b); if (b->n_seqs) ++in->serial_batches;
+	}
 	b->last = 0;
 	if (b->n_seqs == 0 && ++in->empties >= in->workers) b->last = 1;
 }

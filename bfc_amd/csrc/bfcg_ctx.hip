@@ -382,7 +382,9 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	}
 	if (prm->debug_seen) HIPCKN(hipMalloc(&B.seen_out, prm->max_batch_pos));
 	if (!P.filter_mode) { // filter mode hands nothing over: both filters' slices are in LDS
-		HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
+		// (the aggregation buffer of the host-layout commit -- 1.6 GB at -b35, 6.4 GB at -b37 -- is allocated when a batch first needs it:
+		// a context on region-owned segments never does unless its table escapes to the host's layout: ensure_agg)
+		if (!c->seg_ok) HIPCKN(hipMalloc(&B.agg_out, (uint64_t)nfine * P.ag_cap * (P.track ? 32 : 24)));
 		HIPCKN(hipMalloc(&B.agg_cnt, sizeof(uint32_t) * nfine));
 	}
 	for (int b = 0; b < 2; ++b) { HIPCKN(hipMalloc(&c->d_seq2[b], prm->max_batch_pos)); HIPCKN(hipMalloc(&c->d_qual2[b], prm->max_batch_pos + 64)); }
@@ -423,6 +425,7 @@ static int replay_poisoned(bfcg_ctx_t *c);
 static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, uint32_t slab_cap, hipEvent_t *wait, int n_wait);
 extern "C" int bfcg_mg_process_ev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg_cnt, hipEvent_t *wait, int n_wait);
 static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats);
+static int ensure_agg(bfcg_ctx_t *c);
 static int same_block_offset(bfcg_ctx_t *c, int b, const uint8_t *d_seq, const uint8_t **d_qual, uint64_t n_pos, hipStream_t s);
 static int commit_pending_pages(bfcg_ctx_t *c, int b);
 static void absorb_pages(bfcg_ctx_t *c, int b);
@@ -951,7 +954,7 @@ static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg
 	HIPCK(hipMemcpyAsync(d, seg_beg, sizeof(uint32_t) * words, hipMemcpyHostToDevice, c->st));
 	if (c->B.seen_out) HIPCK(hipMemsetAsync(c->B.seen_out, 0, c->prm.max_batch_pos, c->st));
 	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
-	if (use_stream(c) != 0) return -1;
+	if (use_stream(c) != 0 || ensure_agg(c) != 0) return -1;
 	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
 	BatchBufs Bt = c->B;
 	const int op2_run = c->mg_op2 && c->mg_op2_allowed && c->cap2; // (as enqueue_batch: every batch of a one-pass run tests the sticky word and is queued)
@@ -1117,9 +1120,18 @@ static int same_block_offset(bfcg_ctx_t *c, int b, const uint8_t *d_seq, const u
 // One batch, software-pipelined over two streams: stage A of this batch (ALU-bound K1) is enqueued on stA and runs
 // under stage B of the previous batch (LDS/latency-bound) on st.  The call returns once the PREVIOUS batch is
 // finalised (statistics read, table maintained); bfcg_sync / bfcg_stats / exports drain the pipeline.
+static int ensure_agg(bfcg_ctx_t *c)
+{
+	if (c->P.filter_mode || c->P.seg || c->B.agg_out) return 0;
+	const uint64_t nfine = ((uint64_t)1 << c->P.F) >> c->log2n;
+	HIPCK(hipMalloc(&c->B.agg_out, nfine * c->P.ag_cap * (c->P.track ? 32 : 24)));
+	return 0;
+}
+
 static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, int wait_copy, int no_kstats)
 {
 	const int b = c->cur, nb1 = 1 << c->P.F1;
+	if (ensure_agg(c) != 0) return -1;
 	BatchBufs Bt = c->B;
 	Bt.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1; Bt.recs1 = c->recs1[b];

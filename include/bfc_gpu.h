@@ -237,6 +237,9 @@ bfc_ch_t *bfcg_export_table(bfcg_ctx_t *c);              /* host bfc_ch_t (calle
  * [3]/[4] FNV-1a of all sequence / quality streams, [5] FNV-1a of the per-batch read counts, [6] batches parsed by the multi-threaded
  * fast path (uncompressed strict 4-line FASTQ; n_threads = 0 forces the serial parser).  Used to test that both parsers agree. */
 int bfc_ingest_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, uint64_t out[7]);
+/* the same batches as bit planes: direct = 1 written by the FASTQ fast path straight from the mapped file, 0 packed from the byte streams (they
+ * must agree word for word: tests/test_ingest.py).  out[0] batches, out[1] positions, out[2..5] FNV-1a of planes 0..3, out[6] batches packed directly */
+int bfc_ingest_planes_digest(const char *fn, uint64_t chunk_size, uint64_t cap, int n_threads, int q, int direct, uint64_t out[7]);
 /* gzip input (bseq.c:33-50 reads it through one gzread stream): bfc_count inflates a regular .gz file with n_threads threads -- guessed
  * block starts, 16-bit symbols with markers for the unknown 32 KiB window, pieces chained only where one started exactly where its
  * predecessor stopped, CRC-32 / ISIZE of every member checked (bfc_pgz.h); anything it cannot decode goes through gzread.  This runs that

@@ -191,3 +191,37 @@ def test_damaged_inputs_parse_like_the_reference(gpu_lib, tmp_path, seed):
                 if got != want:
                     open("/tmp/ingest_fail.fq", "wb").write(text)
                 assert got == want, (seed, rep, chunk, threads, min_slice)
+
+
+def _planes_digest(fn, chunk, threads, q, direct, cap=1 << 24):
+    from bfc_amd import _lib
+    out = (C.c_uint64 * 7)()
+    assert _lib.load().bfc_ingest_planes_digest(fn.encode(), chunk, cap, threads, q, direct, out) == 0
+    return [int(v) for v in out]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bit_planes_straight_from_the_file(gpu_lib, tmp_path, case):
+    """bfc_count on one GPU hands its batches over as bit planes; the FASTQ fast path writes them straight from the mapped file (no byte streams
+    in between): word for word what bfcg_pack_planes makes of the serial parser's byte streams -- any read lengths (a record may begin at any
+    bit of a word, threads share words at their seams), CRLF, thresholds a signed char cannot reach, inputs that fall back to the serial parser."""
+    rng = np.random.default_rng(zlib.crc32(case.encode()) + 17)
+    fn = str(tmp_path / (case + ".fq"))
+    size = _make(case, fn, rng)
+    for chunk in (20000, 1 << 30) if size < (1 << 22) else (500000,):
+        for q in (20, 0, 41, 95, -200):
+            want = _planes_digest(fn, chunk, 0, q, 0)
+            assert want[6] == 0
+            for threads in (1, 3, 8):
+                got = _planes_digest(fn, chunk, threads, q, 1)
+                assert got[:6] == want[:6], (case, chunk, q, threads)
+            if case in ("plain", "crlf", "tiny_reads", "long_reads") and want[0]:
+                assert got[6] == want[0], "every batch of a strict FASTQ is packed directly"
+                os.environ["BFC_INGEST_MIN_SLICE"] = "64"  # 8 walks inside every batch, however small: seams inside words
+                try:
+                    tiny = _planes_digest(fn, chunk, 8, q, 1)
+                finally:
+                    os.environ.pop("BFC_INGEST_MIN_SLICE", None)
+                assert tiny[:6] == want[:6] and tiny[6] == want[0], (case, chunk, q)
+            if q != 20:
+                continue
