@@ -24,6 +24,7 @@ static thread_local char g_err[512] = "";
 enum { HO_MAX_PAGES = 8 };
 enum { OP_FLAG_WORDS = 12, OP_STICKY = 8 }; // bfcg_ctx.op_flags: two slots of four words, the sticky poison word
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static inline void set_seg_shift(KParams &P, int s, int blk_max) { P.seg_shift = s; P.seg_blk = s < blk_max ? s : blk_max; }
 static int set_err(const char *fmt, ...)
 {
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -73,6 +74,8 @@ struct bfcg_ctx {
 	uint64_t seen_last, pos_final, slot_pos[2]; // seen k-mers at the last finalised batch; positions of the batch(es) finalised since; positions of a slot's batch
 	int pipeline;                // stage A of batch t+1 on its own stream under stage B of batch t
 	int seg_ok;                  // the geometry allows region-owned table segments (KParams.seg): every reset starts in that layout
+	int seg_total_max;           // slots of a segment at most (log2; BFCG_SEG_TOTAL lowers BFCG_SEG_TOTAL_MAX: 14 = round 3's behaviour, larger tables leave for the host's layout)
+	int seg_blk_max;             // slots of a segment's block (log2): 14 = what a CU's LDS holds; BFCG_SEG_BLOCK lowers it so that small tests run segments of several blocks
 	int b3_ok;                   // ... and the bloom insert of batches without `dedupe` runs k_bloom3 (KParams.b3)
 	uint32_t fs_cap_w, list_cap_w; // k_bloom3's LDS tables for batches into a WARM filter (0: none): a footprint of a quarter of a CU's LDS
 	int seg_init_shift;          // log2 slots per segment after a reset
@@ -340,7 +343,9 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (prm->tab_cshift <= 0) while (((uint64_t)nfine << sh) < prm->max_batch_pos / 4 && sh < BFCG_SEG_MAX_SHIFT) ++sh;
 		if (sh > BFCG_SEG_MAX_SHIFT) sh = BFCG_SEG_MAX_SHIFT;
 		c->seg_init_shift = sh;
-		P.seg = 1; P.seg_shift = sh; c->seg_cap_shift = sh;
+		{ const char *e = getenv("BFCG_SEG_BLOCK"); c->seg_blk_max = e && atoi(e) >= 3 && atoi(e) <= BFCG_SEG_MAX_SHIFT ? atoi(e) : BFCG_SEG_MAX_SHIFT; }
+		{ const char *e = getenv("BFCG_SEG_TOTAL"); c->seg_total_max = e && atoi(e) >= c->seg_blk_max && atoi(e) <= BFCG_SEG_TOTAL_MAX ? atoi(e) : BFCG_SEG_TOTAL_MAX; }
+		P.seg = 1; set_seg_shift(P, sh, c->seg_blk_max); c->seg_cap_shift = sh;
 		HIPCKN(set_seg_lds_attr());
 		HIPCKN(hipMalloc(&B.seg_tab, ((uint64_t)nfine << sh) * 8));
 		{ // the hand-over log: ho_K pages per region where level 2 bounds a region's share of a batch (its slab), else one batch at its records' offsets
@@ -462,10 +467,10 @@ extern "C" int bfcg_reset(bfcg_ctx_t *c)
 			HIPCK(hipStreamSynchronize(c->st));
 			if (c->B.table) { HIPCK(hipFree(c->B.table)); c->B.table = 0; }
 			if (c->B.seg_tab) { HIPCK(hipFree(c->B.seg_tab)); c->B.seg_tab = 0; }
-			c->P.seg_shift = c->seg_cap_shift = c->seg_init_shift;
+			set_seg_shift(c->P, c->seg_init_shift, c->seg_blk_max); c->seg_cap_shift = c->seg_init_shift;
 			HIPCK(hipMalloc(&c->B.seg_tab, (nfine << c->P.seg_shift) * 8));
 		} else {
-			c->P.seg_shift = c->seg_init_shift; // start small again inside the allocation the last run grew to (seg_cap_shift says how far it goes)
+			set_seg_shift(c->P, c->seg_init_shift, c->seg_blk_max); // start small again inside the allocation the last run grew to (seg_cap_shift says how far it goes)
 			if (c->n_batches && c->seg_spare && c->seg_spare_shift < c->seg_cap_shift && ((nfine << c->seg_cap_shift) * 8) <= (16ULL << 30)) {
 				// second data set on this context: make the spare as large as the segments grew, so that this run's growths find their target ready
 				HIPCK(hipStreamSynchronize(c->st));
@@ -740,22 +745,22 @@ static int seg_maintain(bfcg_ctx_t *c)
 		  // parked and the mean load stays below 85 % (probing happens in LDS: a fuller segment costs probes, not HBM traffic) ...
 			size_t free_b = 0, total_b = 0;
 			const bool no_room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && ((nfine << target) * 8) + (1ULL << 30) > (uint64_t)free_b + (c->seg_spare && c->seg_spare_shift >= target ? (nfine << c->seg_spare_shift) * 8 : 0);
-			if (no_room || target > BFCG_SEG_MAX_SHIFT) {
+			if (no_room || target > c->seg_total_max) { // (beyond 2^14 slots a segment is several blocks, one workgroup each: KParams.seg_blk)
 				if (ovf == 0 && (double)c->h_stats[ST_KEYS] < 0.85 * (double)(nfine << P.seg_shift)) { c->seg_no_grow = 1; return 0; }
-				if (target > BFCG_SEG_MAX_SHIFT) return seg_to_legacy(c); // ... else the host's layout takes over (random CAS upserts, any size)
+				if (target > c->seg_total_max) return seg_to_legacy(c); // ... else the host's layout takes over (random CAS upserts, any size)
 				return set_err("count table of %llu keys cannot grow to 2^%d slots per region: %.1f GiB of device memory free", (unsigned long long)c->h_stats[ST_KEYS], target, free_b / 1073741824.0);
 			}
 		}
-		const int old_shift = P.seg_shift;
+		const int old_shift = P.seg_shift, old_blk = P.seg_blk;
 		unsigned long long *nt = 0;
 		int nt_shift = target;
-		P.seg_shift = target;
+		set_seg_shift(P, target, c->seg_blk_max);
 		if (c->seg_spare && c->seg_spare_shift >= target) { nt = c->seg_spare; nt_shift = c->seg_spare_shift; c->seg_spare = 0; }
 		else {
 			if (c->seg_spare) { HIPCK(hipFree(c->seg_spare)); c->seg_spare = 0; }
 			HIPCK(hipMalloc(&nt, (nfine << target) * 8));
 		}
-		run_seg_rehash(P, B.seg_tab, old_shift, nt, (uint32_t)nfine, c->st);
+		run_seg_rehash(P, B.seg_tab, old_shift, old_blk, nt, (uint32_t)nfine, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		HIPCK(hipGetLastError());
 		if (((nfine << nt_shift) * 8) <= (16ULL << 30)) {

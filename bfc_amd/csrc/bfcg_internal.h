@@ -42,7 +42,9 @@ struct KParams {
 	int ablate;                 // measurement switches (BFCG_ABLATE): honoured only by a library built with -DBFCG_MEASURE (see BFCG_ABL below)
 	int bloom_bt;               // threads per workgroup of the bloom kernel: 512 (three workgroups per CU), 1024 when the LDS footprint allows one only
 	int seg;                    // 1: the count table is kept as region-owned segments (seg_tab) and updated through LDS by k_commit_seg
-	int seg_shift;              // log2 slots per segment
+	int seg_shift;              // log2 slots per region's table segment
+	int seg_blk;                // a segment is 2^(seg_shift - seg_blk) BLOCKS of 2^seg_blk slots (seg_blk = min(seg_shift, 14): a block fits a CU's LDS); a key lives in
+	                            // block (seg_home(id) >> seg_blk) & (blocks - 1), probing stays inside it: up to 2^14 slots a segment is one block
 	int seg_lo, seg_hi;         // bits [seg_lo, seg_hi) of y0 are implied by the region (kmer_dev.h: SegGeom)
 	uint32_t f_base;            // global id of this rank's first bloom region
 	int no_kstats;              // stage A does not count k-mers / high-quality k-mers (a batch that is replayed was counted the first time)
@@ -98,13 +100,14 @@ void run_hash_only(const KParams &P, const uint8_t *seq, const uint8_t *qual, in
 void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap,
                       unsigned long long *first, unsigned long long *sub_last, hipStream_t st);
 // region-owned segments: grow every segment from 2^old_shift to 2^P.seg_shift slots; replay parked k-mers; convert to the (sub-table, key) layout
-void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st);
+void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, int old_blk, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st);
 void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
 void run_seg_to_table(const KParams &P, const unsigned long long *seg_tab, uint32_t n_fine, unsigned long long *tab, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
 hipError_t set_seg_lds_attr(void);
 // apply the pages 0..pages-1 of the hand-over log to the segments (no bloom pass): before a batch that cannot use the log, and when the pipeline is drained
 void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st);
-#define BFCG_SEG_MAX_SHIFT 14 /* a segment must fit a CU's LDS: 2^14 slots = 128 KiB */
+#define BFCG_SEG_MAX_SHIFT 14 /* a segment's BLOCK must fit a CU's LDS: 2^14 slots = 128 KiB */
+#define BFCG_SEG_TOTAL_MAX 24 /* slots per region at most (seg_home has 26 bits): 2^10 blocks */
 void run_table_rehash(const KParams &P, const unsigned long long *old_tab, int cshift_old, unsigned long long *new_tab,
                       const unsigned long long *old_first, unsigned long long *new_first, hipStream_t st);
 

@@ -1727,7 +1727,13 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
 	__shared__ uint32_t s_new[8], s_mark[8]; // (HO_MAX_PAGES, bfcg_ctx.hip)
-	const uint32_t f = blockIdx.x;
+	// Round 4: a segment of more than 2^14 slots (a genome that is large for its filter: 10 000 keys per region and more) is 2^ub BLOCKS of
+	// 2^14 slots, one workgroup per (region, block): a key lives in block (seg_home >> seg_blk) & (blocks - 1) and is probed inside it, so a
+	// block is what a segment was -- staged in LDS, applied, stored -- and its workgroup takes those entries of the region's pages that are
+	// its own (every block's workgroup reads all of them: 8 bytes per entry against the 128 KiB of the block).  Before, such a table left
+	// the region-owned layout for the host's and random device-scope CAS (218 B of HBM traffic per upsert).
+	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk), blk_mask = (1u << ub) - 1u;
+	const uint32_t f = blockIdx.x >> ub, blk = blockIdx.x & blk_mask;
 	const bool log = A.ho_stride != 0;
 	const uint32_t pages = log ? (A.ho_pages < 8u ? A.ho_pages : 8u) : 1u;
 	uint32_t n;
@@ -1741,8 +1747,10 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 		recs = reinterpret_cast<const unsigned long long *>(A.stream_out) + rs0;
 	}
 	if (n == 0) return;
-	const uint32_t slots = 1u << P.seg_shift, mask = slots - 1;
-	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift);
+	const uint32_t slots = 1u << P.seg_blk, mask = slots - 1;
+	unsigned long long *gseg = A.seg_tab + ((uint64_t)f << P.seg_shift) + ((uint64_t)blk << P.seg_blk);
+	const int blk_sh = P.seg_blk;
+	auto mine = [&](unsigned long long v) -> bool { return ((seg_home(v >> 1) >> blk_sh) & blk_mask) == blk; }; // (one block: always)
 	const SegGeom G = seg_geom(P);
 	// Round 4: everything a page needs is requested BEFORE the segment is staged -- every page's end mark (one lane each, not one dependent
 	// load per page in front of its barrier) and a thread's first two entries -- and a page costs one barrier, not two (a counter of new keys
@@ -1759,7 +1767,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	// Segments up to 2^12 slots keep a 32-bit counter pair per slot behind the segment in LDS: an occurrence of a key that is already there is ONE
 	// non-returning LDS add (calls | high-quality calls << 16) instead of a compare-and-swap loop on the slot -- hot keys no longer make their
 	// lanes retry -- and the counters are folded into the slots, saturating, before the segment goes back (htab.c:73-79 is order-free).
-	const bool use_cnt = !direct && P.seg_shift <= 12 && n < 65536u && !BFCG_ABL(P, 16);
+	const bool use_cnt = !direct && P.seg_blk <= 12 && n < 65536u && !BFCG_ABL(P, 16);
 	unsigned int *lcnt = reinterpret_cast<unsigned int *>(lseg + slots);
 	if (!direct) {
 		const uint4 *src = reinterpret_cast<const uint4 *>(gseg);
@@ -1783,7 +1791,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 					const uint64_t id = v0 >> 1;
 					const uint32_t hi = (uint32_t)(v0 & 1);
 					const unsigned long long fresh = (id << 14) | 1ULL | ((unsigned long long)hi << 8); // (the creating call is the slot's count 1)
-					bool done = false;
+					bool done = ub != 0 && !mine(v0); // (another block's entry)
 					// An even slot is read together with its neighbour (one 16-byte LDS read): the probe sequence is the same, a step that would only
 					// have found another key in slot p goes on to p + 1 at once (scripts/probes/commit_probe.hip on c3's shape: 12.5 -> 11.6 ms per pass).
 					// A zero that went stale meanwhile is examined again by the compare-and-swap; a slot that holds a key keeps it.
@@ -1791,7 +1799,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 					const bool pair = !(p & 1u);
 					if (pair) { const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(&lseg[p]); cur = pr.x; nxt = pr.y; }
 					else cur = lseg[p];
-					if (cur == 0) {
+					if (!done && cur == 0) {
 						cur = atomicCAS(&lseg[p], 0ULL, fresh);
 						if (cur == 0) { ++n_new; done = true; }
 					}
@@ -1827,6 +1835,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 		uint32_t n_new = 0;
 		for (; j < end; j += BT, ++k) {
 			const unsigned long long v = k == 0 ? pre0 : k == 1 ? pre1 : recs[j];
+			if (ub != 0 && !mine(v)) continue; // (another block's entry)
 			const uint64_t id = v >> 1;
 			const uint32_t hi = (uint32_t)(v & 1);
 			const int r = direct ? seg_upsert<false>(gseg, mask, id, 1u, hi) : seg_upsert<true>(lseg, mask, id, 1u, hi);
@@ -1861,26 +1870,32 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 			atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_KEYS], (unsigned long long)pn);
 		}
 	}
-	if (threadIdx.x == 0 && log) A.ho_cur[f] = 0; // the log is empty again
+	if (threadIdx.x == 0 && log && blk == 0) A.ho_cur[f] = 0; // the log is empty again (the other blocks' workgroups read the pages' marks, not the cursor)
 }
 
-// grow: segment f of 2^old_shift slots -> 2^P.seg_shift slots, rebuilt in LDS (all keys are distinct, the new segment is at most half full)
+// grow: segment f of 2^old_shift slots -> 2^P.seg_shift slots, rebuilt in LDS BLOCK by block (all keys are distinct, a new block is at most half
+// full).  Workgroup (f, blk) builds block blk of the new segment from the old block its keys can come from -- block blk & (old blocks - 1): the
+// block of a key is a bit field of its home, which only gains high bits when the segment grows -- and takes the keys whose new block it is.
 template <int BT>
-__global__ __launch_bounds__(BT) void k_seg_rehash(KParams P, const unsigned long long *__restrict__ old_tab, int old_shift, unsigned long long *__restrict__ new_tab)
+__global__ __launch_bounds__(BT) void k_seg_rehash(KParams P, const unsigned long long *__restrict__ old_tab, int old_shift, int old_blk, unsigned long long *__restrict__ new_tab)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
-	const uint32_t f = blockIdx.x, slots = 1u << P.seg_shift, mask = slots - 1, old_slots = 1u << old_shift;
-	const unsigned long long *src = old_tab + ((uint64_t)f << old_shift);
+	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk), blk_mask = (1u << ub) - 1u, ub_old = (uint32_t)(old_shift - old_blk);
+	const uint32_t f = blockIdx.x >> ub, blk = blockIdx.x & blk_mask;
+	const uint32_t slots = 1u << P.seg_blk, mask = slots - 1, old_slots = 1u << old_blk;
+	const unsigned long long *src = old_tab + ((uint64_t)f << old_shift) + ((uint64_t)(blk & ((1u << ub_old) - 1u)) << old_blk);
 	for (uint32_t i = threadIdx.x; i < slots; i += BT) lseg[i] = 0;
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < old_slots; i += BT) {
 		const unsigned long long v = src[i];
 		if (!v) continue;
-		uint32_t p = seg_home(v >> 14) & mask;
+		const uint32_t home = seg_home(v >> 14);
+		if (((home >> P.seg_blk) & blk_mask) != blk) continue;
+		uint32_t p = home & mask;
 		while (atomicCAS(&lseg[p], 0ULL, v) != 0ULL) p = (p + 1) & mask;
 	}
 	__syncthreads();
-	uint4 *dst = reinterpret_cast<uint4 *>(new_tab + ((uint64_t)f << P.seg_shift));
+	uint4 *dst = reinterpret_cast<uint4 *>(new_tab + ((uint64_t)f << P.seg_shift) + ((uint64_t)blk << P.seg_blk));
 	const uint4 *s4 = reinterpret_cast<const uint4 *>(lseg);
 	for (uint32_t i = threadIdx.x; i < slots / 2; i += BT) dst[i] = s4[i];
 }
@@ -1892,13 +1907,15 @@ __global__ void k_seg_replay(KParams P, unsigned long long *seg_tab, const uint6
 {
 	BloomArgs A; A.tab_ovf = ovf; A.tab_ovf_cap = ovf_cap; A.ovf_cnt = ovf_cnt;
 	const SegGeom G = seg_geom(P);
-	const uint32_t mask = (1u << P.seg_shift) - 1;
+	const uint32_t mask = (1u << P.seg_blk) - 1, blk_mask = (1u << (P.seg_shift - P.seg_blk)) - 1u;
 	stats += (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint64_t y0 = src[5 * i], y1 = src[5 * i + 1];
 		const uint32_t c = (uint32_t)src[5 * i + 2], h = (uint32_t)(src[5 * i + 2] >> 32);
 		const uint32_t f = fine_id<W>(P, y0, y1) - P.f_base;
-		const int r = seg_upsert<false>(seg_tab + ((uint64_t)f << P.seg_shift), mask, seg_id(G, y0, y1), c, h);
+		const uint64_t id = seg_id(G, y0, y1);
+		const uint32_t blk = (seg_home(id) >> P.seg_blk) & blk_mask; // (the key's block of the segment; probing stays inside it)
+		const int r = seg_upsert<false>(seg_tab + ((uint64_t)f << P.seg_shift) + ((uint64_t)blk << P.seg_blk), mask, id, c, h);
 		if (r > 0) atomicAdd(&stats[ST_KEYS], 1ULL);
 		else if (r < 0) seg_park(A, y0, y1, c, h);
 	}
@@ -2247,9 +2264,10 @@ bool bloom3_geometry_ok(const KParams &P) { return bfcg_rec_dwords(P.k, P.rec_n)
 
 static void launch_commit_seg(const KParams &P, const BloomArgs &A, int nfine, hipStream_t st)
 {
-	if (P.seg_shift >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(nfine), dim3(1024), (size_t)8 << P.seg_shift, st, P, A);
-	else if (P.seg_shift == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(nfine), dim3(512), (size_t)12 << P.seg_shift, st, P, A); // (+ 4 bytes of counters per slot)
-	else hipLaunchKernelGGL((k_commit_seg<256>), dim3(nfine), dim3(256), (size_t)12 << P.seg_shift, st, P, A);
+	const unsigned grid = (unsigned)nfine << (P.seg_shift - P.seg_blk); // one workgroup per (region, block of its segment)
+	if (P.seg_blk >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(grid), dim3(1024), (size_t)8 << P.seg_blk, st, P, A);
+	else if (P.seg_blk == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(grid), dim3(512), (size_t)12 << P.seg_blk, st, P, A); // (+ 4 bytes of counters per slot)
+	else hipLaunchKernelGGL((k_commit_seg<256>), dim3(grid), dim3(256), (size_t)12 << P.seg_blk, st, P, A);
 	dbg_sync(st, "k_commit_seg");
 }
 void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st)
@@ -2469,9 +2487,9 @@ void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t 
 	hipLaunchKernelGGL(k_table_replay, dim3(g), dim3(256), 0, st, P, tab, src, n, stats, ovf, ovf_cap, stats + (size_t)ST_SLOTS * ST_N, O);
 }
 hipError_t set_seg_lds_attr(void) { return hipFuncSetAttribute((const void *)k_seg_rehash<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); }
-void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st)
+void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, int old_blk, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st)
 {
-	hipLaunchKernelGGL((k_seg_rehash<512>), dim3(n_fine), dim3(512), (size_t)8 << P.seg_shift, st, P, old_tab, old_shift, new_tab);
+	hipLaunchKernelGGL((k_seg_rehash<512>), dim3(n_fine << (P.seg_shift - P.seg_blk)), dim3(512), (size_t)8 << P.seg_blk, st, P, old_tab, old_shift, old_blk, new_tab);
 }
 void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
 {

@@ -65,7 +65,7 @@ for br in sizes:
     ms, nb = g.stage_ms()
     assert st["n_kmers"] == n_kmers, (st["n_kmers"], n_kmers)
     res = dict(batch_reads=br, batches=nb, wall_s=round(dt, 4), G_kmers_per_s=round(n_kmers / dt / 1e9, 3), n_kmers=n_kmers, n_seen=st["n_seen"], n_keys=st["n_keys"],
-               slow_buckets=st["slow_buckets"], tab_cshift=st["tab_cshift"], stage_ms={k_: round(v, 2) for k_, v in ms.items()},
+               slow_buckets=st["slow_buckets"], tab_cshift=st["tab_cshift"], table=g.table_info(), stage_ms={k_: round(v, 2) for k_, v in ms.items()},
                bloom_GBps_algorithmic=round(128 * n_kmers / (ms["bloom"] * 1e-3) / 1e9, 1), bloom_frac=round(128 * n_kmers / (ms["bloom"] * 1e-3) / 1e9 / 8000, 4))
     if args.digest:
         t2 = time.time()

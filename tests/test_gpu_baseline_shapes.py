@@ -333,3 +333,30 @@ def test_clean_batch_followed_by_an_overflowing_one(gpu_lib, monkeypatch, fm):
         g.reset()
     g.dev_free(d_s); g.dev_free(d_q)
     g.close(); oc.close()
+
+
+def test_segments_larger_than_lds_stay_region_owned(gpu_lib):
+    """A genome that is LARGE for its filter (-b22: 32 bloom regions; 1.2 Mbp at 6x: ~40 000 keys per region): the table's segments pass 2^14
+    slots -- what a CU's LDS holds -- and become several blocks, one workgroup each, instead of leaving the region-owned layout for the host's
+    and random device-scope CAS as before round 4 (SURVEY 8a htab.c:60-82 through LDS at any table size).  Bit-exact against the oracle."""
+    rs = gen.ReadSet(seed=77, G=1_200_000, cov=6)
+    seq, qual, off = rs.reads()
+    k, b = 27, 22  # (2k - 5 region bits = 49 identity bits: within the 50 a slot's key field holds)
+    oc = oracle.Counter(k, b)
+    oc.count(seq, qual, off)
+    g = gpu_lib.GpuCounter(k, b, max_batch_pos=(len(seq) + rs.n_reads) // 3 + 4096)
+    per = (rs.n_reads + 2) // 3
+    for i in range(0, rs.n_reads, per):
+        j = min(rs.n_reads, i + per)
+        o = off[i:j + 1] - off[i]
+        g.count_host(gpu_lib.to_stream(seq[int(off[i]):int(off[j])], o), gpu_lib.to_stream(qual[int(off[i]):int(off[j])], o))
+    st, ost = g.stats(), oc.stats()
+    ti = g.table_info()
+    assert ti["segments"] and ti["seg_shift"] > 14, ti
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert st["n_keys"] == len(osl) > 14 * 32 * 1024   # (more than 2^14 slots' worth of keys per region)
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.close(); oc.close()

@@ -83,7 +83,9 @@ def _check(gpu_lib, prm, seq, qual, off, cuts, kw, planes=False):
         sizes, slots = g.export_table().export_sorted()
         osz, osl = oc.export()
         assert np.array_equal(sizes, osz) and np.array_equal(slots, osl), tag
+    info = g.table_info() if not prm["fm"] else None
     g.close(); oc.close()
+    return info
 
 
 @pytest.mark.parametrize("seed", range(120))
@@ -104,6 +106,49 @@ def test_bit_planes_oversized_batches_are_cut(gpu_lib, seed):
     prm, seq, qual, off, cuts, kw = _draw(52000 + seed, scale=6, b_range=(14, 18))
     kw.pop("region_shift", None)
     _check(gpu_lib, prm, seq, qual, off, [0, len(off) - 1], kw, planes=True)
+
+
+@pytest.mark.parametrize("blk", ["3", "5", "7"])
+@pytest.mark.parametrize("seed", range(30))
+def test_random_configuration_segments_of_several_blocks(gpu_lib, seed, blk, monkeypatch):
+    """table segments beyond what a CU's LDS holds are several BLOCKS, one workgroup each (KParams.seg_blk): with BFCG_SEG_BLOCK = 3 / 5 / 7 a block
+    is 8 / 32 / 128 slots instead of 2^14, so these small draws grow their segments across the block boundary several times (rehash block by
+    block, commits that take only their block's entries of a region's pages, parked k-mers replayed into their block, export) -- in every
+    commit path (counter pairs, compare-and-swap, in place), with hand-over windows and without"""
+    monkeypatch.setenv("BFCG_SEG_BLOCK", blk)
+    prm, seq, qual, off, cuts, kw = _draw(61000 + seed, scale=2, b_range=(10, 20))
+    kw.pop("table_layout", None)
+    prm["fm"] = 0
+    info = _check(gpu_lib, prm, seq, qual, off, cuts, kw)
+    _BLOCK_RUNS.append((seed, blk, info))  # (the export converted the segments: what the family exercised is checked once, below)
+
+
+_BLOCK_RUNS = []
+
+
+def test_segments_of_several_blocks_were_exercised(gpu_lib, monkeypatch):
+    """one fixed draw of the family above, looked at BEFORE its export: region-owned segments, grown past the block size"""
+    monkeypatch.setenv("BFCG_SEG_BLOCK", "4")
+    rng = np.random.default_rng(5)
+    n, L, G = 3000, 100, 40000
+    genome = rng.integers(0, 4, G + L)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    seq = np.concatenate([acgt[genome[p:p + L]] for p in rng.integers(0, G, n)]).astype(np.uint8)
+    qual = rng.integers(33, 75, len(seq)).astype(np.uint8)
+    g = gpu_lib.GpuCounter(21, 16, max_batch_pos=len(seq) + n + 64)   # 2^16 bits: one region; 2k - 0 = 42 identity bits
+    for a in range(0, n, 500):
+        o = off[a:a + 501] - off[a]
+        g.count_host(gpu_lib.to_stream(seq[int(off[a]):int(off[a + 500])], o), gpu_lib.to_stream(qual[int(off[a]):int(off[a + 500])], o))
+    g.sync()
+    ti = g.table_info()
+    assert ti["segments"] and ti["seg_shift"] >= 12 and ti["seg_growths"] >= 3, ti   # blocks of 2^4 slots: 2^8 blocks and more per region
+    oc = oracle.Counter(21, 16)
+    oc.count(seq, qual, off)
+    sizes, slots = g.export_table().export_sorted()
+    osz, osl = oc.export()
+    assert np.array_equal(sizes, osz) and np.array_equal(slots, osl)
+    g.close(); oc.close()
 
 
 @pytest.mark.parametrize("seed", range(16))
