@@ -343,7 +343,10 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		if (prm->tab_cshift <= 0) while (((uint64_t)nfine << sh) < prm->max_batch_pos / 4 && sh < BFCG_SEG_MAX_SHIFT) ++sh;
 		if (sh > BFCG_SEG_MAX_SHIFT) sh = BFCG_SEG_MAX_SHIFT;
 		c->seg_init_shift = sh;
-		{ const char *e = getenv("BFCG_SEG_BLOCK"); c->seg_blk_max = e && atoi(e) >= 3 && atoi(e) <= BFCG_SEG_MAX_SHIFT ? atoi(e) : BFCG_SEG_MAX_SHIFT; }
+		// A block of 2^12 slots, not the 2^14 a CU's LDS could hold: blocks up to 2^12 take the counter-pair path at three workgroups of 512 threads per
+		// CU -- c4's 2^13-slot segments as two such blocks instead of one of 64 KiB (1024 threads, compare-and-swap): commits 328 -> 273 ms at 12x
+		// coverage (2^11: 317; every block's workgroup reads all the region's entries), same table
+		{ const char *e = getenv("BFCG_SEG_BLOCK"); c->seg_blk_max = e && atoi(e) >= 3 && atoi(e) <= BFCG_SEG_MAX_SHIFT ? atoi(e) : 12; }
 		{ const char *e = getenv("BFCG_SEG_TOTAL"); c->seg_total_max = e && atoi(e) >= c->seg_blk_max && atoi(e) <= BFCG_SEG_TOTAL_MAX ? atoi(e) : BFCG_SEG_TOTAL_MAX; }
 		P.seg = 1; set_seg_shift(P, sh, c->seg_blk_max); c->seg_cap_shift = sh;
 		HIPCKN(set_seg_lds_attr());

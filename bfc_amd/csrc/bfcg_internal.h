@@ -43,8 +43,8 @@ struct KParams {
 	int bloom_bt;               // threads per workgroup of the bloom kernel: 512 (three workgroups per CU), 1024 when the LDS footprint allows one only
 	int seg;                    // 1: the count table is kept as region-owned segments (seg_tab) and updated through LDS by k_commit_seg
 	int seg_shift;              // log2 slots per region's table segment
-	int seg_blk;                // a segment is 2^(seg_shift - seg_blk) BLOCKS of 2^seg_blk slots (seg_blk = min(seg_shift, 14): a block fits a CU's LDS); a key lives in
-	                            // block (seg_home(id) >> seg_blk) & (blocks - 1), probing stays inside it: up to 2^14 slots a segment is one block
+	int seg_blk;                // a segment is 2^(seg_shift - seg_blk) BLOCKS of 2^seg_blk slots (seg_blk = min(seg_shift, 12): a block fits a third of a CU's LDS with its counter pairs); a key lives in
+	                            // block (seg_home(id) >> seg_blk) & (blocks - 1), probing stays inside it: up to 2^12 slots a segment is one block
 	int seg_lo, seg_hi;         // bits [seg_lo, seg_hi) of y0 are implied by the region (kmer_dev.h: SegGeom)
 	uint32_t f_base;            // global id of this rank's first bloom region
 	int no_kstats;              // stage A does not count k-mers / high-quality k-mers (a batch that is replayed was counted the first time)

@@ -352,7 +352,7 @@ def test_segments_larger_than_lds_stay_region_owned(gpu_lib):
         g.count_host(gpu_lib.to_stream(seq[int(off[i]):int(off[j])], o), gpu_lib.to_stream(qual[int(off[i]):int(off[j])], o))
     st, ost = g.stats(), oc.stats()
     ti = g.table_info()
-    assert ti["segments"] and ti["seg_shift"] > 14, ti
+    assert ti["segments"] and ti["seg_shift"] > 14, ti   # (eight blocks of 2^12 slots and more per region)
     assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
     assert np.array_equal(g.bloom_bytes(), oc.bloom_bytes())
     sizes, slots = g.export_table().export_sorted()
