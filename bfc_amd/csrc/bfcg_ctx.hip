@@ -348,6 +348,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		// coverage (2^11: 317; every block's workgroup reads all the region's entries), same table
 		{ const char *e = getenv("BFCG_SEG_BLOCK"); c->seg_blk_max = e && atoi(e) >= 3 && atoi(e) <= BFCG_SEG_MAX_SHIFT ? atoi(e) : 12; }
 		{ const char *e = getenv("BFCG_SEG_TOTAL"); c->seg_total_max = e && atoi(e) >= c->seg_blk_max && atoi(e) <= BFCG_SEG_TOTAL_MAX ? atoi(e) : BFCG_SEG_TOTAL_MAX; }
+		if (c->seg_total_max > c->seg_blk_max + 15) c->seg_total_max = c->seg_blk_max + 15; // (the blocks are a grid's second dimension: at most 65 535)
 		P.seg = 1; set_seg_shift(P, sh, c->seg_blk_max); c->seg_cap_shift = sh;
 		HIPCKN(set_seg_lds_attr());
 		HIPCKN(hipMalloc(&B.seg_tab, ((uint64_t)nfine << sh) * 8));

@@ -1733,7 +1733,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	// its own (every block's workgroup reads all of them: 8 bytes per entry against the 128 KiB of the block).  Before, such a table left
 	// the region-owned layout for the host's and random device-scope CAS (218 B of HBM traffic per upsert).
 	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk), blk_mask = (1u << ub) - 1u;
-	const uint32_t f = blockIdx.x >> ub, blk = blockIdx.x & blk_mask;
+	const uint32_t f = blockIdx.x, blk = blockIdx.y; // (a grid of regions x blocks: HIP bounds a dimension's THREADS by 2^32)
 	const bool log = A.ho_stride != 0;
 	const uint32_t pages = log ? (A.ho_pages < 8u ? A.ho_pages : 8u) : 1u;
 	uint32_t n;
@@ -1881,7 +1881,7 @@ __global__ __launch_bounds__(BT) void k_seg_rehash(KParams P, const unsigned lon
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
 	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk), blk_mask = (1u << ub) - 1u, ub_old = (uint32_t)(old_shift - old_blk);
-	const uint32_t f = blockIdx.x >> ub, blk = blockIdx.x & blk_mask;
+	const uint32_t f = blockIdx.x, blk = blockIdx.y;
 	const uint32_t slots = 1u << P.seg_blk, mask = slots - 1, old_slots = 1u << old_blk;
 	const unsigned long long *src = old_tab + ((uint64_t)f << old_shift) + ((uint64_t)(blk & ((1u << ub_old) - 1u)) << old_blk);
 	for (uint32_t i = threadIdx.x; i < slots; i += BT) lseg[i] = 0;
@@ -2264,10 +2264,10 @@ bool bloom3_geometry_ok(const KParams &P) { return bfcg_rec_dwords(P.k, P.rec_n)
 
 static void launch_commit_seg(const KParams &P, const BloomArgs &A, int nfine, hipStream_t st)
 {
-	const unsigned grid = (unsigned)nfine << (P.seg_shift - P.seg_blk); // one workgroup per (region, block of its segment)
-	if (P.seg_blk >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), dim3(grid), dim3(1024), (size_t)8 << P.seg_blk, st, P, A);
-	else if (P.seg_blk == 12) hipLaunchKernelGGL((k_commit_seg<512>), dim3(grid), dim3(512), (size_t)12 << P.seg_blk, st, P, A); // (+ 4 bytes of counters per slot)
-	else hipLaunchKernelGGL((k_commit_seg<256>), dim3(grid), dim3(256), (size_t)12 << P.seg_blk, st, P, A);
+	const dim3 grid((unsigned)nfine, 1u << (P.seg_shift - P.seg_blk)); // one workgroup per (region, block of its segment)
+	if (P.seg_blk >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), grid, dim3(1024), (size_t)8 << P.seg_blk, st, P, A);
+	else if (P.seg_blk == 12) hipLaunchKernelGGL((k_commit_seg<512>), grid, dim3(512), (size_t)12 << P.seg_blk, st, P, A); // (+ 4 bytes of counters per slot)
+	else hipLaunchKernelGGL((k_commit_seg<256>), grid, dim3(256), (size_t)12 << P.seg_blk, st, P, A);
 	dbg_sync(st, "k_commit_seg");
 }
 void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st)
@@ -2489,7 +2489,7 @@ void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t 
 hipError_t set_seg_lds_attr(void) { return hipFuncSetAttribute((const void *)k_seg_rehash<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); }
 void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, int old_blk, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st)
 {
-	hipLaunchKernelGGL((k_seg_rehash<512>), dim3(n_fine << (P.seg_shift - P.seg_blk)), dim3(512), (size_t)8 << P.seg_blk, st, P, old_tab, old_shift, old_blk, new_tab);
+	hipLaunchKernelGGL((k_seg_rehash<512>), dim3(n_fine, 1u << (P.seg_shift - P.seg_blk)), dim3(512), (size_t)8 << P.seg_blk, st, P, old_tab, old_shift, old_blk, new_tab);
 }
 void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
 {
