@@ -62,6 +62,7 @@ SYMBOLS = {
     "bfcg_destroy": (None, [C.c_void_p]),
     "bfcg_last_error": (C.c_char_p, []),
     "bfcg_build_id": (C.c_char_p, []),
+    "bfcg_device_count": (C.c_int, []),
     "bfcg_reset": (C.c_int, [C.c_void_p]),
     "bfcg_count_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfcg_count_batch_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),

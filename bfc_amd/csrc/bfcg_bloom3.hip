@@ -54,7 +54,20 @@ __device__ __forceinline__ uint32_t b3_bit(uint32_t w, uint32_t b) { return __bu
 // region's records and filter slice requested into registers under the list passes -- the registers that must live through the passes spill
 // (86 - 225 VGPRs to scratch at the 80 the occupancy allows) and c3's bloom stage went 66 -> 120 - 125 ms; touching the cache lines of the region
 // a later workgroup of the same XCD will take, so that its loads hit in L2: 66.4 -> 70.1 ms.)
-template <int BT, int PF>
+//
+// COLD (round 5): a batch into a filter that is still filling up.  There nearly every k-mer brings clear bits and half of them are copies of an
+// earlier k-mer of the same batch (c3's first call holds every genome k-mer twice): the first-setter protocol -- returning ORs, an entry per
+// contended bit, competitors, look-ups, all by divergent probe loops on LDS compare-and-swaps -- took 28 ps per k-mer for the launch into the
+// empty filter and 13 for the next against 6.7 once the filter is warm (profiles/round4_k_bloom.md, section 3).  A k-mer touches ONE 64-byte
+// block (bbf.c:27-31), so the reference's order only matters inside a block, and a region has 2^R of them with a handful of listed k-mers each:
+// the list is ordered by (block, file index) -- one LDS counter per block, a scan of 2^R counters, a scatter, ranks by comparing a block's few
+// indices -- and ONE LANE PER BLOCK walks its k-mers in file order doing literally what bfc_bf_insert does (bbf.c:33-44): test the four bits,
+// seen iff all are set, set them.  The lane owns the block: plain LDS reads, fire-and-forget ORs, no table, no probing, no retries, and the
+// result is the sequential one by construction.  A list entry is 12 bytes (file index, packed address + clear mask, record index, position in
+// block order); with no first-setter table beside it the list holds 2 879 entries where the protocol's held 2 021.
+#define B3_SEEN 0x40000000u /* COLD: list word: the walk found every bit of this k-mer set */
+#define B3_COLD_NR 8       /* COLD: list positions per thread in the rank pass (8 x 512 = 4096 >= the cold list's capacity) */
+template <int BT, int PF, bool COLD>
 __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -79,10 +92,15 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 	const uint32_t region_dw = 16u << P.R;
 	unsigned char *sp = smem;
 	unsigned int *region = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
-	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.fs_cap * 4;
+	const uint32_t nblk = 1u << P.R;
+	// COLD: per block of the region its listed k-mers' count, then (boff) its first position in block order / (bfill) the scatter's cursor
+	unsigned int *bcnt = reinterpret_cast<unsigned int *>(sp), *boff = bcnt + nblk; // boff has nblk + 1 entries
+	if (COLD) sp += (size_t)(2 * nblk + 4) * 4;
+	unsigned int *fs = reinterpret_cast<unsigned int *>(sp); if (!COLD) sp += (size_t)P.fs_cap * 4;
 	unsigned int *la = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4;   // file-order index
 	unsigned int *lb = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4;   // block | h1 << 8 | h2 << 17 | clear-bit mask << 26 (| B3_UND)
-	unsigned short *lc = reinterpret_cast<unsigned short *>(sp);                              // record index inside the region's slab
+	unsigned short *lc = reinterpret_cast<unsigned short *>(sp); sp += (size_t)P.list_cap * 2; // record index inside the region's slab
+	unsigned short *ord = reinterpret_cast<unsigned short *>(sp);                            // COLD: the list's entries in (block, file index) order
 	const uint32_t fs_mask = P.fs_cap - 1;
 	const uint32_t *recs = A.recs + (uint64_t)rs * 3;
 	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
@@ -124,8 +142,11 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 		const uint4 *src = reinterpret_cast<const uint4 *>(g_region);
 		uint4 *dst = reinterpret_cast<uint4 *>(region);
 		for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
-		uint4 *f4 = reinterpret_cast<uint4 *>(fs);
-		for (uint32_t i = tid; i < P.fs_cap / 4; i += BT) f4[i] = make_uint4(FS32_EMPTY, FS32_EMPTY, FS32_EMPTY, FS32_EMPTY);
+		if constexpr (COLD) { for (uint32_t i = tid; i < 2 * nblk + 4; i += BT) bcnt[i] = 0; }
+		else {
+			uint4 *f4 = reinterpret_cast<uint4 *>(fs);
+			for (uint32_t i = tid; i < P.fs_cap / 4; i += BT) f4[i] = make_uint4(FS32_EMPTY, FS32_EMPTY, FS32_EMPTY, FS32_EMPTY);
+		}
 		if (tid == 0) { s_list_n = 0; s_emit_n = 0; s_ovf = 0; s_fs_used = 0; s_wb_n = 0; }
 	}
 	__syncthreads();
@@ -169,7 +190,10 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 				if (A.seen_out) A.seen_out[cur[u].d[2]] = 2;
 			} else if (act) {
 				const uint32_t li = o_l + below_l;
-				if (li < P.list_cap) { la[li] = cur[u].d[2]; lb[li] = pk[u] | (um[u] << 26); lc[li] = (unsigned short)(base + tid + u * BT); }
+				if (li < P.list_cap) {
+					la[li] = cur[u].d[2]; lb[li] = pk[u] | (um[u] << 26); lc[li] = (unsigned short)(base + tid + u * BT);
+					if constexpr (COLD) __hip_atomic_fetch_add(&bcnt[pk[u] & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
 			}
 			o_s += (uint32_t)__popcll(ms[u]); o_l += (uint32_t)__popcll(ml[u]);
 		}
@@ -187,8 +211,90 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 	if (timing) tq[2] = clock64();
 #endif
 	const uint32_t ln = s_list_n;
-	const bool ovf_list = ln > P.list_cap || ln > 8191 || n > 65535u; // (13-bit list index in a first-setter entry, 16-bit record index in the list)
+	const bool ovf_list = ln > P.list_cap || ln > (COLD ? (uint32_t)(B3_COLD_NR * BT) : 8191u) || n > 65535u; // (13-bit list index in a first-setter entry, 16-bit record index in the list; COLD: 16 positions per thread in the rank pass)
 	bool dirty = true;
+	if constexpr (COLD) {
+		if (!ovf_list) {
+			// ---- block offsets: exclusive scan of the 2^R counters by the first wave (2^R <= 256: four blocks per lane)
+			if (tid < 64) {
+				const uint32_t per = (nblk + 63u) >> 6, b0 = (uint32_t)tid * per;
+				uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) if ((uint32_t)t < per && b0 + t < nblk) { v[t] = bcnt[b0 + t]; sum += v[t]; }
+				uint32_t inc = sum;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+				uint32_t run = inc - sum;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) if ((uint32_t)t < per && b0 + t < nblk) { boff[b0 + t] = run; bcnt[b0 + t] = run; run += v[t]; } // (bcnt becomes the scatter's cursor)
+				if (tid == 63) boff[nblk] = inc;
+			}
+			__syncthreads();
+			// ---- scatter: the list's entries grouped by block (any order inside a block)
+			for (uint32_t li = tid; li < ln; li += BT) ord[atomicAdd(&bcnt[lb[li] & 255u], 1u)] = (unsigned short)li;
+			__syncthreads();
+			// ---- ranks: an entry's place among its block's entries = how many of them come earlier in the file (a block holds a handful).  Every
+			// position is read before any is rewritten: the new places wait in registers across the barrier.
+			uint32_t mv[B3_COLD_NR]; // place << 16 | entry, per position this thread owns (B3_COLD_NR x BT >= the cold list's capacity)
+#pragma unroll
+			for (int t = 0; t < B3_COLD_NR; ++t) {
+				const uint32_t pos = (uint32_t)tid + (uint32_t)t * BT;
+				mv[t] = 0;
+				if (pos < ln) {
+					const uint32_t li = ord[pos], x = la[li], bl = lb[li] & 255u, s0 = boff[bl], s1 = boff[bl + 1];
+					uint32_t r = 0;
+					for (uint32_t j = s0; j < s1; ++j) r += (uint32_t)(la[ord[j]] < x);
+					mv[t] = ((s0 + r) << 16) | li;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int t = 0; t < B3_COLD_NR; ++t) { const uint32_t pos = (uint32_t)tid + (uint32_t)t * BT; if (pos < ln) ord[mv[t] >> 16] = (unsigned short)mv[t]; }
+			__syncthreads();
+			// ---- the walk: lane b takes block b's k-mers in file order -- bbf.c:33-44 as it stands: seen iff every bit is set, then set them
+			if ((uint32_t)tid < nblk) {
+				const uint32_t bl = (uint32_t)tid, bl64 = bl << 6, s0 = boff[bl], s1 = boff[bl + 1];
+				uint32_t li_n = s0 < s1 ? ord[s0] : 0u, w_n = s0 < s1 ? lb[li_n] : 0u;
+				for (uint32_t j = s0; j < s1; ++j) {
+					const uint32_t li = li_n, w = w_n;
+					if (j + 1 < s1) { li_n = ord[j + 1]; w_n = lb[li_n]; } // (the next entry is on its way while this one is decided)
+					const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
+					unsigned int *p0 = b3_wordp(region, bl64, b.b0), *p1 = b3_wordp(region, bl64, b.b1), *p2 = b3_wordp(region, bl64, b.b2), *p3 = b3_wordp(region, bl64, b.b3);
+					const uint32_t w0 = *p0, w1 = *p1, w2 = *p2, w3 = *p3;
+					const uint32_t clr = (b3_bit(w0, b.b0) | (b3_bit(w1, b.b1) << 1) | (b3_bit(w2, b.b2) << 2) | (b3_bit(w3, b.b3) << 3)) ^ 15u; // (bits set before the batch are still set)
+					if (clr == 0) lb[li] = w | B3_SEEN;
+					else { // (two positions may share a word: ORs, not stores; this lane's later reads follow them in order)
+						if (clr & 1u) __hip_atomic_fetch_or(p0, 1u << (b.b0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (clr & 2u) __hip_atomic_fetch_or(p1, 1u << (b.b1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (clr & 4u) __hip_atomic_fetch_or(p2, 1u << (b.b2 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (clr & 8u) __hip_atomic_fetch_or(p3, 1u << (b.b3 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+				}
+			}
+			__syncthreads();
+			// ---- emit the listed k-mers the walk found seen (record re-read by its index), behind what pass 1 emitted
+			for (uint32_t t0 = 0; t0 < ln; t0 += BT) {
+				const uint32_t li = t0 + tid;
+				bool seen = false;
+				if (li < ln) {
+					seen = (lb[li] & B3_SEEN) != 0;
+					if (A.seen_out) A.seen_out[la[li]] = seen ? 2 : 1;
+				}
+				const unsigned long long vote = __ballot(seen);
+				if (vote) {
+					uint32_t o = 0;
+					if (lane == 0) o = atomicAdd(&s_emit_n, (uint32_t)__popcll(vote));
+					o = __builtin_amdgcn_readfirstlane(o);
+					if (seen) {
+						const RecW<3> r = rec_load<3>(recs + (uint64_t)lc[li] * 3);
+						ho_base[o + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] = entry3(r.d[0], r.d[1]);
+					}
+				}
+			}
+			dirty = ln != 0;
+			__syncthreads();
+		}
+	} else
 	if (!ovf_list) {
 		// ---- pass A (dense over the list): set every clear bit; the returning OR tells whether another k-mer of this batch got there first
 		for (uint32_t li = tid; li < ln; li += BT) {
@@ -219,7 +325,8 @@ __global__ __launch_bounds__(BT, PF <= 2 ? 8 : 6) void k_bloom3(KParams P, Bloom
 	if (timing) tq[6] = clock64();
 #endif
 	const bool ovf = ovf_list || s_ovf; // (the same for every thread: nothing writes s_ovf behind this barrier)
-	if (!ovf) {
+	if (COLD && !ovf) ; // (decided and emitted above)
+	else if (!ovf) {
 		if (s_fs_used) {
 			// ---- pass B: every toucher of a bit that has an entry competes for it (this brings in the k-mer that set the bit first in EXECUTION
 			// order).  A clear bit without an entry is this k-mer's alone: it is a first setter and not seen -- nothing left to decide.
@@ -406,8 +513,9 @@ namespace bfcg {
 
 hipError_t set_bloom3_lds_attr(int lds)
 {
-	hipError_t e = hipFuncSetAttribute((const void *)k_bloom3<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_bloom3<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	hipError_t e = hipFuncSetAttribute((const void *)k_bloom3<512, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_bloom3<512, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_bloom3<512, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 	return e;
 }
 
@@ -417,8 +525,9 @@ void run_bloom3(const KParams &P, const BloomArgs &A, int nfine, size_t lds, hip
 {
 	static int pf = 0;
 	if (!pf) { const char *e = getenv("BFCG_B3_PF"); pf = e && atoi(e) == 2 ? 2 : e && atoi(e) == 4 ? 4 : 1; } // (1: by the batch)
-	if (pf == 2 || (pf == 1 && P.b3_warm)) hipLaunchKernelGGL((k_bloom3<512, 2>), dim3(nfine), dim3(512), lds, st, P, A);
-	else hipLaunchKernelGGL((k_bloom3<512, 4>), dim3(nfine), dim3(512), lds, st, P, A);
+	if (P.b3_cold) hipLaunchKernelGGL((k_bloom3<512, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
+	else if (pf == 2 || (pf == 1 && P.b3_warm)) hipLaunchKernelGGL((k_bloom3<512, 2, false>), dim3(nfine), dim3(512), lds, st, P, A);
+	else hipLaunchKernelGGL((k_bloom3<512, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
 }
 
 } // namespace bfcg

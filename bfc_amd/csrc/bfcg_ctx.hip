@@ -21,7 +21,7 @@
 using namespace bfcg;
 
 static thread_local char g_err[512] = "";
-enum { HO_MAX_PAGES = 8 };
+enum { HO_MAX_PAGES = BFCG_HO_MAX_PAGES };
 enum { OP_FLAG_WORDS = 12, OP_STICKY = 8 }; // bfcg_ctx.op_flags: two slots of four words, the sticky poison word
 static double dbg_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static inline void set_seg_shift(KParams &P, int s, int blk_max) { P.seg_shift = s; P.seg_blk = s < blk_max ? s : blk_max; }
@@ -78,6 +78,7 @@ struct bfcg_ctx {
 	int seg_blk_max;             // slots of a segment's block (log2): 14 = what a CU's LDS holds; BFCG_SEG_BLOCK lowers it so that small tests run segments of several blocks
 	int b3_ok;                   // ... and the bloom insert of batches without `dedupe` runs k_bloom3 (KParams.b3)
 	uint32_t fs_cap_w, list_cap_w; // k_bloom3's LDS tables for batches into a WARM filter (0: none): a footprint of a quarter of a CU's LDS
+	uint32_t list_cap_c;         // k_bloom3<.., COLD>'s list for batches into a filter that is still filling up (0: none): 12-byte entries, no first-setter table
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
 	uint64_t n_seg_grow;         // segment growths since creation
@@ -110,6 +111,13 @@ struct bfcg_ctx {
 
 extern "C" const char *bfcg_last_error(void) { return g_err; }
 extern "C" void bfcg_set_error(const char *msg) { set_err("%s", msg); } // bfcg_mg.hip reports through the same channel
+
+extern "C" int bfcg_device_count(void)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return ndev;
+}
 
 extern "C" void bfcg_params_default(bfcg_params_t *p)
 {
@@ -234,6 +242,17 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 				uint32_t l = (size_t)fw * 4 < lw ? (uint32_t)((lw - (size_t)fw * 4) / rwb) : 0;
 				if (l > P.list_cap) l = P.list_cap;
 				if (l >= P.list_cap / 4 * 3 && fw >= 1024) { c->fs_cap_w = fw; c->list_cap_w = l; }
+			}
+		}
+		// Into a filter that is still filling up (round 5): k_bloom3<.., COLD> orders the list by (block, file index) and walks the blocks; its entries
+		// are 12 bytes and need no first-setter table beside them -- the same third of a CU's LDS holds 2 879 of them instead of 2 021
+		c->list_cap_c = 0;
+		if (P.b3 && !(getenv("BFCG_B3_COLD") && atoi(getenv("BFCG_B3_COLD")) == 0)) {
+			const size_t fixed = region + ((size_t)2 << P.R) * 4 + 16 + 16;
+			if (budget > fixed + 12 * 256) {
+				uint32_t l = (uint32_t)((budget - fixed) / 12);
+				if (l > 4096) l = 4096; // (B3_COLD_NR x 512 positions in the rank pass)
+				c->list_cap_c = l;
 			}
 		}
 		{ // the class table of cold batches lies over the first-setter table and the lists
@@ -446,8 +465,9 @@ static int handover_end(bfcg_ctx_t *c, const BatchBufs &Bt, int b);
 // k_bloom3 with the short list and four workgroups per CU for a batch into a warm filter (see bfcg_create)
 static void warm_tables(const bfcg_ctx_t *c, KParams &Pt)
 {
-	Pt.b3_warm = 0;
-	if (Pt.b3 && !Pt.dedupe && !c->cold && c->list_cap_w) { Pt.fs_cap = c->fs_cap_w; Pt.list_cap = c->list_cap_w; Pt.b3_warm = 1; }
+	Pt.b3_warm = 0; Pt.b3_cold = 0;
+	if (Pt.b3 && c->cold && c->list_cap_c) { Pt.list_cap = c->list_cap_c; Pt.b3_cold = 1; Pt.dedupe = 0; } // (the walk resolves copies by itself)
+	else if (Pt.b3 && !Pt.dedupe && !c->cold && c->list_cap_w) { Pt.fs_cap = c->fs_cap_w; Pt.list_cap = c->list_cap_w; Pt.b3_warm = 1; }
 }
 static int dedupe_hint(const bfcg_ctx_t *c) { return (c->n_batches == 0 || (c->cold && c->seen_per_pos < 0.15)) && !getenv("BFCG_NO_DEDUPE"); }
 
@@ -1218,7 +1238,9 @@ static uint64_t split_limit(const bfcg_ctx_t *c)
 	// more than sqrt(mean) -- its few dozen distinct genome k-mers come at coverage/4 copies each -- so the cut sits below list_cap on average:
 	// c2 at 1 048 576 reads per batch ran at 12.2 instead of 25 G k-mers/s with the cut at 1.15 (5 % of the regions on the slow path).
 	// Callers split from 7/6 of this on: just above the limit a few hundred slow regions cost less (5 %) than a second pass over the filter (12 %).
-	return (uint64_t)((double)nfine * (double)c->P.list_cap * 0.95);
+	// (into a filter that is still filling up k_bloom3's COLD mode holds a longer list)
+	const uint32_t cap = c->P.b3 && c->cold && c->list_cap_c ? c->list_cap_c : c->P.list_cap;
+	return (uint64_t)((double)nfine * (double)cap * 0.95);
 }
 static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
 // last cut point in (lo, hi]: index just behind a non-ACGT byte, searched backwards from hi over at most 1 MiB; 0 = none

@@ -11,6 +11,7 @@ static inline int bfcg_tile_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
 /* positions per tile of stage A (k_hist1 / k_scatter1: bfcg_kernels.hip, S1<RW>) */
 static inline int bfcg_tile1_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
 #define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */
+#define BFCG_HO_MAX_PAGES 8 /* batches whose seen k-mers may wait in a region's hand-over log for ONE commit pass (k_commit_seg's page arrays, the context's marks) */
 /* The measurement switches (KParams.ablate = BFCG_ABLATE: skip the stores / the cursor atomics / the hashing of k_scatter1, phase clocks in
    k_bloom, ...) exist only in a library built with -DBFCG_MEASURE (`python -m bfc_amd.build --measure` -> build/libbfc_gpu_measure.so, loaded
    through BFC_GPU_LIB by the scripts that need them).  In the shipped library BFCG_ABL() is the constant 0: the kernels carry neither the
@@ -53,6 +54,8 @@ struct KParams {
 	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
 	int b3;                     // the default path's bloom insert runs k_bloom3: a list entry in LDS is 10 bytes (bloom_lds_bytes), and batches without `dedupe` take that kernel
 	int b3_warm;                // this batch goes into a warm filter: fs_cap / list_cap are the SHORT list's (four workgroups of k_bloom3 per CU instead of three)
+	int b3_cold;                // this batch goes into a filter that is still filling up: k_bloom3<.., COLD> -- the list ordered by (block, file index), one lane walks a
+	                            // block's k-mers as bfc_bf_insert would; list_cap is the cold list's (12-byte entries, no first-setter table beside them)
 };
 
 struct BatchBufs {

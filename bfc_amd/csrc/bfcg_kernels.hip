@@ -1726,16 +1726,23 @@ template <int BT>
 __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
-	__shared__ uint32_t s_new[8], s_mark[8]; // (HO_MAX_PAGES, bfcg_ctx.hip)
+	__shared__ uint32_t s_new[BFCG_HO_MAX_PAGES], s_mark[BFCG_HO_MAX_PAGES];
 	// Round 4: a segment of more than 2^14 slots (a genome that is large for its filter: 10 000 keys per region and more) is 2^ub BLOCKS of
 	// 2^14 slots, one workgroup per (region, block): a key lives in block (seg_home >> seg_blk) & (blocks - 1) and is probed inside it, so a
 	// block is what a segment was -- staged in LDS, applied, stored -- and its workgroup takes those entries of the region's pages that are
 	// its own (every block's workgroup reads all of them: 8 bytes per entry against the 128 KiB of the block).  Before, such a table left
 	// the region-owned layout for the host's and random device-scope CAS (218 B of HBM traffic per upsert).
 	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk), blk_mask = (1u << ub) - 1u;
-	const uint32_t f = blockIdx.x, blk = blockIdx.y; // (a grid of regions x blocks: HIP bounds a dimension's THREADS by 2^32)
+	// (region, block) of this workgroup.  One-dimensional launch `f * blocks + blk` wherever it fits (HIP bounds a dimension's THREADS by 2^32): a
+	// region's blocks are then dispatched back to back and the second finds the region's log entries in L2 (c4: two blocks per region; with the
+	// two-dimensional grid of round 4's end -- blockIdx.y = block -- they ran a whole sweep apart and the commits cost 1.28 instead of 1.09 s)
+	const uint32_t f = gridDim.y == 1 ? blockIdx.x >> ub : blockIdx.x, blk = gridDim.y == 1 ? blockIdx.x & blk_mask : blockIdx.y;
 	const bool log = A.ho_stride != 0;
-	const uint32_t pages = log ? (A.ho_pages < 8u ? A.ho_pages : 8u) : 1u;
+	if (log && A.ho_pages > (uint32_t)BFCG_HO_MAX_PAGES) { // (the host never asks for more: a bug if it ever does -- loudly, not by dropping pages)
+		if (threadIdx.x == 0) atomicAdd(&A.stats[(size_t)(f & (ST_SLOTS - 1)) * ST_N + ST_ERR_POOL], 1ULL);
+		return;
+	}
+	const uint32_t pages = log ? A.ho_pages : 1u;
 	uint32_t n;
 	const unsigned long long *recs;
 	if (log) { n = A.ho_mark[(size_t)(pages - 1) * A.ho_mark_stride + f]; recs = A.ho + (uint64_t)f * A.ho_stride; }
@@ -1756,7 +1763,7 @@ __global__ __launch_bounds__(BT) void k_commit_seg(KParams P, BloomArgs A)
 	// load per page in front of its barrier) and a thread's first two entries -- and a page costs one barrier, not two (a counter of new keys
 	// per page instead of one that is cleared in between).  With 64 KiB segments (config c4: 1024 threads, ~1.2 entries per thread and page)
 	// a page was two exposed memory latencies and two barriers for a microsecond of upserts: 22 ms per batch beside 23 ms for the stream.
-	if (threadIdx.x < 8) {
+	if (threadIdx.x < BFCG_HO_MAX_PAGES) {
 		s_new[threadIdx.x] = 0;
 		s_mark[threadIdx.x] = threadIdx.x < pages ? (log ? A.ho_mark[(size_t)threadIdx.x * A.ho_mark_stride + f] : n) : n;
 	}
@@ -1881,7 +1888,7 @@ __global__ __launch_bounds__(BT) void k_seg_rehash(KParams P, const unsigned lon
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lseg[];
 	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk), blk_mask = (1u << ub) - 1u, ub_old = (uint32_t)(old_shift - old_blk);
-	const uint32_t f = blockIdx.x, blk = blockIdx.y;
+	const uint32_t f = gridDim.y == 1 ? blockIdx.x >> ub : blockIdx.x, blk = gridDim.y == 1 ? blockIdx.x & blk_mask : blockIdx.y; // (as k_commit_seg)
 	const uint32_t slots = 1u << P.seg_blk, mask = slots - 1, old_slots = 1u << old_blk;
 	const unsigned long long *src = old_tab + ((uint64_t)f << old_shift) + ((uint64_t)(blk & ((1u << ub_old) - 1u)) << old_blk);
 	for (uint32_t i = threadIdx.x; i < slots; i += BT) lseg[i] = 0;
@@ -2262,9 +2269,19 @@ static inline bool bloom_fast3(const KParams &P)
 // threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
 bool bloom3_geometry_ok(const KParams &P) { return bfcg_rec_dwords(P.k, P.rec_n) == 3 && P.n_hashes == 4 && P.R <= 8 && bloom_fast3(P); }
 
+// one workgroup per (region, block of its segment): one-dimensional `f * blocks + blk` -- a region's blocks back to back -- unless that
+// exceeds HIP's 2^32 threads per grid dimension (tiny test blocks on large filters), then regions x blocks
+static dim3 seg_grid(const KParams &P, uint32_t n_fine, uint32_t bt)
+{
+	const uint32_t ub = (uint32_t)(P.seg_shift - P.seg_blk);
+	const uint64_t wgs = (uint64_t)n_fine << ub;
+	static const bool force2d = getenv("BFCG_SEG_GRID2D") != nullptr; // (A/B only)
+	if (wgs * bt < (1ULL << 32) && !force2d) return dim3((unsigned)wgs, 1u);
+	return dim3(n_fine, 1u << ub);
+}
 static void launch_commit_seg(const KParams &P, const BloomArgs &A, int nfine, hipStream_t st)
 {
-	const dim3 grid((unsigned)nfine, 1u << (P.seg_shift - P.seg_blk)); // one workgroup per (region, block of its segment)
+	const dim3 grid = seg_grid(P, (uint32_t)nfine, P.seg_blk >= 13 ? 1024u : P.seg_blk == 12 ? 512u : 256u); // one workgroup per (region, block of its segment)
 	if (P.seg_blk >= 13) hipLaunchKernelGGL((k_commit_seg<1024>), grid, dim3(1024), (size_t)8 << P.seg_blk, st, P, A);
 	else if (P.seg_blk == 12) hipLaunchKernelGGL((k_commit_seg<512>), grid, dim3(512), (size_t)12 << P.seg_blk, st, P, A); // (+ 4 bytes of counters per slot)
 	else hipLaunchKernelGGL((k_commit_seg<256>), grid, dim3(256), (size_t)12 << P.seg_blk, st, P, A);
@@ -2328,7 +2345,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		A.ho = B.ho; A.ho_stride = B.ho_stride; A.ho_cur = B.ho_cur; A.ho_mark = B.ho_stride ? B.ho_mark + (size_t)B.ho_page * B.ho_mark_stride : nullptr;
 		bool f3 = false;
 		if constexpr (RW == 3) {
-			if (P.b3 && !P.dedupe) { f3 = true; run_bloom3(P, A, nfine, lds, st); } // (bfcg_bloom3.hip; cold batches with copies resolved by class stay with k_bloom)
+			if (P.b3 && (P.b3_cold || !P.dedupe)) { f3 = true; run_bloom3(P, A, nfine, lds, st); } // (bfcg_bloom3.hip; without its COLD mode, cold batches with copies resolved by class stay with k_bloom)
 			else if (P.n_hashes == 4 && bloom_fast3(P)) { f3 = true; hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>), dim3(nfine), dim3(512), lds, st, P, A); }
 		}
 		if (f3) ;
@@ -2400,6 +2417,7 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 int bloom_lds_bytes(const KParams &P)
 {
 	const size_t second = P.filter_mode ? ((size_t)64 << P.R) : P.seg ? 0 : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)); // second filter's slice or aggregation table
+	if (P.b3 && P.b3_cold) return (int)(((size_t)64 << P.R) + ((size_t)2 << P.R) * 4 + 16 + (size_t)P.list_cap * 12 + 16); // k_bloom3<.., COLD>: region, block counters + offsets, 12-byte entries
 	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + second + (size_t)P.list_cap * (P.b3 ? 10 : 8) + 16);
 }
 
@@ -2424,7 +2442,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	if constexpr (RW == 3) { e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; }
-	if constexpr (RW == 3) { e = set_bloom3_lds_attr(lds); if (e != hipSuccess) return e; }
+	if constexpr (RW == 3) { e = set_bloom3_lds_attr(lds > 53008 ? lds : 53008); if (e != hipSuccess) return e; } // (its COLD mode lays the same third of a CU's LDS out differently)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
@@ -2489,7 +2507,7 @@ void run_table_replay(const KParams &P, unsigned long long *tab, const uint64_t 
 hipError_t set_seg_lds_attr(void) { return hipFuncSetAttribute((const void *)k_seg_rehash<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); }
 void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old_shift, int old_blk, unsigned long long *new_tab, uint32_t n_fine, hipStream_t st)
 {
-	hipLaunchKernelGGL((k_seg_rehash<512>), dim3(n_fine, 1u << (P.seg_shift - P.seg_blk)), dim3(512), (size_t)8 << P.seg_blk, st, P, old_tab, old_shift, old_blk, new_tab);
+	hipLaunchKernelGGL((k_seg_rehash<512>), seg_grid(P, n_fine, 512u), dim3(512), (size_t)8 << P.seg_blk, st, P, old_tab, old_shift, old_blk, new_tab);
 }
 void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st)
 {

@@ -108,6 +108,9 @@ const char *bfcg_last_error(void);
 /* "src:<sha256/16 of the library's sources> git:<HEAD when it was built>": ties a travelling libbfc_gpu.so to the sources it claims
  * (bfc_amd/build.py::source_hash recomputes the first part from the tree; __graft_entry__.smoke() and bench.py compare). */
 const char *bfcg_build_id(void);
+/* HIP devices this process sees (0 if none, or if the runtime cannot start): callers that spread a run over several GPUs (bfc_count with
+ * BFC_GPU_DEVICES, bench.py --gpus N) check their device list against it and fail loudly rather than run on fewer */
+int bfcg_device_count(void);
 /* clear both bloom filters and the table */
 int bfcg_reset(bfcg_ctx_t *c);
 

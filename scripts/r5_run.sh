@@ -1,0 +1,46 @@
+# round 5: GPU evidence runs.  PARTS selects: quick (fuzz + parity + group tests), tests (whole GPU suite + smoke), bench (driver-style line),
+# ab (c3 bench with ENV_A / ENV_B settings), inproc (bench.py --gpus 2 with ranks emulated on device 0, c3), c4 / c5 (full size), prof (traces + PMC)
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
+export TMPDIR=/tmp
+PARTS=${PARTS:-"quick bench"}
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+summ() { python - "$1" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+if d.get("error"): print("ERROR", d["error"]); sys.exit()
+print(d['value'], d['ms_per_step'], d['config']['stage_ms_per_step'], 'verified', d.get('verified'), d['build_id'], 'frac', d['roofline']['frac'], d['roofline']['whole_job_frac'], 'n_gpus', d['n_gpus'], 'lib batches', d['config']['library_batches_per_step'])
+s = d.get('secondary', {})
+for k in s: print(k, s[k].get('value'), s[k].get('ms_per_step'), s[k].get('verified'), s[k].get('stage_ms_per_step'), s[k].get('error'))
+print('cpu', (d.get('cpu_baseline') or {}).get('value'), 'e2e', (d.get('e2e') or {}).get('mkmers_per_s'), (d.get('e2e') or {}).get('wall_s'), 'pcie', (d.get('pcie') or {}).get('mkmers_per_s'))
+if d.get('verified') is False: print(d.get('verification'))
+PY
+}
+if has quick; then
+  timeout 1500 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_group.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_quick.log; tail -6 gpurun_out/r5_quick.log
+fi
+if has tests; then
+  timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_gpu_tests.log; tail -8 gpurun_out/r5_gpu_tests.log
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+fi
+if has bench; then
+  timeout 1800 python bench.py --steps ${STEPS:-10} --warmup 3 ${BENCH_ARGS:-} > gpurun_out/r5_bench.json 2> gpurun_out/r5_bench.log; echo bench rc=$?
+  summ gpurun_out/r5_bench.json
+fi
+if has ab; then
+  for v in A B; do
+    eval "envs=\$ENV_$v"
+    env $envs timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary ${AB_ARGS:---no-secondary} > gpurun_out/r5_ab_$v.json 2> gpurun_out/r5_ab_$v.log; echo "ab $v ($envs) rc=$?"
+    summ gpurun_out/r5_ab_$v.json
+  done
+fi
+if has inproc; then
+  BFC_BENCH_DEVICES=0,0 timeout 1200 python bench.py --gpus 2 --steps ${STEPS:-3} --warmup 1 > gpurun_out/r5_bench_gpus2_emulated.json 2> gpurun_out/r5_bench_gpus2_emulated.log; echo inproc rc=$?
+  summ gpurun_out/r5_bench_gpus2_emulated.json
+  python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/r5_bench_gpus2_plain.json 2>/dev/null; echo "plain --gpus 2 rc=$?"; cat gpurun_out/r5_bench_gpus2_plain.json
+fi
+if has c4; then timeout 900 python scripts/c4_run.py --batch-reads 16777216 > gpurun_out/r5_c4_16m.log 2>&1; tail -2 gpurun_out/r5_c4_16m.log | cut -c1-700; fi
+if has c5; then timeout 900 python scripts/c4_run.py --batch-reads 8388608 --filter-mode 1 --k 51 --trim 1 > gpurun_out/r5_c5_8m.log 2>&1; tail -3 gpurun_out/r5_c5_8m.log | cut -c1-700; fi
+if has prof; then
+  PMC=2 STEPS=1 bash scripts/prof_round2.sh c3 > gpurun_out/prof_c3.out 2>&1; tail -3 gpurun_out/prof_c3.out | cut -c1-200
+  ROUND=5 python tools/make_round_md.py gpurun_out/prof_c3 c3 > gpurun_out/round5_c3.md; cp profiles/round5_c3_pmc.json gpurun_out/ 2>/dev/null
+fi

@@ -43,6 +43,9 @@ CASES = {
     # loaded as a whole GPU's share of the 8-GPU configuration would be; ~2.5 h of one core and ~35 GB here.  bench.py's secondary `c4e` and
     # tests/test_gpu_baseline_shapes.py hold the GPU path to it
     "c4e": dict(gen=dict(seed=4, G=387_500_000, cov=30.0), k=33, b=37, fm=0),
+    # an EIGHTH of c5 (round 5): the same 77.5 M reads at c5's parameters, `-s 3g -k51 -1` => -b37, two 16 GiB filters (count.c:67-68), 16-byte records;
+    # 7.7 G k-mers.  ~2 h of one core and ~40 GB here.  bench.py's secondary `c5e` and tests/test_gpu_baseline_shapes.py hold the GPU path to it
+    "c5e": dict(gen=dict(seed=4, G=387_500_000, cov=30.0), k=51, b=37, fm=1),
 }
 
 

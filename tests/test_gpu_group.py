@@ -302,3 +302,41 @@ def test_bench_through_the_group_path_is_verified(tmp_path):
     assert d["verified"] is True, d.get("verification")
     assert "RCCL" in d["config"]["parallelism"] and d["n_gpus"] == 1
     assert d["roofline"]["kernel"].startswith("bloom-insert path") and 0 < d["roofline"]["frac"] < 1
+
+
+def _bench_inproc(n, devices, workload, extra=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BFC_BENCH_FORCE_DIST"):
+        env.pop(k_, None)
+    if devices is not None:
+        env["BFC_BENCH_DEVICES"] = devices
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--workload", workload, "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-secondary", "--no-boundary"] + list(extra), capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
+    return r.returncode, json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_gpus_n_runs_n_ranks_in_process(n):
+    """`python bench.py --gpus N` exactly as the driver types it (no launcher): all N ranks in this process through bfcg_group_create(n_local = N),
+    one host thread per rank -- here emulated on device 0 (BFC_BENCH_DEVICES, which only this test sets: peer copies instead of RCCL, the same
+    bookkeeping) --, strong scaling on ONE read set, and the sums of what the ranks hold are the reference's answers for it ("verified")."""
+    rc, d, err = _bench_inproc(n, ",".join(["0"] * n), "c2")
+    assert rc == 0, err[-1500:]
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["verified"] is True, d.get("verification")
+    assert "owner computes" in d["config"]["parallelism"] and "NO bloom reduce" in d["config"]["parallelism"] and "peer copies" in d["config"]["parallelism"]
+    assert d["value"] > 0 and d["roofline"]["clock"].startswith("hip_events")
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly():
+    """the plain invocation (devices 0 and 1) on a box with ONE device: an "error" line and exit code 2, not a 1-GPU number"""
+    from bfc_amd import _lib
+    if _lib.load().bfcg_device_count() >= 2:
+        pytest.skip("this box has two devices: the plain invocation is a real 2-GPU run here")
+    rc, d, err = _bench_inproc(2, None, "c2")
+    assert rc == 2 and d["value"] is None and d["n_gpus"] == 2 and "not running on fewer GPUs" in d["error"]

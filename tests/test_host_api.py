@@ -52,6 +52,23 @@ def test_no_gpu_means_loud_failure_for_groups_too(gpu_lib):
     assert "LOUD" in r.stdout and "no CPU fallback" in (r.stdout + r.stderr)
 
 
+def test_bench_gpus_n_without_n_devices_fails_loudly(gpu_lib):
+    """`python bench.py --gpus 2` with no launcher runs both ranks in one process (bfcg_group_create, n_local = 2); on a box with fewer devices it
+    must say so in its ONE JSON line and exit non-zero -- never a silent 1-GPU run labelled n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    env.pop("WORLD_SIZE", None)
+    for n, word in ((2, "not running on fewer GPUs"), (3, "power of two")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["value"] is None and word in d["error"]
+
+
 def test_host_bloom_matches_oracle(gpu_lib):
     """bfc_bf_init/insert/get (bbf.c): same bits, same return values; bad shifts give NULL (bbf.c:9)."""
     L = oracle.lib()
