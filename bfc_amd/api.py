@@ -191,8 +191,9 @@ def bfc_count(fn, opt):
     return HostTable(p)
 
 
-def pack_planes(seq_stream, qual_stream, q, n_threads=1):
-    """The four bit planes of a byte-stream batch (bfcg_pack_planes; no GPU involved): uint32 array [4, bfcg_plane_words(n)]."""
+def pack_planes(seq_stream, qual_stream, q, n_chunks=1):
+    """The four bit planes of a byte-stream batch (bfcg_pack_planes; no GPU involved): uint32 array [4, bfcg_plane_words(n)].
+    n_chunks > 1 packs the stream as that many word ranges one after the other (what disjoint threads would each take: tests of the seams)."""
     L = _lib.load()
     seq_stream = np.ascontiguousarray(seq_stream, dtype=np.uint8)
     qs = np.ascontiguousarray(qual_stream, dtype=np.uint8) if qual_stream is not None else None
@@ -201,7 +202,7 @@ def pack_planes(seq_stream, qual_stream, q, n_threads=1):
     planes = np.zeros((4, pw), dtype=np.uint32)
     if qs is None:
         planes[3, :] = 0xffffffff
-    step = ((n + n_threads - 1) // n_threads + 31) // 32 * 32 if n_threads > 1 else max(n, 32)
+    step = ((n + n_chunks - 1) // n_chunks + 31) // 32 * 32 if n_chunks > 1 else max(n, 32)
     for lo in range(0, n, max(step, 32)):
         L.bfcg_pack_planes(seq_stream.ctypes.data, qs.ctypes.data if qs is not None else None, lo, min(n, lo + max(step, 32)), n, q, planes.ctypes.data, pw)
     return planes

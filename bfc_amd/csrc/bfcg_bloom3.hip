@@ -516,6 +516,7 @@ hipError_t set_bloom3_lds_attr(int lds)
 	hipError_t e = hipFuncSetAttribute((const void *)k_bloom3<512, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_bloom3<512, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_bloom3<512, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_bloom3<512, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 	return e;
 }
 
@@ -525,9 +526,236 @@ void run_bloom3(const KParams &P, const BloomArgs &A, int nfine, size_t lds, hip
 {
 	static int pf = 0;
 	if (!pf) { const char *e = getenv("BFCG_B3_PF"); pf = e && atoi(e) == 2 ? 2 : e && atoi(e) == 4 ? 4 : 1; } // (1: by the batch)
-	if (P.b3_cold) hipLaunchKernelGGL((k_bloom3<512, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
+	if (P.b3_cold && P.b3_warm) hipLaunchKernelGGL((k_bloom3<512, 2, true>), dim3(nfine), dim3(512), lds, st, P, A); // (the walk for a warm batch: the short list, four workgroups per CU)
+	else if (P.b3_cold) hipLaunchKernelGGL((k_bloom3<512, 4, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	else if (pf == 2 || (pf == 1 && P.b3_warm)) hipLaunchKernelGGL((k_bloom3<512, 2, false>), dim3(nfine), dim3(512), lds, st, P, A);
 	else hipLaunchKernelGGL((k_bloom3<512, 4, false>), dim3(nfine), dim3(512), lds, st, P, A);
 }
 
+} // namespace bfcg
+
+// ------------------------------------------------------------------------------------------
+// k_bloom3fm (round 5): the bloom insert of `bfc -1`'s count pass (filter mode, count.c:67-68: a k-mer seen before goes into the SECOND filter) for
+// 16-byte records whose bloom address is a bit field of their first two words -- k >= bf_shift + 9, so block, h1 and h2 are all bits of y0
+// (kmer.h:87; BASELINE config c5: k = 51, -b37) -- in k_bloom3's structure and with the block walk for EVERY batch:
+//   pass 1   every record: address, four bit positions, four LDS reads; all set before the batch => seen whatever the order: its bits are ORed
+//            into the second filter's slice (same hash, same block: it sits in LDS beside the first, count.c:67-68); else a list entry
+//            (file index | block, h1, h2) and the block's counter;
+//   walk     the list ordered by (block, file index), one lane per block doing what bfc_bf_insert does (bbf.c:33-44): seen iff every bit is set
+//            -- then the second filter's bits --, else set them.
+// Nothing is handed over.  A region whose list does not fit is not sent to a slower path: the walk is exact over any prefix of the file order,
+// so the region's records are taken in ROUNDS of file-index ranges (halved until a range's list fits) -- no HBM pool, no first-setter table.
+// Round 1-4's k_bloom<.., FM> served this mode before (c5's count pass: 1.52 of 3.10 s in it, 24.6 ps per k-mer against 10 for k_bloom3 on c4).
+struct Dec4 { int up, iw, is; uint32_t rmask; };
+__device__ __forceinline__ Dec4 dec4_geom(const KParams &P)
+{
+	Dec4 g;
+	g.up = P.rec_n ? P.rec_lo : P.bf_shift - 9;
+	const int io = (P.k - P.rec_n) + P.k + 1; // first bit of the file index inside the 128-bit record (Rec<4>::pack)
+	g.iw = io >> 5; g.is = io & 31; g.rmask = (1u << P.R) - 1u;
+	return g;
+}
+template <int BT, int PF>
+__global__ __launch_bounds__(BT, 6) void k_bloom3fm(KParams P, BloomArgs A)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	__shared__ uint32_t s_list_n, s_seen;
+	const uint32_t f = blockIdx.x;
+	if (batch_poisoned(A)) return;
+	uint32_t rs, n;
+	region_list(A, f, rs, n);
+	if (n == 0) return;
+	A.stats += (size_t)(f & (ST_SLOTS - 1)) * ST_N;
+	const uint32_t region_dw = 16u << P.R, nblk = 1u << P.R;
+	unsigned char *sp = smem;
+	unsigned int *region = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
+	unsigned int *region_hi = reinterpret_cast<unsigned int *>(sp); sp += (size_t)region_dw * 4;
+	unsigned int *bcnt = reinterpret_cast<unsigned int *>(sp), *boff = bcnt + nblk; sp += (size_t)(2 * nblk + 4) * 4;
+	unsigned int *la = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4;   // file-order index
+	unsigned int *lb = reinterpret_cast<unsigned int *>(sp); sp += (size_t)P.list_cap * 4;   // block | h1 << 8 | h2 << 17 (| B3_SEEN)
+	unsigned short *ord = reinterpret_cast<unsigned short *>(sp);                            // the list's entries in (block, file index) order
+	const uint32_t *recs = A.recs + (uint64_t)rs * 4;
+	unsigned int *g_region = reinterpret_cast<unsigned int *>(A.bloom) + (uint64_t)f * region_dw;
+	unsigned int *g_region_hi = reinterpret_cast<unsigned int *>(A.bloom_hi) + (uint64_t)f * region_dw;
+	const Dec4 D = dec4_geom(P);
+	const int tid = threadIdx.x, lane = tid & 63;
+	// block (R <= 8 bits) | h1 << 8 | h2 << 17 from the record's first two words: y0' bits [0, R) and [up, up + 18)
+	auto addr4 = [&](uint32_t d0, uint32_t d1) -> uint32_t {
+		const uint32_t hh = __builtin_amdgcn_alignbit(d1, d0, D.up);
+		uint32_t h2 = (hh >> 9) & 511u;
+		h2 |= (uint32_t)((h2 & 31u) == 0); // bbf.c:33
+		return (d0 & D.rmask) | ((hh & 511u) << 8) | (h2 << 17);
+	};
+	auto idx4 = [&](const RecW<4> &r) -> uint32_t { // bits [io, io + 32) of the 128-bit record
+		const uint32_t a = D.iw == 0 ? r.d[0] : D.iw == 1 ? r.d[1] : D.iw == 2 ? r.d[2] : r.d[3], b = D.iw == 0 ? r.d[1] : D.iw == 1 ? r.d[2] : r.d[3];
+		return D.is ? __builtin_amdgcn_alignbit(b, a, D.is) : a;
+	};
+	auto set_hi = [&](uint32_t bl64, const B3Pos &b) { // count.c:68 on the slice in LDS (two positions may share a word: ORs)
+		__hip_atomic_fetch_or(b3_wordp(region_hi, bl64, b.b0), 1u << (b.b0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_or(b3_wordp(region_hi, bl64, b.b1), 1u << (b.b1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_or(b3_wordp(region_hi, bl64, b.b2), 1u << (b.b2 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_or(b3_wordp(region_hi, bl64, b.b3), 1u << (b.b3 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	{ // stage both slices (16-byte loads)
+		const uint4 *src = reinterpret_cast<const uint4 *>(g_region), *src2 = reinterpret_cast<const uint4 *>(g_region_hi);
+		uint4 *dst = reinterpret_cast<uint4 *>(region), *dst2 = reinterpret_cast<uint4 *>(region_hi);
+		for (uint32_t i = tid; i < region_dw / 4; i += BT) { dst[i] = src[i]; dst2[i] = src2[i]; }
+	}
+	// rounds of file-index ranges: range r of 2^(32 - sh) = [r << sh, (r + 1) << sh); one round takes everything
+	uint32_t r = 0, sh = 32, seen_total = 0;
+	bool dirty = false;
+	const uint32_t cap = P.list_cap < (uint32_t)(B3_COLD_NR * BT) ? P.list_cap : (uint32_t)(B3_COLD_NR * BT);
+	for (;;) {
+		for (uint32_t i = tid; i < 2 * nblk + 4; i += BT) bcnt[i] = 0;
+		if (tid == 0) { s_list_n = 0; s_seen = 0; }
+		__syncthreads(); // (first round: the slices are staged)
+		// ---- pass 1 over the range's records: classify against the region as the earlier ranges left it
+		uint32_t my_seen = 0;
+		RecW<4> rec[PF], nxt[PF]; // (the records of the round after this one are on their way while this one is classified)
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+			const uint32_t i = tid + u * BT;
+			rec[u].d[0] = rec[u].d[1] = rec[u].d[2] = rec[u].d[3] = 0; nxt[u] = rec[u];
+			if (i < n) rec[u] = rec_load<4>(recs + (uint64_t)i * 4);
+			if (i + BT * PF < n) nxt[u] = rec_load<4>(recs + (uint64_t)(i + BT * PF) * 4);
+		}
+		for (uint32_t base = 0; base < n; base += BT * PF) {
+			uint32_t pk[PF], um[PF], ix[PF];
+			bool act[PF];
+#pragma unroll
+			for (int u = 0; u < PF; ++u) {
+				ix[u] = idx4(rec[u]);
+				act[u] = base + tid + u * BT < n && (sh == 32 || (ix[u] >> sh) == r);
+				pk[u] = addr4(rec[u].d[0], rec[u].d[1]);
+				const B3Pos b = b3_positions((pk[u] >> 8) & 511u, pk[u] >> 17);
+				const uint32_t bl64 = (pk[u] & 255u) << 6;
+				const uint32_t w0 = *b3_wordp(region, bl64, b.b0), w1 = *b3_wordp(region, bl64, b.b1), w2 = *b3_wordp(region, bl64, b.b2), w3 = *b3_wordp(region, bl64, b.b3);
+				um[u] = (b3_bit(w0, b.b0) | (b3_bit(w1, b.b1) << 1) | (b3_bit(w2, b.b2) << 2) | (b3_bit(w3, b.b3) << 3)) ^ 15u;
+				if (act[u] && um[u] == 0) { // every bit was set before this range: seen, whatever the order inside it
+					set_hi(bl64, b); ++my_seen;
+					if (A.seen_out) A.seen_out[ix[u]] = 2;
+				}
+			}
+			unsigned long long ml[PF];
+			uint32_t tot_l = 0;
+#pragma unroll
+			for (int u = 0; u < PF; ++u) { ml[u] = __ballot(act[u] && um[u] != 0); tot_l += (uint32_t)__popcll(ml[u]); }
+			uint32_t o_l = 0;
+			if (lane == 0 && tot_l) o_l = atomicAdd(&s_list_n, tot_l);
+			o_l = __builtin_amdgcn_readfirstlane(o_l);
+#pragma unroll
+			for (int u = 0; u < PF; ++u) {
+				if (act[u] && um[u] != 0) {
+					const uint32_t li = o_l + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml[u], 0u));
+					if (li < cap) { la[li] = ix[u]; lb[li] = pk[u]; __hip_atomic_fetch_add(&bcnt[pk[u] & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+				}
+				o_l += (uint32_t)__popcll(ml[u]);
+			}
+			if (base + BT * PF < n) {
+#pragma unroll
+				for (int u = 0; u < PF; ++u) {
+					rec[u] = nxt[u];
+					const uint32_t i = base + 2 * BT * PF + tid + u * BT;
+					if (i < n) nxt[u] = rec_load<4>(recs + (uint64_t)i * 4);
+				}
+			}
+		}
+		for (int o = 32; o; o >>= 1) my_seen += __shfl_down(my_seen, o);
+		if (lane == 0 && my_seen) atomicAdd(&s_seen, my_seen);
+		__syncthreads();
+		const uint32_t ln = s_list_n;
+		if (ln > cap) { // too many for one walk: the lower half of the range first (the region itself is as it was; the second filter's ORs were right and stay)
+			__syncthreads(); // (everybody has read the counters before the next round clears them)
+			--sh; r <<= 1;   // (a range of ONE index holds one k-mer: this ends)
+			continue;
+		}
+		seen_total += s_seen;
+		if (ln) {
+			if (tid < 64) { // block offsets: exclusive scan of the 2^R counters (four blocks per lane at most)
+				const uint32_t per = (nblk + 63u) >> 6, b0 = (uint32_t)tid * per;
+				uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) if ((uint32_t)t < per && b0 + t < nblk) { v[t] = bcnt[b0 + t]; sum += v[t]; }
+				uint32_t inc = sum;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+				uint32_t run = inc - sum;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) if ((uint32_t)t < per && b0 + t < nblk) { boff[b0 + t] = run; bcnt[b0 + t] = run; run += v[t]; }
+				if (tid == 63) boff[nblk] = inc;
+			}
+			__syncthreads();
+			for (uint32_t li = tid; li < ln; li += BT) ord[atomicAdd(&bcnt[lb[li] & 255u], 1u)] = (unsigned short)li;
+			__syncthreads();
+			uint32_t mv[B3_COLD_NR];
+#pragma unroll
+			for (int t = 0; t < B3_COLD_NR; ++t) {
+				const uint32_t pos = (uint32_t)tid + (uint32_t)t * BT;
+				mv[t] = 0;
+				if (pos < ln) {
+					const uint32_t li = ord[pos], x = la[li], bl = lb[li] & 255u, s0 = boff[bl], s1 = boff[bl + 1];
+					uint32_t rk = 0;
+					for (uint32_t j = s0; j < s1; ++j) rk += (uint32_t)(la[ord[j]] < x);
+					mv[t] = ((s0 + rk) << 16) | li;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int t = 0; t < B3_COLD_NR; ++t) { const uint32_t pos = (uint32_t)tid + (uint32_t)t * BT; if (pos < ln) ord[mv[t] >> 16] = (unsigned short)mv[t]; }
+			__syncthreads();
+			uint32_t w_seen = 0;
+			if ((uint32_t)tid < nblk) { // the walk: lane b takes block b's k-mers in file order (bbf.c:33-44, count.c:59-68)
+				const uint32_t bl64 = (uint32_t)tid << 6, s0 = boff[tid], s1 = boff[tid + 1];
+				uint32_t li_n = s0 < s1 ? ord[s0] : 0u, w_n = s0 < s1 ? lb[li_n] : 0u;
+				for (uint32_t j = s0; j < s1; ++j) {
+					const uint32_t li = li_n, w = w_n;
+					if (j + 1 < s1) { li_n = ord[j + 1]; w_n = lb[li_n]; }
+					const B3Pos b = b3_positions((w >> 8) & 511u, (w >> 17) & 511u);
+					unsigned int *p0 = b3_wordp(region, bl64, b.b0), *p1 = b3_wordp(region, bl64, b.b1), *p2 = b3_wordp(region, bl64, b.b2), *p3 = b3_wordp(region, bl64, b.b3);
+					const uint32_t w0 = *p0, w1 = *p1, w2 = *p2, w3 = *p3;
+					const uint32_t clr = (b3_bit(w0, b.b0) | (b3_bit(w1, b.b1) << 1) | (b3_bit(w2, b.b2) << 2) | (b3_bit(w3, b.b3) << 3)) ^ 15u;
+					if (clr == 0) { set_hi(bl64, b); ++w_seen; }
+					else {
+						if (clr & 1u) __hip_atomic_fetch_or(p0, 1u << (b.b0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (clr & 2u) __hip_atomic_fetch_or(p1, 1u << (b.b1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (clr & 4u) __hip_atomic_fetch_or(p2, 1u << (b.b2 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (clr & 8u) __hip_atomic_fetch_or(p3, 1u << (b.b3 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+					if (A.seen_out) A.seen_out[la[li]] = clr == 0 ? 2 : 1;
+				}
+			}
+			if (tid == 0) s_seen = 0;
+			__syncthreads();
+			for (int o = 32; o; o >>= 1) w_seen += __shfl_down(w_seen, o);
+			if (lane == 0 && w_seen) atomicAdd(&s_seen, w_seen);
+			__syncthreads();
+			seen_total += s_seen;
+			dirty = true;
+		}
+		// the next range: the sibling if this was a lower half, else up until a range that is one, and its sibling
+		if (sh == 32) break;
+		while (sh < 32 && (r & 1u)) { r >>= 1; ++sh; }
+		if (sh == 32) break;
+		r |= 1u;
+		__syncthreads();
+	}
+	if (dirty) {
+		uint4 *dst = reinterpret_cast<uint4 *>(g_region);
+		const uint4 *src = reinterpret_cast<const uint4 *>(region);
+		for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
+	}
+	if (seen_total) {
+		uint4 *dst = reinterpret_cast<uint4 *>(g_region_hi);
+		const uint4 *src = reinterpret_cast<const uint4 *>(region_hi);
+		for (uint32_t i = tid; i < region_dw / 4; i += BT) dst[i] = src[i];
+		if (tid == 0) atomicAdd(&A.stats[ST_SEEN], (unsigned long long)seen_total);
+	}
+}
+
+namespace bfcg {
+hipError_t set_bloom3fm_lds_attr(int lds) { return hipFuncSetAttribute((const void *)k_bloom3fm<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+void run_bloom3fm(const KParams &P, const BloomArgs &A, int nfine, size_t lds, hipStream_t st)
+{
+	hipLaunchKernelGGL((k_bloom3fm<512, 2>), dim3(nfine), dim3(512), lds, st, P, A);
+}
 } // namespace bfcg

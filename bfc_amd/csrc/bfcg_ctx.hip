@@ -78,6 +78,7 @@ struct bfcg_ctx {
 	int seg_blk_max;             // slots of a segment's block (log2): 14 = what a CU's LDS holds; BFCG_SEG_BLOCK lowers it so that small tests run segments of several blocks
 	int b3_ok;                   // ... and the bloom insert of batches without `dedupe` runs k_bloom3 (KParams.b3)
 	uint32_t fs_cap_w, list_cap_w; // k_bloom3's LDS tables for batches into a WARM filter (0: none): a footprint of a quarter of a CU's LDS
+	uint32_t list_cap_cw;        // ... and for batches into a warm filter where those take the walk too (BFCG_B3_WALK_WARM): a quarter of a CU's LDS
 	uint32_t list_cap_c;         // k_bloom3<.., COLD>'s list for batches into a filter that is still filling up (0: none): 12-byte entries, no first-setter table
 	int seg_init_shift;          // log2 slots per segment after a reset
 	int seg_escaped;             // the segments outgrew LDS (or the table was exported): converted to the (sub-table, key) layout until the next reset
@@ -246,13 +247,27 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		}
 		// Into a filter that is still filling up (round 5): k_bloom3<.., COLD> orders the list by (block, file index) and walks the blocks; its entries
 		// are 12 bytes and need no first-setter table beside them -- the same third of a CU's LDS holds 2 879 of them instead of 2 021
-		c->list_cap_c = 0;
+		c->list_cap_c = 0; c->list_cap_cw = 0;
 		if (P.b3 && !(getenv("BFCG_B3_COLD") && atoi(getenv("BFCG_B3_COLD")) == 0)) {
 			const size_t fixed = region + ((size_t)2 << P.R) * 4 + 16 + 16;
 			if (budget > fixed + 12 * 256) {
 				uint32_t l = (uint32_t)((budget - fixed) / 12);
 				if (l > 4096) l = 4096; // (B3_COLD_NR x 512 positions in the rank pass)
 				c->list_cap_c = l;
+			}
+			c->list_cap_cw = 0;
+			if ((size_t)40900 > fixed + 12 * 256 && getenv("BFCG_B3_WALK_WARM") && atoi(getenv("BFCG_B3_WALK_WARM"))) c->list_cap_cw = (uint32_t)(((size_t)40900 - fixed) / 12);
+		}
+		// filter mode on 16-byte records (config c5: k = 51, -b37): k_bloom3fm keeps both slices, the block counters and 10-byte list entries -- no
+		// first-setter table; a region whose list overflows is taken in rounds of file-index ranges, so the capacity only sets the speed
+		P.b3fm = 0;
+		if (prm->filter_mode && c->rw == 16 && bloom3fm_geometry_ok(P) && !getenv("BFCG_NO_B3")) {
+			const size_t fixed = 2 * region + ((size_t)2 << P.R) * 4 + 16 + 16;
+			if (budget > fixed + 10 * 256) {
+				uint32_t l = (uint32_t)((budget - fixed) / 10);
+				if ((e = getenv("BFCG_B3FM_LIST")) != 0 && atoi(e) >= 64 && (uint32_t)atoi(e) < l) l = (uint32_t)atoi(e); // (tests: a tiny list forces the rounds)
+				if (l > 4096) l = 4096;
+				P.b3fm = 1; P.list_cap = l; P.fs_cap = 512;
 			}
 		}
 		{ // the class table of cold batches lies over the first-setter table and the lists
@@ -467,6 +482,7 @@ static void warm_tables(const bfcg_ctx_t *c, KParams &Pt)
 {
 	Pt.b3_warm = 0; Pt.b3_cold = 0;
 	if (Pt.b3 && c->cold && c->list_cap_c) { Pt.list_cap = c->list_cap_c; Pt.b3_cold = 1; Pt.dedupe = 0; } // (the walk resolves copies by itself)
+	else if (Pt.b3 && !Pt.dedupe && !c->cold && c->list_cap_cw && c->list_cap_cw >= c->list_cap_w) { Pt.list_cap = c->list_cap_cw; Pt.b3_warm = 1; Pt.b3_cold = 1; }
 	else if (Pt.b3 && !Pt.dedupe && !c->cold && c->list_cap_w) { Pt.fs_cap = c->fs_cap_w; Pt.list_cap = c->list_cap_w; Pt.b3_warm = 1; }
 }
 static int dedupe_hint(const bfcg_ctx_t *c) { return (c->n_batches == 0 || (c->cold && c->seen_per_pos < 0.15)) && !getenv("BFCG_NO_DEDUPE"); }
@@ -772,6 +788,9 @@ static int seg_maintain(bfcg_ctx_t *c)
 			if (no_room || target > c->seg_total_max) { // (beyond 2^14 slots a segment is several blocks, one workgroup each: KParams.seg_blk)
 				if (ovf == 0 && (double)c->h_stats[ST_KEYS] < 0.85 * (double)(nfine << P.seg_shift)) { c->seg_no_grow = 1; return 0; }
 				if (target > c->seg_total_max) return seg_to_legacy(c); // ... else the host's layout takes over (random CAS upserts, any size)
+				// no room for the next segment size, and too full (or k-mers parked) to run on as it is: the host's layout sizes its table to the memory
+				// that IS free (seg_to_legacy) and may well succeed where doubling every segment cannot -- try it before giving up
+				if (seg_to_legacy(c) == 0) return 0;
 				return set_err("count table of %llu keys cannot grow to 2^%d slots per region: %.1f GiB of device memory free", (unsigned long long)c->h_stats[ST_KEYS], target, free_b / 1073741824.0);
 			}
 		}
@@ -820,6 +839,9 @@ static int seg_to_legacy(bfcg_ctx_t *c, int for_export)
 	const uint64_t nfine = ((uint64_t)1 << P.F) >> c->log2n;
 	const uint64_t keys = c->h_stats[ST_KEYS];
 	if (c->seg_spare) { HIPCK(hipFree(c->seg_spare)); c->seg_spare = 0; }
+	// a context that counts on in the host's layout needs k_bloom's aggregation buffer (1.6 GB at -b35, 6.4 GB at -b37): taken BEFORE the table is
+	// sized to the memory that is free, not at the next batch when nothing may be left
+	if (!for_export && !P.filter_mode && !B.agg_out) HIPCK(hipMalloc(&B.agg_out, nfine * P.ag_cap * (P.track ? 32 : 24)));
 	int cs = c->prm.tab_cshift > 0 ? c->prm.tab_cshift : 2;
 	const uint64_t want = for_export ? keys + keys * 3 / 4 : 2 * keys + (c->prm.max_batch_pos / 4);
 	while ((1ULL << (P.l_pre + cs)) < want && P.l_pre + cs < 36) ++cs;
@@ -1240,6 +1262,10 @@ static uint64_t split_limit(const bfcg_ctx_t *c)
 	// Callers split from 7/6 of this on: just above the limit a few hundred slow regions cost less (5 %) than a second pass over the filter (12 %).
 	// (into a filter that is still filling up k_bloom3's COLD mode holds a longer list)
 	const uint32_t cap = c->P.b3 && c->cold && c->list_cap_c ? c->list_cap_c : c->P.list_cap;
+	// Filter mode through k_bloom3fm: a batch costs a sweep over BOTH filters (c5: 2 x 2 x 16 GiB each way -- 17 ms at the rate the kernel draws, as
+	// much as the rest of its work on 8 M reads), while a region whose list overflows only takes its records in two rounds instead of one: the limit
+	// sits where a region's k-mers (0.66 per position at k = 51) about fill the list, not a third below it
+	if (c->P.b3fm) return (uint64_t)((double)nfine * (double)cap * 0.95 * 1.6);
 	return (uint64_t)((double)nfine * (double)cap * 0.95);
 }
 static inline int is_acgt(uint8_t ch) { ch &= 0xDF; return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }

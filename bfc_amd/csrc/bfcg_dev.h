@@ -193,4 +193,6 @@ namespace bfcg {
 // bfcg_bloom3.hip
 hipError_t set_bloom3_lds_attr(int lds);
 void run_bloom3(const KParams &P, const BloomArgs &A, int nfine, size_t lds, hipStream_t st);
+hipError_t set_bloom3fm_lds_attr(int lds);
+void run_bloom3fm(const KParams &P, const BloomArgs &A, int nfine, size_t lds, hipStream_t st);
 }

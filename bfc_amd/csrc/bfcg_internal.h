@@ -54,6 +54,7 @@ struct KParams {
 	int rec_lo, rec_n;          // bits [rec_lo, rec_lo + rec_n) of y0 are a record's level-1 bucket and are not stored in it (0: everything is stored)
 	int b3;                     // the default path's bloom insert runs k_bloom3: a list entry in LDS is 10 bytes (bloom_lds_bytes), and batches without `dedupe` take that kernel
 	int b3_warm;                // this batch goes into a warm filter: fs_cap / list_cap are the SHORT list's (four workgroups of k_bloom3 per CU instead of three)
+	int b3fm;                   // filter mode (`bfc -1`) on 16-byte records whose bloom address is a bit field of their words: k_bloom3fm (list_cap: its 10-byte entries)
 	int b3_cold;                // this batch goes into a filter that is still filling up: k_bloom3<.., COLD> -- the list ordered by (block, file index), one lane walks a
 	                            // block's k-mers as bfc_bf_insert would; list_cap is the cold list's (12-byte entries, no first-setter table beside them)
 };
@@ -94,6 +95,7 @@ void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, cons
                  const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev);
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev);
 int bloom_lds_bytes(const KParams &P);
+bool bloom3fm_geometry_ok(const KParams &P); // k_bloom3fm's conditions (16-byte records, k >= bf_shift + 9: block, h1, h2 are bits of y0; 4 hashes; regions of <= 256 blocks)
 bool bloom3_geometry_ok(const KParams &P); // k_bloom3's conditions (12-byte records whose bloom address is a bit field of their words, 4 hashes, regions of <= 256 blocks)
 hipError_t set_bloom_lds_attr(const KParams &P);
 void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *bloom, uint8_t *flags, hipStream_t st);

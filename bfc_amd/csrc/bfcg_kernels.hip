@@ -2267,6 +2267,12 @@ static inline bool bloom_fast3(const KParams &P)
 
 // a CU's LDS holds 160 KB / segment size workgroups: keep its 2048 lanes busy whatever that number is (c4's 64 KiB segments at 256
 // threads per workgroup: commit 2.89 s, at 1024: 1.44 s)
+bool bloom3fm_geometry_ok(const KParams &P)
+{
+	const int up = P.rec_n ? P.rec_lo : P.bf_shift - 9, a = P.k - P.rec_n, io = a + P.k + 1;
+	return bfcg_rec_dwords(P.k, P.rec_n) == 4 && P.n_hashes == 4 && P.R <= 8 && P.k >= P.bf_shift + 9 && (P.rec_n == 0 || P.rec_lo + P.rec_n == P.bf_shift - 9)
+	       && P.R <= up && up >= 1 && up <= 31 && a >= up + 18 && io + 32 <= 128;
+}
 bool bloom3_geometry_ok(const KParams &P) { return bfcg_rec_dwords(P.k, P.rec_n) == 3 && P.n_hashes == 4 && P.R <= 8 && bloom_fast3(P); }
 
 // one workgroup per (region, block of its segment): one-dimensional `f * blocks + blk` -- a region's blocks back to back -- unless that
@@ -2337,7 +2343,8 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	else if (P.F2 > 0 && B.cnt_live) A.cnt2 = B.cnt_live; // two passes: the regions' counts beside their starts (region_list)
 	size_t lds = (size_t)bloom_lds_bytes(P);
 	if (P.filter_mode && B.bloom_hi) { // both filters' slices in LDS, nothing to hand over
-		if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
+		if (RW == 4 && P.b3fm) run_bloom3fm(P, A, nfine, lds, st); // (bfcg_bloom3.hip)
+		else if (P.n_hashes == 4 && P.bloom_bt == 1024) hipLaunchKernelGGL((k_bloom<W, RW, 1024, 2, 4, false, true>), dim3(nfine), dim3(1024), lds, st, P, A);
 		else if (P.n_hashes == 4) hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 4, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 		else hipLaunchKernelGGL((k_bloom<W, RW, 512, 4, 0, false, true>), dim3(nfine), dim3(512), lds, st, P, A);
 	} else if (P.seg && B.seg_tab && (B.stream_out || B.ho)) { // region-owned table segments: seen k-mers are handed to k_commit_seg, one workgroup per region
@@ -2417,6 +2424,7 @@ void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const u
 int bloom_lds_bytes(const KParams &P)
 {
 	const size_t second = P.filter_mode ? ((size_t)64 << P.R) : P.seg ? 0 : (size_t)P.ag_cap * ((P.k > 32 ? 24 : 16) + (P.track ? 8 : 0)); // second filter's slice or aggregation table
+	if (P.b3fm) return (int)(((size_t)128 << P.R) + ((size_t)2 << P.R) * 4 + 16 + (size_t)P.list_cap * 10 + 16); // k_bloom3fm: both slices, block counters + offsets, 10-byte entries
 	if (P.b3 && P.b3_cold) return (int)(((size_t)64 << P.R) + ((size_t)2 << P.R) * 4 + 16 + (size_t)P.list_cap * 12 + 16); // k_bloom3<.., COLD>: region, block counters + offsets, 12-byte entries
 	return (int)(((size_t)64 << P.R) + (size_t)P.fs_cap * 4 + second + (size_t)P.list_cap * (P.b3 ? 10 : 8) + 16);
 }
@@ -2442,7 +2450,8 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	if constexpr (RW == 3) { e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; }
-	if constexpr (RW == 3) { e = set_bloom3_lds_attr(lds > 53008 ? lds : 53008); if (e != hipSuccess) return e; } // (its COLD mode lays the same third of a CU's LDS out differently)
+	if constexpr (RW == 3) { e = set_bloom3_lds_attr(lds > 53008 ? lds : 53008); if (e != hipSuccess) return e; }
+	if constexpr (RW == 4) { e = set_bloom3fm_lds_attr(lds > 53008 ? lds : 53008); if (e != hipSuccess) return e; } // (its COLD mode lays the same third of a CU's LDS out differently)
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_commit_seg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << BFCG_SEG_MAX_SHIFT); if (e != hipSuccess) return e;

@@ -18,6 +18,9 @@ PY
 if has quick; then
   timeout 1500 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_group.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_quick.log; tail -6 gpurun_out/r5_quick.log
 fi
+if has fuzzenv; then  # the fuzz + parity suites under an environment setting (FUZZ_ENV="BFCG_X=1 ...")
+  env $FUZZ_ENV timeout 1200 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_fuzzenv.log; echo "fuzzenv ($FUZZ_ENV)"; tail -4 gpurun_out/r5_fuzzenv.log
+fi
 if has tests; then
   timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_gpu_tests.log; tail -8 gpurun_out/r5_gpu_tests.log
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
@@ -43,4 +46,11 @@ if has c5; then timeout 900 python scripts/c4_run.py --batch-reads 8388608 --fil
 if has prof; then
   PMC=2 STEPS=1 bash scripts/prof_round2.sh c3 > gpurun_out/prof_c3.out 2>&1; tail -3 gpurun_out/prof_c3.out | cut -c1-200
   ROUND=5 python tools/make_round_md.py gpurun_out/prof_c3 c3 > gpurun_out/round5_c3.md; cp profiles/round5_c3_pmc.json gpurun_out/ 2>/dev/null
+fi
+if has fm; then  # the filter-mode kernel: its parity tests, the c5s shape, the FM fuzz draws
+  timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_shapes.py tests/test_gpu_fuzz.py tests/test_gpu_group.py -q -m gpu -x -k "filter_mode or c5 or fm or fuzz or group_host" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_fm.log; tail -5 gpurun_out/r5_fm.log
+fi
+if has c5ab; then
+  BFCG_NO_B3=1 timeout 900 python scripts/c4_run.py --batch-reads 8388608 --filter-mode 1 --k 51 --cov ${C5_COV:-8} > gpurun_out/r5_c5_old.log 2>&1; tail -1 gpurun_out/r5_c5_old.log | cut -c1-600
+  timeout 900 python scripts/c4_run.py --batch-reads 8388608 --filter-mode 1 --k 51 --cov ${C5_COV:-8} > gpurun_out/r5_c5_new.log 2>&1; tail -1 gpurun_out/r5_c5_new.log | cut -c1-600
 fi

@@ -63,7 +63,7 @@ def _check(gpu_lib, prm, seq, qual, off, cuts, kw, planes=False):
     cap = len(seq) + n + 64
     g = gpu_lib.GpuCounter(prm["k"], prm["b"], q=prm["q"], n_hashes=prm["nh"], l_pre=prm["l_pre"], filter_mode=prm["fm"], max_batch_pos=cap, **kw)
     if planes:  # the whole input as ONE set of bit planes (bfcg_pack_planes, three packing threads' ranges), its pieces counted at their bit offsets
-        pl = gpu_lib.pack_planes(gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off) if qual is not None else None, prm["q"], n_threads=3)
+        pl = gpu_lib.pack_planes(gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off) if qual is not None else None, prm["q"], n_chunks=3)
         for a, e in zip(cuts[:-1], cuts[1:]):
             g.count_planes(pl, int(off[a]) + a, int(off[e]) + e - int(off[a]) - a, has_qual=qual is not None)
     for a, e in zip(cuts[:-1], cuts[1:]):

@@ -358,3 +358,51 @@ def test_batches_whose_kmers_hardly_repeat_switch_to_stream_mode(gpu_lib, k):
     g.reset()  # back to aggregation
     assert g.stats()["crowded_regions"] == 0
     g.close(); oc.close()
+
+
+# ---- k_bloom3fm (round 5): filter mode (`bfc -1`, count.c:67-68) on 16-byte records whose bloom address is a bit field of their words
+@pytest.mark.parametrize("k,b", [(51, 31), (47, 28), (45, 30), (51, 33), (49, 26)])
+@pytest.mark.parametrize("n_batches,list_cap", [(1, 0), (3, 0), (2, 64)])
+def test_filter_mode_block_walk(gpu_lib, g1, monkeypatch, k, b, n_batches, list_cap):
+    """Both filters (first: every k-mer's bits; second: the k-mers seen before, count.c:67-68) and the per-k-mer seen flags against the sequential
+    oracle, for geometries that select k_bloom3fm (k >= bf_shift + 9, 16-byte records), over several batches, and with a list of 64 entries per
+    region so that regions are taken in rounds of file-index ranges."""
+    if list_cap:
+        monkeypatch.setenv("BFCG_B3FM_LIST", str(list_cap))
+    rs, (seq, qual, off) = g1
+    n = 6000 if b >= 30 else 3000
+    seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
+    oc = oracle.Counter(k, b, filter_mode=1)
+    tr = oc.count(seq, qual, off, trace=True)
+    g = _gpu_count(gpu_lib, k, b, seq, qual, off, n_batches, filter_mode=1, debug_seen=(n_batches == 1))
+    assert g.mg_info()["rec_bytes"] == 16
+    assert np.array_equal(g.bloom_bytes(0), oc.bloom_bytes()), "first filter differs"
+    assert np.array_equal(g.bloom_bytes(1), oc.bloom_bytes(True)), "second filter differs"
+    ost, st = oc.stats(), g.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    assert st["slow_buckets"] == 0  # (no pool path in this kernel: overflowing regions take rounds)
+    if n_batches == 1:
+        fl = g.seen_flags(len(seq) + n)
+        assert np.array_equal(fl[fl > 0] == 2, (tr[:, 3] >> 1) & 1 == 1), "seen flags differ from the sequential semantics"
+    g.close(); oc.close()
+
+
+def test_filter_mode_block_walk_heavy_regions(gpu_lib, monkeypatch):
+    """A filter of ONE region's worth per 2^17 bits and a genome with many copies: thousands of k-mers per region and block, lists that overflow
+    several times over (rounds halve the file-index range until a range fits), copies of a k-mer inside one batch (the second copy is seen)."""
+    rng = np.random.default_rng(515)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, G, n = 150, 3000, 4000
+    genome = rng.choice(acgt, G + L)
+    pos = rng.integers(0, G, n)
+    seq = genome[(pos[:, None] + np.arange(L)[None, :])].astype(np.uint8).reshape(-1)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    for k, b in ((47, 20), (45, 19)):  # (16-byte records: 2k + 33 <= 128 without dropped bits)
+        oc = oracle.Counter(k, b, filter_mode=1)
+        oc.count(seq, qual, off)
+        g = _gpu_count(gpu_lib, k, b, seq, qual, off, 2, filter_mode=1)
+        assert g.mg_info()["rec_bytes"] == 16
+        assert np.array_equal(g.bloom_bytes(0), oc.bloom_bytes()) and np.array_equal(g.bloom_bytes(1), oc.bloom_bytes(True))
+        assert g.stats()["n_seen"] == oc.stats()["n_seen"]
+        g.close(); oc.close()

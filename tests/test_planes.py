@@ -36,7 +36,7 @@ def test_planes_of_every_byte_value(q, threads):
     n = 256 * 256 + 77  # every (sequence byte, quality byte) pair, and a ragged end
     seq = np.concatenate([np.repeat(np.arange(256, dtype=np.uint8), 256), rng.integers(0, 256, 77).astype(np.uint8)])
     qual = np.concatenate([np.tile(np.arange(256, dtype=np.uint8), 256), rng.integers(0, 256, 77).astype(np.uint8)])
-    pl = bfc_amd.pack_planes(seq, qual, q, n_threads=threads)
+    pl = bfc_amd.pack_planes(seq, qual, q, n_chunks=threads)
     want = _props(seq, qual, q)
     for p in range(4):
         assert np.array_equal(_bits(pl[p], n), want[p]), "plane %d" % p
