@@ -189,6 +189,30 @@ __device__ __forceinline__ uint32_t fs32_lookup(const unsigned int *fs, uint32_t
 }
 
 
+// ---- the four bit positions of a k-mer inside its 512-bit block without a loop (k_bloom3, k_bloom3fm, k_query4)
+struct B3Pos { uint32_t b0, b1, b2, b3; };
+// bbf.c:33-41: positions z = h1, h1 + h2, ... (mod 512), those below 8 (the lock byte) skipped.  The first five candidates of the walk; a
+// skipped one shifts the rest by one (the tests combine as lane masks on the scalar unit); a second skip shows as a position below 8 and
+// takes the reference's loop (h2 < 8 or > 504 AND a step into the lock byte: one k-mer in a thousand).
+__device__ __forceinline__ B3Pos b3_positions(uint32_t h1, uint32_t h2)
+{
+	const uint32_t u1 = h1 + h2, u2 = u1 + h2, u3 = u2 + h2, u4 = u3 + h2;
+	const uint32_t c0 = h1, c1 = u1 & 511u, c2 = u2 & 511u, c3 = u3 & 511u, c4 = u4 & 511u;
+	const bool s0 = c0 < 8u, s1 = s0 | (c1 < 8u), s2 = s1 | (c2 < 8u), s3 = s2 | (c3 < 8u);
+	B3Pos p;
+	p.b0 = s0 ? c1 : c0; p.b1 = s1 ? c2 : c1; p.b2 = s2 ? c3 : c2; p.b3 = s3 ? c4 : c3;
+	if (__builtin_expect(min(min(p.b0, p.b1), min(p.b2, p.b3)) < 8u, 0)) {
+		uint32_t z = h1;
+		p.b0 = bloom_next(z, h2); p.b1 = bloom_next(z, h2); p.b2 = bloom_next(z, h2); p.b3 = bloom_next(z, h2);
+	}
+	return p;
+}
+// the dword of bit b of block bl inside the LDS region, by its byte offset; bit b of that dword
+__device__ __forceinline__ unsigned int *b3_wordp(unsigned int *region, uint32_t bl64, uint32_t b)
+{ return reinterpret_cast<unsigned int *>(reinterpret_cast<unsigned char *>(region) + (bl64 | ((b >> 3) & 0x3cu))); }
+__device__ __forceinline__ uint32_t b3_bit(uint32_t w, uint32_t b) { return __builtin_amdgcn_ubfe(w, b, 1u); } // (the field offset is b's low five bits)
+
+
 namespace bfcg {
 // bfcg_bloom3.hip
 hipError_t set_bloom3_lds_attr(int lds);

@@ -2053,6 +2053,76 @@ __global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restri
 }
 
 // reads r: positions [off[r], off[r+1]-1) of the stream (the last byte of the span is the separator)
+// k_query4 (round 5): the bloom query for n_hashes = 4 with the memory system's REQUEST RATE in mind.  Random 64-byte gathers into a 16 GiB
+// array reach 48.8 G per second on this chip whatever their size between 16 and 128 bytes (scripts/probes/gather_probe.hip,
+// profiles/round5_gather_probe.txt: the rate of HBM row activations, not bytes, is the limit); k_query's co-operative gather -- four lanes, four
+// 16-byte quarters, one query after the other with the k-mer arithmetic of the next in between -- reached 22 G queries/s: it kept ONE gather in
+// flight per wave most of the time.  Here a group of four lanes still serves its four queries together, but lane m fetches only the DWORD that
+// holds position m of the query (the four dwords of a block leave as one request), tests one bit, and the group ANDs the four bits (quad
+// permutes on the vector unit: no LDS crossbar); the loads of query j + 1 are issued before the bits of query j are looked at, so a wave
+// has two queries' gathers in flight beside its arithmetic.  bbf.c:47-63 as it stands: all n_hashes bits set <=> hit.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <typename W, int TILE, int BT>
+__global__ __launch_bounds__(BT) void k_query4(KParams P, const uint8_t *__restrict__ seq, int64_t n_pos,
+                                               const unsigned int *__restrict__ bloom, uint8_t *__restrict__ flags)
+{
+	constexpr int PW = (TILE + 64) / 32 + 2, S = TILE / BT;
+	static_assert(S % 2 == 0, "queries are taken in pairs");
+	__shared__ uint32_t planes[4 * PW];
+	const W m = kmask<W>(P.k);
+	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
+	const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	build_planes<TILE, BT>(seq, nullptr, n_pos, tile * TILE, P.q, planes);
+	__syncthreads();
+	const uint32_t member = threadIdx.x & 3u, sh = (member & 1u) << 4;
+	const bool upper = (member & 2u) != 0;
+	// the owner's part: block and the four positions (two per word; bit 31 of the second: there is a k-mer) of the query at tile position j * BT + thread
+	auto own = [&](int j, uint32_t &blk, uint32_t &pa, uint32_t &pb) {
+		const int r = j * BT + (int)threadIdx.x;
+		W y0, y1; bool hi;
+		blk = 0; pa = 0; pb = 0; // (no k-mer here: the group fetches block 0's first dword for it, and nobody looks)
+		if (tile * TILE + r < n_pos && kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
+			const BloomAddr a = bloom_addr(bloom_hash<W>(P.k, y0, y1, m), P.bf_shift);
+			const B3Pos b = b3_positions(a.h1, a.h2);
+			blk = (uint32_t)a.blk; pa = b.b0 | (b.b1 << 16); pb = b.b2 | (b.b3 << 16) | 0x80000000u;
+		}
+	};
+	// the group's part: lane m fetches the dword of position m of each of the group's four queries
+	auto fetch1 = [&](uint32_t qb, uint32_t qa, uint32_t qc, uint32_t &w, uint32_t &bit) {
+		const uint32_t b = ((upper ? qc : qa) >> sh) & 511u;
+		w = bloom[(uint64_t)qb * 16u + (b >> 5)]; bit = b & 31u;
+	};
+	auto fetch = [&](uint32_t blk, uint32_t pa, uint32_t pb, uint32_t (&w)[4], uint32_t (&bit)[4]) {
+		fetch1(dpp_quad<0x00>(blk), dpp_quad<0x00>(pa), dpp_quad<0x00>(pb), w[0], bit[0]);
+		fetch1(dpp_quad<0x55>(blk), dpp_quad<0x55>(pa), dpp_quad<0x55>(pb), w[1], bit[1]);
+		fetch1(dpp_quad<0xAA>(blk), dpp_quad<0xAA>(pa), dpp_quad<0xAA>(pb), w[2], bit[2]);
+		fetch1(dpp_quad<0xFF>(blk), dpp_quad<0xFF>(pa), dpp_quad<0xFF>(pb), w[3], bit[3]);
+	};
+	auto settle = [&](int j, uint32_t pb, const uint32_t (&w)[4], const uint32_t (&bit)[4]) {
+		uint32_t mine = 0;
+#pragma unroll
+		for (uint32_t p = 0; p < 4; ++p) {
+			uint32_t t = (w[p] >> bit[p]) & 1u;
+			t &= dpp_quad<0xB1>(t); t &= dpp_quad<0x4E>(t); // all four bits of query p (bbf.c:60: every one of the n_hashes bits)
+			if (member == p) mine = t;
+		}
+		const int64_t e = tile * TILE + j * BT + (int)threadIdx.x;
+		if (e < n_pos) flags[e] = !(pb >> 31) ? 0 : mine ? 2 : 1;
+	};
+	uint32_t blkA, paA, pbA, wA[4], bitA[4], blkB, paB, pbB, wB[4], bitB[4];
+	own(0, blkA, paA, pbA);
+	fetch(blkA, paA, pbA, wA, bitA);
+#pragma unroll 1
+	for (int j = 0; j < S; j += 2) {
+		own(j + 1, blkB, paB, pbB);
+		fetch(blkB, paB, pbB, wB, bitB);
+		settle(j, pbA, wA, bitA);
+		if (j + 2 < S) { own(j + 2, blkA, paA, pbA); fetch(blkA, paA, pbA, wA, bitA); }
+		settle(j + 1, pbB, wB, bitB);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_streak(int k, float min_frac, const uint8_t *__restrict__ flags, const uint64_t *__restrict__ off,
                                                 uint64_t n_reads, int32_t *__restrict__ out_start, int32_t *__restrict__ out_end)
 {
@@ -2475,6 +2545,13 @@ void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *
 {
 	const int64_t tiles = (n_pos + TILE1 - 1) / TILE1;
 	const unsigned g = (unsigned)(((tiles + 7) / 8) * 8);
+	const char *eq = getenv("BFCG_QUERY4"); // (1: k_query4 whatever the filter's size -- tests; 0: never -- A/B; read per call: tests switch it)
+	const int q4 = eq ? atoi(eq) : -1;
+	if (P.n_hashes == 4 && P.bf_shift <= 41 && (q4 == 1 || (q4 != 0 && P.bf_shift >= 35))) {
+		if (P.k <= 32) hipLaunchKernelGGL((k_query4<uint32_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+		else hipLaunchKernelGGL((k_query4<uint64_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+		return;
+	}
 	const bool coop = P.bf_shift >= 35; // 4 GiB and more: measured 13.8 -> 21.2 G queries/s on 16 GiB, but 23.1 -> 21.9 on 1 GiB
 	if (P.k <= 32) {
 		if (coop) hipLaunchKernelGGL((k_query<uint32_t, TILE1, BT1, true>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);

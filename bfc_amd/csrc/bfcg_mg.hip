@@ -467,6 +467,26 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		}
 	}
 	(void)hipGetLastError(); // hipDeviceEnablePeerAccess on an already enabled pair
+	if (g->mp) { // one rank per process: every process must have decided the same exchange layout (slab mode, slab capacity, words per row of sizes) --
+	             // each decides it from its own environment and context; an all-gather with different counts would hang or corrupt memory
+		rank_t &R = g->r[0];
+		const uint32_t mine[4] = {(uint32_t)g->slabs_ok, g->slab_cap, (uint32_t)g->row_words, (uint32_t)g->rec_bytes};
+		std::vector<uint32_t> all((size_t)4 * n_ranks, 0);
+		hipError_t he = hipSetDevice(R.device);
+		ncclResult_t ne = ncclSuccess;
+		if (he == hipSuccess) he = hipMemcpyAsync(R.d_counts + (size_t)4 * R.rank, mine, sizeof(mine), hipMemcpyHostToDevice, R.xs); // (d_counts holds n_ranks x row_words >= 4 n_ranks words)
+		if (he == hipSuccess) ne = ncclAllGather(R.d_counts + (size_t)4 * R.rank, R.d_counts, 4, ncclUint32, R.comm, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipMemcpyAsync(all.data(), R.d_counts, sizeof(uint32_t) * all.size(), hipMemcpyDeviceToHost, R.xs);
+		if (he == hipSuccess && ne == ncclSuccess) he = hipStreamSynchronize(R.xs);
+		if (he != hipSuccess || ne != ncclSuccess) { bfcg_set_error("all-gather of the ranks' exchange layout failed"); g->failed = 1; bfcg_group_destroy(g); return NULL; }
+		for (int p = 0; p < n_ranks; ++p)
+			if (memcmp(&all[(size_t)4 * p], mine, sizeof(mine)) != 0) {
+				char msg[256];
+				snprintf(msg, sizeof(msg), "rank %d decided another exchange layout (slab mode %u / %u, slab capacity %u / %u, row words %u / %u): same BFCG_MG_SLABS and parameters on every process?",
+				         p, all[(size_t)4 * p], mine[0], all[(size_t)4 * p + 1], mine[1], all[(size_t)4 * p + 2], mine[2]);
+				bfcg_set_error(msg); g->failed = 1; bfcg_group_destroy(g); return NULL;
+			}
+	}
 	for (int i = 0; i < n_local; ++i) {
 		void **arg = (void **)malloc(2 * sizeof(void *));
 		arg[0] = g; arg[1] = (void *)(intptr_t)i;

@@ -54,3 +54,12 @@ if has c5ab; then
   BFCG_NO_B3=1 timeout 900 python scripts/c4_run.py --batch-reads 8388608 --filter-mode 1 --k 51 --cov ${C5_COV:-8} > gpurun_out/r5_c5_old.log 2>&1; tail -1 gpurun_out/r5_c5_old.log | cut -c1-600
   timeout 900 python scripts/c4_run.py --batch-reads 8388608 --filter-mode 1 --k 51 --cov ${C5_COV:-8} > gpurun_out/r5_c5_new.log 2>&1; tail -1 gpurun_out/r5_c5_new.log | cut -c1-600
 fi
+if has trim; then  # the query kernel: trim tests, then c5's trim pass at 8x with and without k_query4
+  timeout 1200 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_dropin.py -q -m gpu -x -k "trim" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_trim.log; tail -4 gpurun_out/r5_trim.log
+  for q in 0 1; do
+    BFCG_QUERY4=$q timeout 900 python scripts/c4_run.py --batch-reads 16777216 --filter-mode 1 --k 51 --cov ${C5_COV:-8} --trim 1 > gpurun_out/r5_c5_trim_q$q.log 2>&1; echo "BFCG_QUERY4=$q"; tail -1 gpurun_out/r5_c5_trim_q$q.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in d if k.startswith('trim') or k in ('gpu_s','gpu_stage_ms')})"
+  done
+fi
+if has s1abl; then  # k_scatter1 under the measurement switches (the -DBFCG_MEASURE library): what each part costs on the current kernel
+  for a in 0 2048 1024 256 512 1280 3328; do BFCG_ABLATE=$a timeout 300 python scripts/s1_ablate.py 2>&1 | tail -1; done > gpurun_out/r5_s1_ablate.txt; cat gpurun_out/r5_s1_ablate.txt
+fi

@@ -275,11 +275,14 @@ def test_random_exact_dump(gpu_lib, seed, tmp_path):
     t.close(); g.close(); oc.close()
 
 
+@pytest.mark.parametrize("q4", ["0", "1"])
 @pytest.mark.parametrize("seed", range(20))
-def test_random_trim_pass(gpu_lib, seed):
+def test_random_trim_pass(gpu_lib, seed, q4, monkeypatch):
     """`bfc -1` under random parameters: count in filter mode on the GPU, then the GPU trim pass; start / end of every read equal the
-    oracle's max_streak + keep rule (correct.c:478-497, 557-569) on the oracle's second filter"""
+    oracle's max_streak + keep rule (correct.c:478-497, 557-569) on the oracle's second filter.  q4 = 1: through k_query4 (four lanes fetch the
+    four dwords of a query's positions, two queries in flight -- the kernel filters of 4 GiB and more take) whatever the filter's size."""
     import ctypes as C
+    monkeypatch.setenv("BFCG_QUERY4", q4)
     prm, seq, qual, off, cuts, kw = _draw(13000 + seed)
     rng = np.random.default_rng(seed)
     n = len(off) - 1
