@@ -9,7 +9,7 @@
 static inline int bfcg_rec_dwords(int k, int rec_n) { const int bits = 2 * k - rec_n + 33; return bits <= 96 ? 3 : bits <= 128 ? 4 : 5; }
 static inline int bfcg_tile_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
 /* positions per tile of stage A (k_hist1 / k_scatter1: bfcg_kernels.hip, S1<RW>) */
-static inline int bfcg_tile1_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
+static inline int bfcg_tile1_of_rw(int rw) { return rw == 3 ? 4096 : 3072; }
 #define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */
 #define BFCG_HO_MAX_PAGES 8 /* batches whose seen k-mers may wait in a region's hand-over log for ONE commit pass (k_commit_seg's page arrays, the context's marks) */
 /* The measurement switches (KParams.ablate = BFCG_ABLATE: skip the stores / the cursor atomics / the hashing of k_scatter1, phase clocks in

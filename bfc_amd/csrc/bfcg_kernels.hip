@@ -1978,9 +1978,19 @@ __global__ __launch_bounds__(BT) void k_hash_only(KParams P, const uint8_t *__re
 //   k_streak: max_streak (correct.c:478-497) and the keep/trim rule (correct.c:557-569), one lane per read
 
 // COOP: for filters far larger than the caches (see below); otherwise every lane gathers for itself, first bit first
+// The query kernels' result is ONE BIT per stream position -- the k-mer ending there is in the filter -- written as the wave's ballot: 64 positions,
+// one 8-byte store (a tile starts at a multiple of 64 and a wave takes 64 consecutive positions, so word e / 64 is the wave's own).  Round 1-4 wrote a
+// byte per position (none / miss / hit) and k_streak, one lane per read, fetched them back byte by byte at a stride of a read's length: 83 of the
+// 174 ms of c5's trim pass per 41 M reads went into that kernel (profiles/round5_trim.md).  All a read's longest streak needs is the hit bit
+// (correct.c:483-495: anything that is not a hit -- a miss, a position without a k-mer -- restarts the run).
+__device__ __forceinline__ void query_emit(unsigned long long *__restrict__ bits, int64_t e, int64_t n_pos, bool hit)
+{
+	const unsigned long long v = __ballot(hit);
+	if ((threadIdx.x & 63) == 0 && e < n_pos) bits[e >> 6] = v; // (positions at and beyond n_pos vote 0)
+}
 template <typename W, int TILE, int BT, bool COOP>
 __global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restrict__ seq, int64_t n_pos,
-                                              const unsigned int *__restrict__ bloom, uint8_t *__restrict__ flags)
+                                              const unsigned int *__restrict__ bloom, unsigned long long *__restrict__ flags)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2;
 	__shared__ uint32_t planes[4 * PW];
@@ -1999,10 +2009,9 @@ __global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restri
 		for (int j = 0; j < TILE / BT; ++j) {
 			const int r = j * BT + threadIdx.x;
 			const int64_t e = tile * TILE + r;
-			if (e >= n_pos) continue;
 			W y0, y1; bool hi;
 			uint8_t fl = 0;
-			if (kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
+			if (e < n_pos && kmer_at<W, TILE>(planes, r, P.k, m, y0, y1, hi)) {
 				BloomAddr a = bloom_addr(bloom_hash<W>(P.k, y0, y1, m), P.bf_shift);
 				const unsigned int *blk = bloom + a.blk * 16;
 				uint32_t z = a.h1;
@@ -2012,7 +2021,7 @@ __global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restri
 				if (cnt) for (int t = 1; t < P.n_hashes; ++t) { b = bloom_next(z, a.h2); cnt += (blk[b >> 5] >> (b & 31)) & 1u; }
 				fl = cnt == (uint32_t)P.n_hashes ? 2 : 1;
 			}
-			flags[e] = fl;
+			query_emit(flags, e, n_pos, fl == 2);
 		}
 		return;
 	}
@@ -2048,7 +2057,7 @@ __global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restri
 			part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
 			if (member == p) my_cnt = part;
 		}
-		if (e < n_pos) flags[e] = !(my_h >> 18) ? 0 : my_cnt == (uint32_t)P.n_hashes ? 2 : 1;
+		query_emit(flags, e, n_pos, (my_h >> 18) && my_cnt == (uint32_t)P.n_hashes);
 	}
 }
 
@@ -2064,7 +2073,7 @@ __global__ __launch_bounds__(BT) void k_query(KParams P, const uint8_t *__restri
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 template <typename W, int TILE, int BT>
 __global__ __launch_bounds__(BT) void k_query4(KParams P, const uint8_t *__restrict__ seq, int64_t n_pos,
-                                               const unsigned int *__restrict__ bloom, uint8_t *__restrict__ flags)
+                                               const unsigned int *__restrict__ bloom, unsigned long long *__restrict__ flags)
 {
 	constexpr int PW = (TILE + 64) / 32 + 2, S = TILE / BT;
 	static_assert(S % 2 == 0, "queries are taken in pairs");
@@ -2108,7 +2117,7 @@ __global__ __launch_bounds__(BT) void k_query4(KParams P, const uint8_t *__restr
 			if (member == p) mine = t;
 		}
 		const int64_t e = tile * TILE + j * BT + (int)threadIdx.x;
-		if (e < n_pos) flags[e] = !(pb >> 31) ? 0 : mine ? 2 : 1;
+		query_emit(flags, e, n_pos, (pb >> 31) && mine);
 	};
 	uint32_t blkA, paA, pbA, wA[4], bitA[4], blkB, paB, pbB, wB[4], bitB[4];
 	own(0, blkA, paA, pbA);
@@ -2123,17 +2132,39 @@ __global__ __launch_bounds__(BT) void k_query4(KParams P, const uint8_t *__restr
 	}
 }
 
-__global__ __launch_bounds__(256) void k_streak(int k, float min_frac, const uint8_t *__restrict__ flags, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(256) void k_streak(int k, float min_frac, const unsigned long long *__restrict__ bits, const uint64_t *__restrict__ off,
                                                 uint64_t n_reads, int32_t *__restrict__ out_start, int32_t *__restrict__ out_end)
 {
 	const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
 	if (r >= n_reads) return;
 	const uint64_t p0 = off[r];
 	const int len = (int)(off[r + 1] - p0) - 1;
+	// correct.c:483-495 on the hit bits: a hit extends the run, anything else restarts it behind itself; t = run length << 32 | run start, the maximum
+	// keeps the longest run and of equal ones the later.  The read's bits are taken 64 at a time and walked RUN by run (count-trailing-zeros on the
+	// word and on its complement): a handful of steps per read instead of one per position, no memory access inside.
 	unsigned long long mx = 0, t = 0;
-	for (int i = 0; i < len; ++i) { // correct.c:483-495 on the flag stream: a hit extends the run, anything else restarts it after i
-		if (flags[p0 + i] == 2) t += 1ULL << 32; else t = (unsigned long long)i + 1;
-		mx = mx > t ? mx : t;
+	for (int i = 0; i < len; i += 64) {
+		const uint64_t bp = p0 + (uint64_t)i;
+		const unsigned long long lo = bits[bp >> 6], hi = (bp & 63) ? bits[(bp >> 6) + 1] : 0ULL; // (the word behind the read's last may be stale: masked by nb)
+		const int sft = (int)(bp & 63), nb = len - i < 64 ? len - i : 64;
+		unsigned long long w = sft ? (lo >> sft) | (hi << (64 - sft)) : lo;
+		if (nb < 64) w &= (1ULL << nb) - 1ULL;
+		int pos = 0;
+		while (pos < nb) {
+			const unsigned long long x = w >> pos;
+			if (x & 1ULL) { // a run of hits
+				int ones = ~x ? __builtin_ctzll(~x) : 64;
+				if (ones > nb - pos) ones = nb - pos;
+				t += (unsigned long long)ones << 32;
+				mx = mx > t ? mx : t;
+				pos += ones;
+			} else { // everything up to the next hit restarts the run behind it
+				int zeros = x ? __builtin_ctzll(x) : 64;
+				if (zeros > nb - pos) zeros = nb - pos;
+				pos += zeros;
+				t = (unsigned long long)(i + pos);
+			}
+		}
 	}
 	int st = -1, en = -1;
 	if ((mx >> 32) && (double)((mx >> 32) + (unsigned long long)k) / len > min_frac) { // correct.c:557 (min_frac is a float, bfc.h:21)
@@ -2234,8 +2265,10 @@ static inline int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < ca
 // k_scatter1's tile by record size: 4096 positions, 3072 for 20-byte records -- two workgroups of 512 threads per CU (56 / 73 / 68 KiB of LDS).
 // (Three workgroups of 3584 positions, 768 threads on 4608, 1024 threads, one memory-in wave beside seven hashing waves: all measured, none
 // faster -- the kernel's floor is its skeleton of LDS ranks, scan, staging and barriers, not the hashing: DESIGN.md section 6b.)
-template <int RW> struct S1 { static constexpr int BT = 512, TILE = RW == 5 ? 3072 : 4096; };
-static_assert(S1<3>::TILE == 4096 && S1<4>::TILE == 4096 && S1<5>::TILE == 3072, "bfcg_tile1_of_rw (bfcg_internal.h) sizes the host's buffers");
+// Round 5: 16-byte records take 3072 too -- with 2^10 level-1 buckets (config c5: k = 51, -b37) the stage of 4096 records, their bucket bytes and
+// the counters were 92 KiB: ONE workgroup per CU, 17 ps per k-mer against 8 for c3's 12-byte records; 3072 positions: 75 KiB, two per CU.
+template <int RW> struct S1 { static constexpr int BT = 512, TILE = RW == 3 ? 4096 : 3072; };
+static_assert(S1<3>::TILE == 4096 && S1<4>::TILE == 3072 && S1<5>::TILE == 3072, "bfcg_tile1_of_rw (bfcg_internal.h) sizes the host's buffers");
 #define TILE2 BFCG_TILE2
 #define BT2 512
 
@@ -2548,23 +2581,23 @@ void run_query(const KParams &P, const uint8_t *seq, int64_t n_pos, const void *
 	const char *eq = getenv("BFCG_QUERY4"); // (1: k_query4 whatever the filter's size -- tests; 0: never -- A/B; read per call: tests switch it)
 	const int q4 = eq ? atoi(eq) : -1;
 	if (P.n_hashes == 4 && P.bf_shift <= 41 && (q4 == 1 || (q4 != 0 && P.bf_shift >= 35))) {
-		if (P.k <= 32) hipLaunchKernelGGL((k_query4<uint32_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
-		else hipLaunchKernelGGL((k_query4<uint64_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+		if (P.k <= 32) hipLaunchKernelGGL((k_query4<uint32_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, reinterpret_cast<unsigned long long *>(flags));
+		else hipLaunchKernelGGL((k_query4<uint64_t, TILE1, BT1>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, reinterpret_cast<unsigned long long *>(flags));
 		return;
 	}
 	const bool coop = P.bf_shift >= 35; // 4 GiB and more: measured 13.8 -> 21.2 G queries/s on 16 GiB, but 23.1 -> 21.9 on 1 GiB
 	if (P.k <= 32) {
-		if (coop) hipLaunchKernelGGL((k_query<uint32_t, TILE1, BT1, true>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
-		else hipLaunchKernelGGL((k_query<uint32_t, TILE1, BT1, false>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+		if (coop) hipLaunchKernelGGL((k_query<uint32_t, TILE1, BT1, true>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, reinterpret_cast<unsigned long long *>(flags));
+		else hipLaunchKernelGGL((k_query<uint32_t, TILE1, BT1, false>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, reinterpret_cast<unsigned long long *>(flags));
 	} else {
-		if (coop) hipLaunchKernelGGL((k_query<uint64_t, TILE1, BT1, true>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
-		else hipLaunchKernelGGL((k_query<uint64_t, TILE1, BT1, false>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, flags);
+		if (coop) hipLaunchKernelGGL((k_query<uint64_t, TILE1, BT1, true>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, reinterpret_cast<unsigned long long *>(flags));
+		else hipLaunchKernelGGL((k_query<uint64_t, TILE1, BT1, false>), dim3(g), dim3(BT1), 0, st, P, seq, n_pos, (const unsigned int *)bloom, reinterpret_cast<unsigned long long *>(flags));
 	}
 }
 void run_streak(int k, float min_frac, const uint8_t *flags, const uint64_t *off, uint64_t n_reads, int32_t *out_start, int32_t *out_end, hipStream_t st)
 {
 	if (n_reads == 0) return;
-	hipLaunchKernelGGL(k_streak, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, k, min_frac, flags, off, n_reads, out_start, out_end);
+	hipLaunchKernelGGL(k_streak, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, k, min_frac, reinterpret_cast<const unsigned long long *>(flags), off, n_reads, out_start, out_end);
 }
 
 void run_kcov(const KParams &P, const uint8_t *seq, int64_t n_pos, int min_occ, const void *tab, uint8_t *flags, uint16_t *out, hipStream_t st)
