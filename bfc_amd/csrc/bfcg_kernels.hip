@@ -233,21 +233,22 @@ template <> struct Rec<3> {
 	}
 };
 template <> struct Rec<4> {
+	// On two 64-bit halves (round 5; the 128-bit arithmetic it replaces compiled into chains of selects around variable funnel shifts): records are
+	// 16 bytes iff 96 < a + k + 33 <= 128, i.e. 64 <= a + k <= 95 with 1 <= a <= 63 -- y1 straddles the halves, the quality flag (bit a + k) and
+	// the index (from bit a + k + 1) lie in the upper one.
 	static __device__ __forceinline__ void pack(RecW<4> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
 	{
-		typedef unsigned __int128 u128;
-		const u128 v = (u128)y0_drop(g, y0) | ((u128)y1 << g.a) | ((u128)hi << (g.a + g.k)) | ((u128)idx << (g.a + g.k + 1));
-		const uint64_t lo = (uint64_t)v, hi64 = (uint64_t)(v >> 64);
+		const uint64_t lo = y0_drop(g, y0) | (y1 << g.a);
+		const uint64_t hi64 = (y1 >> (64 - g.a)) | ((uint64_t)hi << (g.a + g.k - 64)) | ((uint64_t)idx << (g.a + g.k - 63));
 		r.d[0] = (uint32_t)lo; r.d[1] = (uint32_t)(lo >> 32); r.d[2] = (uint32_t)hi64; r.d[3] = (uint32_t)(hi64 >> 32);
 	}
 	static __device__ __forceinline__ void unpack(const RecW<4> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
 	{
-		typedef unsigned __int128 u128;
-		const u128 v = (u128)(r.d[0] | ((uint64_t)r.d[1] << 32)) | ((u128)(r.d[2] | ((uint64_t)r.d[3] << 32)) << 64);
-		y0 = y0_join(g, (uint64_t)v & ((1ULL << g.a) - 1), imp);
-		y1 = (uint64_t)(v >> g.a) & (g.k >= 64 ? ~0ULL : (1ULL << g.k) - 1);
-		hi = (uint64_t)(v >> (g.a + g.k)) & 1;
-		idx = (uint32_t)(v >> (g.a + g.k + 1));
+		const uint64_t lo = r.d[0] | ((uint64_t)r.d[1] << 32), hi64 = r.d[2] | ((uint64_t)r.d[3] << 32);
+		y0 = y0_join(g, lo & ((1ULL << g.a) - 1), imp);
+		y1 = ((lo >> g.a) | (hi64 << (64 - g.a))) & ((1ULL << g.k) - 1);
+		hi = (hi64 >> (g.a + g.k - 64)) & 1;
+		idx = (uint32_t)(hi64 >> (g.a + g.k - 63));
 	}
 };
 template <> struct Rec<5> {
@@ -2419,8 +2420,8 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
 		if (B.cap2) { // one pass: region slabs and cursors
 			hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
-			if (RW == 3 && scatter2_fast(P))
-				hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true, RW == 3>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+			if ((RW == 3 || RW == 4) && scatter2_fast(P)) // (round 5: 16-byte records too -- their first word holds the same low bits of y0)
+				hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true, RW == 3 || RW == 4>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
 				                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
 			else
 			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
@@ -2544,7 +2545,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	}
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
-	if (RW == 3) { e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true, RW == 3>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e; }
+	if (RW == 3 || RW == 4) { e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true, RW == 3 || RW == 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e; }
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

@@ -429,7 +429,12 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * g->row_words, hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
 	std::vector<ncclComm_t> comms((size_t)n_local, (ncclComm_t)0);
 	if (g->xp == XP_RCCL && !g->mp && n_ranks > 1) {
-		if (ncclCommInitAll(comms.data(), n_local, devices) != ncclSuccess) { bfcg_set_error("ncclCommInitAll failed"); bfcg_group_destroy(g); return NULL; }
+		const ncclResult_t nr = ncclCommInitAll(comms.data(), n_local, devices);
+		if (nr != ncclSuccess) {
+			char msg[384];
+			snprintf(msg, sizeof(msg), "ncclCommInitAll failed: %s (%s)", ncclGetErrorString(nr), ncclGetLastError(NULL));
+			bfcg_set_error(msg); bfcg_group_destroy(g); return NULL;
+		}
 	}
 	for (int i = 0; i < n_local; ++i) {
 		rank_t &R = g->r[i];
@@ -462,7 +467,12 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 			if (!g->mp) R.comm = comms[i];
 			else {
 				ncclUniqueId id; memcpy(&id, uid, BFCG_UID_BYTES);
-				if (ncclCommInitRank(&R.comm, n_ranks, id, R.rank) != ncclSuccess) { bfcg_set_error("ncclCommInitRank failed"); bfcg_group_destroy(g); return NULL; }
+				const ncclResult_t nr = ncclCommInitRank(&R.comm, n_ranks, id, R.rank);
+				if (nr != ncclSuccess) { // (say why: two ranks of one communicator on the same device are refused, for one -- scripts/probes/rccl_same_device.py)
+					char msg[384];
+					snprintf(msg, sizeof(msg), "ncclCommInitRank failed: %s (%s)", ncclGetErrorString(nr), ncclGetLastError(NULL));
+					R.comm = 0; bfcg_set_error(msg); bfcg_group_destroy(g); return NULL;
+				}
 			}
 		}
 	}

@@ -154,11 +154,11 @@ def test_c5_parameters(gpu_lib):
 @pytest.mark.skipif("c5e" not in BASE, reason="tests/golden/baseline.json has no c5e entry (make_baseline_goldens.py c5e: ~1.2 h of one core)")
 def test_c5_eighth_full_geometry(gpu_lib):
     """An EIGHTH of config c5 itself: the 77.5 M reads of c4e at c5's parameters -- `-s 3g -k51 -1`: k=51, -b37, two 16 GiB filters,
-    2^20 regions, 10+10 scatter levels, 16-byte records, k_bloom3fm -- in calls of 8 M reads as scripts/c4_run.py and bench.py's secondary `c5e`
+    2^20 regions, 10+10 scatter levels, 16-byte records, k_bloom3fm -- in calls of 16 M reads as scripts/c4_run.py and bench.py's secondary `c5e`
     submit them: k-mer / high / seen totals and BOTH filters' popcount + FNV-1a equal the reference's (tests/golden/baseline.json[c5e])."""
     e = BASE["c5e"]
     rs = gen.ReadSet(**e["gen"])
-    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 8_388_608, filter_mode=1)
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 16_777_216, filter_mode=1)
     assert g.mg_info()["rec_bytes"] == 16
     _check_against(g, e)
     assert g.stats()["slow_buckets"] == 0
