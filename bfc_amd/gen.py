@@ -66,6 +66,27 @@ class ReadSet:
             raise OSError("cannot write " + fn)
         return fn
 
+    def fastq_parallel(self, fn, r0=0, r1=None, threads=16):
+        """The same file as fastq(), written by `threads` threads (ranges of reads into part files, appended in order): the single-threaded writer
+        makes ~160 MB/s, 100 s for config c3's 15.6 GB."""
+        import shutil
+        from concurrent.futures import ThreadPoolExecutor
+        r1 = self.n_reads if r1 is None else min(int(r1), self.n_reads)
+        threads = max(1, min(int(threads), (r1 - r0 + 999_999) // 1_000_000))
+        if threads == 1:
+            return self.fastq(fn, r0, r1)
+        per = (r1 - r0 + threads - 1) // threads
+        parts = [(r0 + i * per, min(r1, r0 + (i + 1) * per), "%s.part%d" % (fn, i)) for i in range(threads) if r0 + i * per < r1]
+        with ThreadPoolExecutor(len(parts)) as ex:  # (ctypes releases the GIL around the C writer)
+            list(ex.map(lambda t: self.fastq(t[2], t[0], t[1]), parts))
+        os.replace(parts[0][2], fn)
+        with open(fn, "ab") as out:
+            for _, _, pf in parts[1:]:
+                with open(pf, "rb") as f:
+                    shutil.copyfileobj(f, out, 64 << 20)
+                os.unlink(pf)
+        return fn
+
 
 # named fixtures / configs (SURVEY B.2, section 8d)
 FIXTURES = {
