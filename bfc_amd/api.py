@@ -414,7 +414,7 @@ class GpuGroup:
         out = (C.c_int * 6)()
         self.L.bfcg_group_info(self.g, out)
         return dict(n_ranks=out[0], n_local=out[1], transport={1: "rccl", 2: "peer"}.get(out[2], out[2]), rec_bytes=out[3], nb1=out[4], first_rank=out[5],
-                    slab_mode=bool(self.L.bfcg_group_slab_mode(self.g)))
+                    slab_mode=bool(self.L.bfcg_group_slab_mode(self.g)), lazy_batches=int(self.L.bfcg_group_lazy_batches(self.g)))
 
     def ctx(self, i):
         """Local rank i's counting context as a GpuCounter view (owned by the group)."""

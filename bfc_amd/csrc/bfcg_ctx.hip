@@ -87,6 +87,8 @@ struct bfcg_ctx {
 	// the batches behind it on the device; the host then replays them, in order, through the two-pass partition and stays there until the next reset.
 	int onepass_ok, onepass;     // the buffers exist / the current run still uses the one-pass partition
 	uint32_t *op_cursor[2], *op_seg[2], *op_flags, *h_flags[2];
+	int unfinished, unfinished_mg;     // bfcg_mg_process_slabs_dev has enqueued a stage B that bfcg_mg_process_finish has not seen yet (and its entry in the replay queue)
+	uint32_t *h_rows[2]; int rows_slot; // a group's slab mode without the host's wait: the host's copy of a stage A's rows (bfcg_mg_scatter_slabs_async), the slot of the last one
 	uint32_t op_cap; uint64_t op_min_pos;
 	uint32_t *cnt2; uint32_t cap2; uint64_t recs2_n; // one-pass level 2 (region slabs); records recs2 / stream_out hold
 	struct opq_t { const uint8_t *seq, *qual; uint64_t n_pos; int slot; const void *recv; int mg; } opq[4]; int n_opq; // batches enqueued one-pass and not yet known to be clean
@@ -348,6 +350,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 			HIPCKN(hipMalloc(&c->op_seg[b], sizeof(uint32_t) * ((size_t)25 * nb1 + 8)));
 		}
 	}
+	if (c->mg_slab_ok) for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_rows[b], sizeof(uint32_t) * ((size_t)8 * nb1 + 2 * (size_t)n_ranks)));
 	if (c->onepass_ok || c->mg_op2_ok || c->mg_slab_ok) {
 		for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_flags[b], 4 * sizeof(uint32_t)));
 		// per batch slot b: op_flags[4 b + 0] a level-1 slab overflowed (raised on stage A's stream), [4 b + 2] a region's slab (stage B's stream);
@@ -453,7 +456,7 @@ extern "C" void bfcg_destroy(bfcg_ctx_t *c)
 	(void)hipFree(c->stream_out); (void)hipFree(c->B.seg_tab); (void)hipFree(c->seg_spare);
 	(void)hipFree(c->ho); (void)hipFree(c->ho_cur); (void)hipFree(c->ho_mark); (void)hipFree(c->ho_keys);
 	for (int b = 0; b < 2; ++b) if (c->h_ho_keys[b]) (void)hipHostFree(c->h_ho_keys[b]);
-	for (int b = 0; b < 2; ++b) { (void)hipFree(c->op_cursor[b]); (void)hipFree(c->op_seg[b]); if (c->h_flags[b]) (void)hipHostFree(c->h_flags[b]); }
+	for (int b = 0; b < 2; ++b) { (void)hipFree(c->op_cursor[b]); (void)hipFree(c->op_seg[b]); if (c->h_flags[b]) (void)hipHostFree(c->h_flags[b]); if (c->h_rows[b]) (void)hipHostFree(c->h_rows[b]); }
 	(void)hipFree(c->op_flags); (void)hipFree(c->cnt2); for (int i = 0; i < 4; ++i) free(c->mg_seg[i]);
 	(void)hipFree(c->B.tab_ovf); (void)hipFree(c->B.pool); (void)hipFree(c->B.seen_out); (void)hipFree(c->B.agg_out); (void)hipFree(c->B.agg_cnt);
 	(void)hipHostFree(c->h_stats); (void)hipHostFree(c->h_snap[0]); (void)hipHostFree(c->h_snap[1]); (void)hipFree(c->d_seg); if (c->h_seg) (void)hipHostFree(c->h_seg);
@@ -895,25 +898,29 @@ static int mg_scatter2(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qua
 extern "C" int bfcg_mg_scatter(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts) { return mg_scatter2(c, d_seq, d_qual, n_pos, d_send, counts, 0); }
 // (a batch whose one-pass stage A overflowed a slab, repeated: its k-mers were counted the first time)
 extern "C" int bfcg_mg_scatter_again(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts) { return mg_scatter2(c, d_seq, d_qual, n_pos, d_send, counts, 1); }
+// A group of ONE rank has no exchange for stage A of the next batch to run beside: its kernels follow stage B on the same stream wherever a
+// single GPU's do (c->pipeline: kernels sized to fill the chip fight for its CUs -- DESIGN.md section 6b, c3 on two streams).
+static inline hipStream_t mg_stage_a_stream(bfcg_ctx_t *c) { return c->n_ranks == 1 && !c->pipeline ? c->st : c->stA; }
 static int mg_scatter2(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts, int no_kstats)
 {
 	const int nb1 = 1 << c->P.F1, b = c->cur;
+	const hipStream_t sA = mg_stage_a_stream(c);
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
 	if (n_pos == 0) { // nothing to contribute to this global batch: keep the timing events defined
-		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], c->stA));
+		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], sA));
 		memset(counts, 0, sizeof(uint32_t) * nb1); return 0;
 	}
 	BatchBufs Bt = c->B;
 	Bt.rows1 = c->rows1[b]; Bt.chunk1 = c->chunk1[b]; Bt.start1 = c->start1[b]; Bt.row_base = Bt.start1 + nb1 + 1;
-	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, c->stA) != 0) return -1;
+	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, sA) != 0) return -1;
 	KParams Pa = c->P;
 	Pa.no_kstats = no_kstats;
-	run_stage_a(Pa, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
+	run_stage_a(Pa, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, sA, c->evt[b]);
 	HIPCK(hipGetLastError());
 	uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (nb1 + 1));
-	hipError_t e = hipMemcpyAsync(tmp, Bt.start1, sizeof(uint32_t) * (nb1 + 1), hipMemcpyDeviceToHost, c->stA);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stA);
+	hipError_t e = hipMemcpyAsync(tmp, Bt.start1, sizeof(uint32_t) * (nb1 + 1), hipMemcpyDeviceToHost, sA);
+	if (e == hipSuccess) e = hipStreamSynchronize(sA);
 	if (e != hipSuccess) { free(tmp); return set_err("reading the level-1 bucket starts failed: %s", hipGetErrorString(e)); }
 	for (int i = 0; i < nb1; ++i) counts[i] = tmp[i + 1] - tmp[i];
 	free(tmp);
@@ -930,27 +937,74 @@ extern "C" int bfcg_mg_slab_info(bfcg_ctx_t *c, uint32_t out[2]) { out[0] = c->o
 extern "C" int bfcg_mg_scatter_slabs(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *fills, int *overflow)
 {
 	const int nb1 = 1 << c->P.F1, nb_loc = nb1 >> c->log2n, b = c->cur;
+	const hipStream_t sA = mg_stage_a_stream(c);
 	*overflow = 0;
 	if (!c->mg_slab_ok || !c->op_cursor[b]) return set_err("this context has no slab mode");
 	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
 	HIPCK(hipSetDevice(c->prm.device));
 	if (n_pos == 0) { // nothing to contribute to this global batch: keep the timing events defined
-		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], c->stA));
+		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], sA));
 		memset(fills, 0, sizeof(uint32_t) * (size_t)nb1 * 8); return 0;
 	}
 	BatchBufs Bt = c->B;
 	Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags + 4 * b; Bt.op_cap = c->op_cap; Bt.cap2 = c->cap2;
 	Bt.op_own_lo = (uint32_t)c->rank * (uint32_t)nb_loc; Bt.op_own_n = (uint32_t)nb_loc; Bt.op_own_delta = own_delta;
-	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, c->stA) != 0) return -1;
-	run_stage_a_onepass(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, c->stA, c->evt[b]);
+	if (same_block_offset(c, b, d_seq, &d_qual, n_pos, sA) != 0) return -1;
+	run_stage_a_onepass(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, sA, c->evt[b]);
 	HIPCK(hipGetLastError());
 	std::vector<uint32_t> tmp((size_t)8 * nb1);
-	hipError_t e = hipMemcpyAsync(tmp.data(), Bt.op_seg + (size_t)8 * nb1, sizeof(uint32_t) * (size_t)8 * nb1, hipMemcpyDeviceToHost, c->stA); // the segments' ends (k_seg_setup)
-	if (e == hipSuccess) e = hipMemcpyAsync(c->h_flags[b], Bt.op_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stA);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stA);
+	hipError_t e = hipMemcpyAsync(tmp.data(), Bt.op_seg + (size_t)8 * nb1, sizeof(uint32_t) * (size_t)8 * nb1, hipMemcpyDeviceToHost, sA); // the segments' ends (k_seg_setup)
+	if (e == hipSuccess) e = hipMemcpyAsync(c->h_flags[b], Bt.op_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, sA);
+	if (e == hipSuccess) e = hipStreamSynchronize(sA);
 	if (e != hipSuccess) return set_err("reading the slabs' fill failed: %s", hipGetErrorString(e));
 	*overflow = c->h_flags[b][0] != 0;
 	for (int seg = 0; seg < 8 * nb1; ++seg) fills[seg] = *overflow ? 0u : tmp[seg] - (uint32_t)seg * c->op_cap; // (k_seg_setup: the slab of segment seg starts at seg x capacity)
+	return 0;
+}
+
+// The same stage A WITHOUT the host's wait (round 5: a group whose ranks are all in one process keeps the host out of the batch's loop).  The fills
+// stay on the device: k_pack_rows lays them out as one row per destination in d_rows_out (n_ranks rows of row_w = nb_loc x 8 + 2 words: the fills of
+// the destination's slabs, then this stage A's overflow flag), which the caller sends beside the blocks; a copy of the rows is on its way to the
+// host.  bfcg_mg_scatter_slabs_wait -- called when the exchange and the owner's stage B are already enqueued -- waits for that copy and hands
+// out what bfcg_mg_scatter_slabs would have.  *done: recorded on stage A's stream behind all of it (the exchange waits for it).
+extern "C" int bfcg_mg_row_words(bfcg_ctx_t *c) { return (((1 << c->P.F1) >> c->log2n) * 8) + 2; }
+extern "C" int bfcg_mg_scatter_slabs_async(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *d_rows_out, hipEvent_t *done)
+{
+	const int nb1 = 1 << c->P.F1, nb_loc = nb1 >> c->log2n, b = c->cur, row_w = nb_loc * 8 + 2;
+	const hipStream_t sA = mg_stage_a_stream(c);
+	if (!c->mg_slab_ok || !c->op_cursor[b] || !c->h_rows[b]) return set_err("this context has no slab mode");
+	if (n_pos > c->prm.max_batch_pos) return set_err("batch of %llu positions exceeds max_batch_pos=%llu", (unsigned long long)n_pos, (unsigned long long)c->prm.max_batch_pos);
+	HIPCK(hipSetDevice(c->prm.device));
+	const size_t row_bytes = sizeof(uint32_t) * (size_t)c->n_ranks * row_w;
+	if (n_pos == 0) { // nothing to contribute to this global batch: rows of zeros; keep the timing events defined
+		for (int i = 0; i < 3; ++i) HIPCK(hipEventRecord(c->evt[b][i], sA));
+		HIPCK(hipMemsetAsync(d_rows_out, 0, row_bytes, sA));
+	} else {
+		BatchBufs Bt = c->B;
+		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags + 4 * b; Bt.op_cap = c->op_cap; Bt.cap2 = c->cap2;
+		Bt.op_own_lo = (uint32_t)c->rank * (uint32_t)nb_loc; Bt.op_own_n = (uint32_t)nb_loc; Bt.op_own_delta = own_delta;
+		if (same_block_offset(c, b, d_seq, &d_qual, n_pos, sA) != 0) return -1;
+		run_stage_a_onepass(c->P, Bt, d_seq, d_qual, (int64_t)n_pos, (uint64_t *)d_send, sA, c->evt[b]);
+		run_pack_rows(c->P, Bt, c->n_ranks, (uint32_t)row_w, d_rows_out, sA);
+		HIPCK(hipGetLastError());
+	}
+	HIPCK(hipMemcpyAsync(c->h_rows[b], d_rows_out, row_bytes, hipMemcpyDeviceToHost, sA));
+	HIPCK(hipEventRecord(c->evA[b], sA));
+	c->rows_slot = b;
+	*done = c->evA[b];
+	return 0;
+}
+// fills[8 * 2^F1] (bucket-major, XCD-minor, as bfcg_mg_scatter_slabs) and *overflow of the stage A enqueued last
+extern "C" int bfcg_mg_scatter_slabs_wait(bfcg_ctx_t *c, uint32_t *fills, int *overflow)
+{
+	const int nb1 = 1 << c->P.F1, nb_loc = nb1 >> c->log2n, b = c->rows_slot, row_w = nb_loc * 8 + 2;
+	HIPCK(hipSetDevice(c->prm.device));
+	HIPCK(hipEventSynchronize(c->evA[b]));
+	int ovf = 0;
+	for (int p = 0; p < c->n_ranks; ++p) ovf |= c->h_rows[b][(size_t)p * row_w + (size_t)nb_loc * 8] != 0;
+	for (int p = 0; p < c->n_ranks; ++p)
+		for (int i = 0; i < nb_loc * 8; ++i) fills[(size_t)p * nb_loc * 8 + i] = ovf ? 0u : c->h_rows[b][(size_t)p * row_w + i];
+	*overflow = ovf;
 	return 0;
 }
 
@@ -1036,6 +1090,80 @@ static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg
 	HIPCK(hipGetLastError());
 	c->used[b] = 1;
 	++c->n_batches;
+	return finalise_previous(c, b);
+}
+
+// Stage B of a global batch whose sizes the host does not have yet (slab mode, all ranks in one process): d_rows_in holds every source's row for
+// this rank (n_ranks rows of bfcg_mg_row_words words, written by the exchange that `wait` orders this behind); k_seg_setup_mg turns them into the
+// segment arrays on the device.  rec_bound: what the batch can hold at most (sizes the level-2 grid; surplus workgroups exit).  The batch is
+// enqueued and NOT finalised: bfcg_mg_process_finish does that once the caller has the sizes (the same call of the group, a moment later).
+// may this rank take a batch that way right now?  (level 2 in one pass -- its region slabs bound what a batch can write whatever the sizes turn out
+// to be --, no order stamps, no per-position debug output)
+extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c) { return c->mg_slab_ok && c->mg_op2 && c->mg_op2_allowed && c->cap2 && !c->B.seen_out && !c->P.track && c->h_rows[0] != 0; }
+extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, hipEvent_t *wait, int n_wait)
+{
+	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, spb = N * 8, n_seg = nb_loc * spb, b = c->cur;
+	HIPCK(hipSetDevice(c->prm.device));
+	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
+	if (words > c->seg_words) return set_err("internal: %zu segment words, room for %zu", words, c->seg_words);
+	if (!slab_cap || !bfcg_mg_async_ok(c)) return set_err("internal: bfcg_mg_process_slabs_dev needs slabs, a one-pass level 2 and no debug_seen");
+	if (rec_bound > c->recv_cap) rec_bound = c->recv_cap;
+	uint32_t *d = c->d_seg + (size_t)b * c->seg_words;
+	for (int i = 0; i < n_wait; ++i) HIPCK(hipStreamWaitEvent(c->st, wait[i], 0));
+	HIPCK(hipEventRecord(c->evt[b][6], c->st));
+	run_seg_setup_mg(c->P, c->rw / 4, d_rows_in, (uint32_t)(nb_loc * 8 + 2), N, slab_cap, d, nullptr, c->st);
+	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
+	if (use_stream(c) != 0 || ensure_agg(c) != 0) return -1;
+	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;
+	BatchBufs Bt = c->B;
+	const int op2_run = c->mg_op2 && c->mg_op2_allowed && c->cap2;
+	const int op2 = op2_run && rec_bound >= (uint64_t)8 << c->P.F >> c->log2n;
+	if (op2_run) Bt.op_sticky = c->op_flags + OP_STICKY;
+	if (op2) {
+		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2; Bt.op_flags = c->op_flags + 4 * b;
+		HIPCK(hipMemsetAsync(Bt.op_flags, 0, 4 * sizeof(uint32_t), c->st));
+	}
+	if (handover_begin(c, Bt, b, op2, c->call_no + 1) != 0) return -1;
+	KParams Pm = c->P;
+	Pm.dedupe = dedupe_hint(c);
+	warm_tables(c, Pm);
+	run_stage_b(Pm, Bt, (const uint64_t *)d_recv, d, d + n_seg, n_seg, spb, d + 2 * n_seg, d + 3 * n_seg + 1, rec_bound, c->st, c->evt[b]);
+	if (handover_end(c, Bt, b) != 0) return -1;
+	if (op2_run) {
+		HIPCK(hipMemcpyAsync(c->h_flags[b] + 1, c->op_flags + OP_STICKY, sizeof(uint32_t), hipMemcpyDeviceToHost, c->st));
+		if (c->n_opq == 4) return set_err("internal: one-pass queue overflow");
+		int free_i = 0;
+		for (;; ++free_i) { int used = 0; for (int i = 0; i < c->n_opq; ++i) used |= c->opq[i].mg == free_i + 1; if (!used) break; }
+		memset(c->mg_seg[free_i], 0, sizeof(uint32_t) * (size_t)N * nb_loc * 8); c->mg_seg_slab[free_i] = 1; // (the sizes follow: bfcg_mg_process_finish)
+		bfcg_ctx::opq_t &q = c->opq[c->n_opq++];
+		q.seq = q.qual = nullptr; q.n_pos = rec_bound; q.slot = b; q.recv = d_recv; q.mg = free_i + 1;
+		c->unfinished_mg = free_i + 1;
+	} else c->unfinished_mg = 0;
+	HIPCK(hipMemcpyAsync(c->h_snap[b], c->B.stats, sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1), hipMemcpyDeviceToHost, c->st));
+	c->slot_call[b] = ++c->call_no; c->slot_pos[b] = rec_bound;
+	HIPCK(hipEventRecord(c->evB[b], c->st));
+	HIPCK(hipGetLastError());
+	c->used[b] = 1;
+	++c->n_batches;
+	c->unfinished = 1;
+	return 0;
+}
+// ... and the sizes have arrived on the host: fills[(s * nb_loc + k) * 8 + x] = records from source s in the slab of (owned bucket k, XCD x) -- kept
+// for a replay of this stage B (a region's slab may turn out too small one call later) --, then the batch BEFORE this one is finalised as
+// bfcg_mg_process_slabs does.
+extern "C" int bfcg_mg_process_finish(bfcg_ctx_t *c, const uint32_t *fills)
+{
+	if (!c->unfinished) return set_err("internal: no stage B waits for its sizes");
+	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, b = c->cur;
+	c->unfinished = 0;
+	uint64_t tot = 0;
+	for (size_t i = 0; i < (size_t)N * nb_loc * 8; ++i) tot += fills[i];
+	c->slot_pos[b] = tot;
+	if (c->unfinished_mg) {
+		memcpy(c->mg_seg[c->unfinished_mg - 1], fills, sizeof(uint32_t) * (size_t)N * nb_loc * 8);
+		for (int i = 0; i < c->n_opq; ++i) if (c->opq[i].mg == c->unfinished_mg) c->opq[i].n_pos = tot;
+		c->unfinished_mg = 0;
+	}
 	return finalise_previous(c, b);
 }
 

@@ -921,6 +921,66 @@ __global__ __launch_bounds__(1024) void k_seg_setup(KParams P, const uint32_t *_
 	if (t == nb1 - 1) { row_base[(size_t)nb1 * 8] = s_rows[t]; bucket_start[nb1] = s_recs[t]; }
 }
 
+// A rank of a group, slab mode without the host in the batch's loop (bfcg_mg.hip, round 5).
+// k_pack_rows (source, behind k_seg_setup): the fills of this rank's slabs as one ROW per destination -- rows[p * row_w + k * 8 + x] = records in
+// the slab of (bucket p * nb_loc + k, XCD x), rows[p * row_w + nb_loc * 8] = a slab of this stage A overflowed (nothing of it may be used) -- which
+// travels to rank p beside the block of slabs itself.
+__global__ __launch_bounds__(256) void k_pack_rows(const uint32_t *__restrict__ seg_end, const uint32_t *__restrict__ flags, int nb_loc, uint32_t cap, uint32_t row_w,
+                                                  uint32_t *__restrict__ rows)
+{
+	const uint32_t p = blockIdx.x, n = (uint32_t)nb_loc * 8u;
+	const uint32_t poison = flags[0];
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+		const uint32_t seg = p * n + i; // (global bucket * 8 + XCD: k_seg_setup's segment number; its slab starts at seg x capacity)
+		rows[(size_t)p * row_w + i] = poison ? 0u : seg_end[seg] - seg * cap;
+	}
+	if (threadIdx.x == 0) { rows[(size_t)p * row_w + n] = poison; rows[(size_t)p * row_w + n + 1] = 0u; }
+}
+// k_seg_setup_mg (owner): the rows of all N sources -> the segment arrays of this rank's level 2, as mg_process_any builds them on the host from
+// the sizes: segment ((k * N + s) * 8 + x) = the slab of (source s, owned bucket k, XCD x) at its fixed place ((s * nb_loc + k) * 8 + x) x cap of the
+// receive buffer.  One workgroup; thread t = k * N + s owns 8 segments (nb_loc x N = 2^F1 <= 1024 threads).  A source whose stage A overflowed
+// empties the whole batch (every rank sees the same rows, so every rank's stage B of this batch moves nothing; the host finds the flag when it
+// reads its own copy of the rows and repeats the batch through the two passes).  total[0] = records received (read with the batch's statistics).
+__global__ __launch_bounds__(1024) void k_seg_setup_mg(const uint32_t *__restrict__ rows, uint32_t row_w, int N, int nb_loc, uint32_t cap, int tile2,
+                                                       uint32_t *__restrict__ seg_beg, uint32_t *__restrict__ seg_end, uint32_t *__restrict__ row_base,
+                                                       uint32_t *__restrict__ bucket_start, unsigned long long *__restrict__ total)
+{
+	__shared__ uint32_t s_rows[1024], s_recs[1024];
+	__shared__ uint32_t s_poison;
+	const int t = threadIdx.x, nt = nb_loc * N, k = t / N, s = t - k * N;
+	if (t == 0) s_poison = 0;
+	__syncthreads();
+	if (t < N && rows[(size_t)t * row_w + (size_t)nb_loc * 8] != 0) s_poison = 1; // (benign race: every writer stores 1)
+	__syncthreads();
+	const bool poison = s_poison != 0;
+	uint32_t len[8], nrow = 0, recs = 0;
+#pragma unroll
+	for (int x = 0; x < 8; ++x) {
+		uint32_t l = 0;
+		if (t < nt && !poison) { l = rows[(size_t)s * row_w + (size_t)k * 8 + x]; if (l > cap) l = cap; }
+		len[x] = l; nrow += (l + tile2 - 1) / tile2; recs += l;
+	}
+	s_rows[t] = nrow; s_recs[t] = recs;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) {
+		const uint32_t a = t >= o ? s_rows[t - o] : 0, b = t >= o ? s_recs[t - o] : 0;
+		__syncthreads();
+		s_rows[t] += a; s_recs[t] += b;
+		__syncthreads();
+	}
+	if (t < nt) {
+		uint32_t r = s_rows[t] - nrow;
+		if (s == 0) bucket_start[k] = s_recs[t] - recs;
+#pragma unroll
+		for (int x = 0; x < 8; ++x) {
+			const uint32_t seg = (uint32_t)t * 8u + x, beg = (((uint32_t)s * (uint32_t)nb_loc + (uint32_t)k) * 8u + x) * cap;
+			seg_beg[seg] = beg; seg_end[seg] = beg + len[x]; row_base[seg] = r;
+			r += (len[x] + tile2 - 1) / tile2;
+		}
+	}
+	if (t == nt - 1) { row_base[(size_t)nt * 8] = s_rows[t]; bucket_start[nb_loc] = s_recs[t]; if (total) *total = s_recs[t]; }
+}
+
 __device__ __forceinline__ SegGeom seg_geom(const KParams &P) { SegGeom g; g.k = P.k; g.lo = P.seg_lo; g.hi = P.seg_hi; return g; }
 
 // ------------------------------------------------------------------------------------------
@@ -2513,6 +2573,18 @@ void run_stage_a(const KParams &P, const BatchBufs &B, const uint8_t *seq, const
 
 void run_stage_a_onepass(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint64_t *out1, hipStream_t st, hipEvent_t *ev)
 { DISPATCH_W(run_stage_a_onepass_t, P, B, seq, qual, n_pos, (uint32_t *)out1, st, ev); }
+
+// a group's slab mode without host sizes (kernels above): the source's rows behind its one-pass stage A; the owner's segment arrays from all sources' rows
+void run_pack_rows(const KParams &P, const BatchBufs &B, int n_ranks, uint32_t row_w, uint32_t *rows, hipStream_t st)
+{
+	const int nb1 = 1 << P.F1;
+	hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)n_ranks), dim3(256), 0, st, B.op_seg + (size_t)8 * nb1, B.op_flags, nb1 / n_ranks, B.op_cap, row_w, rows);
+}
+void run_seg_setup_mg(const KParams &P, int rw_dwords, const uint32_t *rows, uint32_t row_w, int n_ranks, uint32_t cap, uint32_t *seg, unsigned long long *total, hipStream_t st)
+{
+	const int nb1 = 1 << P.F1, nb_loc = nb1 / n_ranks, n_seg = nb1 * 8;
+	hipLaunchKernelGGL(k_seg_setup_mg, dim3(1), dim3(1024), 0, st, rows, row_w, n_ranks, nb_loc, cap, rw_dwords == 5 ? 3072 : TILE2, seg, seg + n_seg, seg + 2 * n_seg, seg + 3 * n_seg + 1, total);
+}
 
 void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
                  const uint32_t *row_base, const uint32_t *bucket_start, uint64_t n_rec_bound, hipStream_t st, hipEvent_t *ev)

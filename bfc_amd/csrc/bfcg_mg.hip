@@ -30,6 +30,12 @@ extern "C" int bfcg_mg_process_slabs(bfcg_ctx_t *c, const void *d_recv, const ui
 extern "C" int bfcg_mg_slab_info(bfcg_ctx_t *c, uint32_t out[2]);
 extern "C" int bfcg_mg_scatter_slabs(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *fills, int *overflow);
 extern "C" int bfcg_mg_scatter_again(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t *counts);
+extern "C" int bfcg_mg_row_words(bfcg_ctx_t *c);
+extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c);
+extern "C" int bfcg_mg_scatter_slabs_async(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *d_rows_out, hipEvent_t *done);
+extern "C" int bfcg_mg_scatter_slabs_wait(bfcg_ctx_t *c, uint32_t *fills, int *overflow);
+extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, hipEvent_t *wait, int n_wait);
+extern "C" int bfcg_mg_process_finish(bfcg_ctx_t *c, const uint32_t *fills);
 extern "C" void bfcg_set_error(const char *msg);
 extern "C" double bfcg_mg_warm_factor(bfcg_ctx_t *c);
 extern "C" void bfcg_mg_allow_onepass(bfcg_ctx_t *c, int on);
@@ -52,6 +58,8 @@ struct rank_t {
 	uint64_t send_cap, recv_cap; // bytes
 	uint32_t *counts;          // this rank's level-1 bucket sizes of the current batch (host) + one word: this rank's group has failed
 	uint32_t *d_counts;        // multi-process: all ranks' rows, device side of the all-gather
+	uint32_t *d_rows_out[2], *d_rows_in[2]; // slab mode, all ranks in this process: the fills of stage A's slabs as one row per destination (device), and every
+	                           // source's row for this rank -- they travel beside the blocks, the owner's stage B reads them on the device (rank_batch: `lazy`)
 	uint64_t batch_call[64];   // the context's call number after stage B of global batch t (t & 63): bfcg_group_progress
 	ncclComm_t comm;
 	uint8_t *d_seq, *d_qual; uint64_t in_cap; // staging of host batches
@@ -75,6 +83,8 @@ struct bfcg_group {
 	uint32_t slab_cap; uint64_t blk; // records per slab; per block of nb_loc x 8 slabs (what one rank sends to one destination)
 	size_t row_words;           // a rank's row of sizes: up to 8 x nb1 words, then its failure word, then its overflow word
 	uint64_t kmer_limit;        // k-mers of a global batch one rank's regions take at full speed
+	int lazy_ok, lazy;          // the sizes reach the host AFTER exchange and stage B are enqueued: possible at all (slab mode, every rank in this process); for the current batch
+	uint64_t n_lazy;            // global batches taken that way
 	std::vector<rank_t> r;
 	uint32_t *all_counts;       // [n_ranks][nb1 + 1], host (pinned): every rank's bucket sizes of the current batch and its failure word
 	pthread_barrier_t bar;      // local ranks
@@ -199,6 +209,8 @@ static int rank_batch(bfcg_group_t *g, int i)
 	if (R.sent_pending[sb]) { GHIP(hipEventSynchronize(R.ev_sent[sb])); R.sent_pending[sb] = 0; }
 	const uint8_t *ds = R.in_seq, *dq = R.in_qual;
 	int slab = g->slabs; // (the same on every rank: decided between batches)
+	const int lazy = slab && g->lazy; // (decided by run_job for this batch)
+	int redo = 0;        // lazy: a slab overflowed somewhere -- found after this batch's (empty) stage B was enqueued
 	memset(R.counts, 0, sizeof(uint32_t) * cs);
 	if (ok) {
 		if (R.in_host && R.in_pos) {
@@ -210,6 +222,78 @@ static int rank_batch(bfcg_group_t *g, int i)
 				ds = R.d_seq; dq = R.in_qual ? R.d_qual : 0;
 			}
 		}
+	}
+	if (lazy) {
+		// ---- Slab mode without the host in the batch's loop (round 5).  The exchange never depended on the sizes (whole blocks travel); only the
+		// owner's stage B did, and only through the host.  Now every source's fills travel beside its block as a ROW in device memory
+		// (k_pack_rows), the owner builds its segment arrays from the rows on the device (k_seg_setup_mg), and stage A, exchange and stage B are
+		// all enqueued before this thread looks at anything: it reads its own copy of the rows -- the overflow decision, the sizes a replay of
+		// this stage B would need -- while the device still has the whole of stage B before it.  A slab that overflowed anywhere marks its row;
+		// every owner sees every row, so stage B of the batch moves nothing on every rank, and the ranks repeat it through the two passes
+		// below exactly as before -- the decision still falls inside this call, the caller's buffers are still his.
+		const size_t rw_ = (size_t)bfcg_mg_row_words(R.ctx);
+		hipEvent_t ev_a = 0;
+		if (ok && bfcg_mg_scatter_slabs_async(R.ctx, ds, dq, R.in_pos, send, (uint32_t)(R.send_cap / rb), R.d_rows_out[sb], &ev_a) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+		pthread_barrier_wait(&g->bar); // every local rank has enqueued its stage A, or failed to
+		ok = !g->failed;
+		if (ok) {
+			GHIP(hipStreamWaitEvent(R.xs, ev_a, 0));
+			uint32_t *const rin = R.d_rows_in[g->t & 1];
+			GHIP(hipMemcpyAsync(rin + (size_t)me * rw_, R.d_rows_out[sb] + (size_t)me * rw_, sizeof(uint32_t) * rw_, hipMemcpyDeviceToDevice, R.xs)); // (the own block was written in place)
+			if (g->xp == XP_RCCL) {
+				if (N > 1) GNCCL(ncclGroupStart());
+				for (int step = 1; step < N; ++step) {
+					const int to = (me + step) % N, from = (me - step + N) % N;
+					const uint64_t nbytes = g->blk * rb;
+					for (uint64_t c0 = 0; c0 < nbytes; c0 += MSG_BYTES) {
+						GNCCL(ncclSend(send + (uint64_t)to * nbytes + c0, (size_t)(nbytes - c0 < MSG_BYTES ? nbytes - c0 : MSG_BYTES), ncclUint8, to, R.comm, R.xs));
+						GNCCL(ncclRecv(recv + (uint64_t)from * nbytes + c0, (size_t)(nbytes - c0 < MSG_BYTES ? nbytes - c0 : MSG_BYTES), ncclUint8, from, R.comm, R.xs));
+					}
+					GNCCL(ncclSend(R.d_rows_out[sb] + (size_t)to * rw_, rw_, ncclUint32, to, R.comm, R.xs));
+					GNCCL(ncclRecv(rin + (size_t)from * rw_, rw_, ncclUint32, from, R.comm, R.xs));
+				}
+				if (N > 1) GNCCL(ncclGroupEnd());
+			} else {
+				for (int step = 1; step < N; ++step) {
+					const int to = (me + step) % N;
+					const rank_t &T = g->r[to - g->first];
+					GHIP(hipMemcpyPeerAsync(T.recv[g->t & 1] + (uint64_t)me * g->blk * rb, T.device, send + (uint64_t)to * g->blk * rb, R.device, g->blk * rb, R.xs));
+					GHIP(hipMemcpyPeerAsync(T.d_rows_in[g->t & 1] + (size_t)me * rw_, T.device, R.d_rows_out[sb] + (size_t)to * rw_, R.device, sizeof(uint32_t) * rw_, R.xs));
+				}
+			}
+			GHIP(hipEventRecord(R.ev_x, R.xs));
+		}
+		pthread_barrier_wait(&g->bar); // every sender's event is recorded: the owners may wait for them
+		int enq = 0;
+		if (ok && !g->failed) {
+			std::vector<hipEvent_t> ev;
+			if (g->xp == XP_RCCL) ev.push_back(R.ev_x);
+			else for (int j = 0; j < g->n_local; ++j) ev.push_back(g->r[j].ev_x);
+			if (bfcg_mg_process_slabs_dev(R.ctx, recv, R.d_rows_in[g->t & 1], g->slab_cap, (uint64_t)N * g->blk, ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+			else enq = 1;
+		}
+		// ---- only now the host's copy of the sizes
+		int ovf = 0;
+		if (ok && bfcg_mg_scatter_slabs_wait(R.ctx, R.counts, &ovf) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); memset(R.counts, 0, sizeof(uint32_t) * cs); }
+		R.counts[cs - 1] = ovf ? 1u : 0u;
+		R.counts[cs - 2] = g->failed ? 1u : 0u;
+		memcpy(g->all_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs);
+		pthread_barrier_wait(&g->bar); // all local ranks have published their sizes
+		for (int p = 0; p < N; ++p) redo |= g->all_counts[(size_t)p * cs + cs - 1] != 0;
+		{
+			const size_t per = (size_t)nb_loc * 8;
+			std::vector<uint32_t> seg((size_t)N * per, 0u);
+			if (!redo) for (int s2 = 0; s2 < N; ++s2) memcpy(&seg[(size_t)s2 * per], &g->all_counts[(size_t)s2 * cs + (size_t)me * per], sizeof(uint32_t) * per);
+			if (enq && bfcg_mg_process_finish(R.ctx, seg.data()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+		}
+		pthread_barrier_wait(&g->bar); // (everybody has read the rows before anybody writes the next ones)
+		if (redo) { // the empty stage B and the exchange that carried the overflowed slabs: out of the way before the send buffer is written again
+			if (bfcg_sync(R.ctx) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+			GHIP(hipStreamSynchronize(R.xs));
+			ok = !g->failed;
+		} else if (i == 0) ++g->n_lazy;
+	} else
+	if (ok) {
 		if (ok && slab) {
 			int ovf = 0;
 			// (the rank's own slabs: the same place inside its block of the receive buffer, which lies send_cap bytes behind the send buffer)
@@ -217,6 +301,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 			R.counts[cs - 1] = ovf ? 1u : 0u;
 		} else if (ok && bfcg_mg_scatter(R.ctx, ds, dq, R.in_pos, send, R.counts) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
 	}
+	if (!lazy) {
 	if (!ok) memset(R.counts, 0, sizeof(uint32_t) * cs);
 	// The failure word travels with the sizes: g->failed is local to a process, and a rank that skipped the exchange while its peers posted
 	// ncclSend / ncclRecv for it would leave them blocked for good.  A group that has failed keeps taking part in this all-gather (and only in it),
@@ -224,10 +309,13 @@ static int rank_batch(bfcg_group_t *g, int i)
 	R.counts[cs - 2] = g->failed ? 1u : 0u;
 	publish_sizes(g, R);
 	pthread_barrier_wait(&g->bar); // all local ranks have published their sizes
+	}
 	if (slab) { // a slab overflowed somewhere: every rank repeats its stage A through the two passes (its k-mers are counted) and the run stays with them
-		int any = 0;
-		for (int p = 0; p < N; ++p) any |= g->all_counts[(size_t)p * cs + cs - 1] != 0;
-		pthread_barrier_wait(&g->bar); // (everybody has read the rows before anybody writes the next ones)
+		int any = redo;
+		if (!lazy) {
+			for (int p = 0; p < N; ++p) any |= g->all_counts[(size_t)p * cs + cs - 1] != 0;
+			pthread_barrier_wait(&g->bar); // (everybody has read the rows before anybody writes the next ones)
+		}
 		if (any) {
 			if (i == 0 && getenv("BFCG_DEBUG_MG")) fprintf(stderr, "[D::group] batch %llu: a level-1 slab overflowed on some rank: two-pass stage A from here on\n", (unsigned long long)g->t);
 			if (i == 0) g->slabs = 0;
@@ -240,6 +328,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 			pthread_barrier_wait(&g->bar);
 		}
 	}
+	if (!lazy || redo) { // (a lazy batch that went well is complete: its exchange and stage B were enqueued above)
 	if (i == 0) g->go = !g->failed; // one decision for all local ranks -- and, the failure words being all-gathered, for all processes
 	pthread_barrier_wait(&g->bar);
 	const uint32_t *C = g->all_counts;
@@ -309,6 +398,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 			if (process_in_groups(g, R, recv, seg.data(), ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
 		}
 	}
+	}
 	{ uint64_t calls = 0; bfcg_progress(R.ctx, &calls, 0, 0, 0); R.batch_call[g->t & 63] = calls; } // this global batch is complete on this rank once that call is
 	// The exchange is left running: the next batch's stage A (other send buffer) proceeds beside it.  What the next batch may not do before
 	// this one is through is ordered elsewhere: its exchange follows this one on the stream xs; a receive buffer is written again two batches
@@ -339,8 +429,25 @@ static void *rank_main(void *arg)
 	}
 }
 
+// May the next global batch keep the host out of its loop (rank_batch: `lazy`)?  Slab mode with every rank in this process; every context able to
+// take its stage B from rows on the device; and no rank so loaded that the owner would have to split what it receives by groups of sources
+// (process_in_groups_slabs decides that from the sizes, which the host then does not have in time: k-mers <= positions and the hash spreads them
+// evenly, so the shares' positions / N + 5 % bound what a rank receives).
+static int lazy_possible(bfcg_group_t *g)
+{
+	if (!g->lazy_ok || !g->slabs || g->failed) return 0;
+	uint64_t pos = 0;
+	for (auto &R : g->r) { if (!bfcg_mg_async_ok(R.ctx)) return 0; pos += R.in_pos; }
+	if (g->n_ranks > 1) {
+		const uint64_t per = pos / (uint64_t)g->n_ranks + pos / (uint64_t)g->n_ranks / 20;
+		for (auto &R : g->r) if ((double)per > (double)g->kmer_limit * bfcg_mg_warm_factor(R.ctx)) return 0;
+	}
+	return 1;
+}
+
 static int run_job(bfcg_group_t *g)
 {
+	g->lazy = lazy_possible(g);
 	pthread_mutex_lock(&g->mu);
 	g->n_done = 0; ++g->job;
 	pthread_cond_broadcast(&g->cv);
@@ -370,6 +477,7 @@ extern "C" void bfcg_group_destroy(bfcg_group_t *g)
 		if (R.ctx) (void)bfcg_sync(R.ctx);
 		if (R.comm) { if (g->failed && g->mp) (void)ncclCommAbort(R.comm); else (void)ncclCommDestroy(R.comm); } // (peers of a failed run may never post what a clean destroy waits for)
 		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); if (!R.combined) { (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); } (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
+		for (int b = 0; b < 2; ++b) { (void)hipFree(R.d_rows_out[b]); (void)hipFree(R.d_rows_in[b]); }
 		if (R.ev_x) (void)hipEventDestroy(R.ev_x);
 		for (int b = 0; b < 2; ++b) if (R.ev_sent[b]) (void)hipEventDestroy(R.ev_sent[b]);
 		if (R.xs) (void)hipStreamDestroy(R.xs);
@@ -425,6 +533,8 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		if (S + (rcap > S ? rcap : S) + 8192 >= 0xffffffffULL) g->slabs_ok = 0;
 		g->slabs = g->slabs_ok;
 		g->row_words = (size_t)g->nb1 * (g->slabs_ok ? 8 : 1) + 2;
+		{ const char *e2 = getenv("BFCG_MG_LAZY"); g->lazy_ok = g->slabs_ok && !g->mp && !(e2 && atoi(e2) == 0); } // (between processes the sizes' all-gather still gates a batch: DESIGN.md section 5)
+		g->lazy = 0; g->n_lazy = 0;
 	}
 	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * g->row_words, hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
 	std::vector<ncclComm_t> comms((size_t)n_local, (ncclComm_t)0);
@@ -457,6 +567,12 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 			if (e == hipSuccess) e = hipMalloc(&R.recv[1], R.recv_cap);
 		}
 		if (e == hipSuccess) e = hipMalloc(&R.d_counts, sizeof(uint32_t) * (size_t)n_ranks * g->row_words);
+		if (g->lazy_ok) for (int b = 0; b < 2; ++b) {
+			const size_t w = (size_t)n_ranks * (size_t)bfcg_mg_row_words(R.ctx);
+			if (e == hipSuccess) e = hipMalloc(&R.d_rows_out[b], sizeof(uint32_t) * w);
+			if (e == hipSuccess) e = hipMalloc(&R.d_rows_in[b], sizeof(uint32_t) * w);
+			if (e == hipSuccess) e = hipMemset(R.d_rows_in[b], 0, sizeof(uint32_t) * w);
+		}
 		R.in_cap = cap;
 		if (e == hipSuccess) e = hipMalloc(&R.d_seq, cap);
 		if (e == hipSuccess) e = hipMalloc(&R.d_qual, cap);
@@ -511,6 +627,7 @@ extern "C" int bfcg_group_info(bfcg_group_t *g, int out[6])
 	return 0;
 }
 extern "C" int bfcg_group_slab_mode(bfcg_group_t *g) { return g->slabs; }
+extern "C" uint64_t bfcg_group_lazy_batches(bfcg_group_t *g) { return g->n_lazy; }
 extern "C" bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i) { return i >= 0 && i < g->n_local ? g->r[i].ctx : NULL; }
 
 static int drain_exchange(bfcg_group_t *g)

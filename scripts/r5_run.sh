@@ -63,3 +63,23 @@ fi
 if has s1abl; then  # k_scatter1 under the measurement switches (the -DBFCG_MEASURE library): what each part costs on the current kernel
   for a in 0 2048 1024 256 512 1280 3328; do BFCG_ABLATE=$a timeout 300 python scripts/s1_ablate.py 2>&1 | tail -1; done > gpurun_out/r5_s1_ablate.txt; cat gpurun_out/r5_s1_ablate.txt
 fi
+if has group; then  # the group tests, then c3 through an in-process group of one (lazy sizes on / off) against the plain path, one box
+  timeout 1500 python -m pytest tests/test_gpu_group.py -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_group.log; tail -6 gpurun_out/r5_group.log
+  for v in plain lazy1 lazy0; do
+    case $v in plain) envs="X=1";; lazy1) envs="BFC_BENCH_FORCE_GROUP=1";; lazy0) envs="BFC_BENCH_FORCE_GROUP=1 BFCG_MG_LAZY=0";; esac
+    env $envs timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary --no-secondary > gpurun_out/r5_group_$v.json 2> gpurun_out/r5_group_$v.log; echo "group $v ($envs) rc=$?"
+    summ gpurun_out/r5_group_$v.json
+  done
+fi
+if has e2eab; then  # the boundary: bfc-dropin on the c3 FASTQ (READS of it) in tmpfs, the mapping given back behind the parser (default) against one munmap at the end
+  python - <<PY
+import sys, time; sys.path.insert(0,'.')
+from bfc_amd import gen
+t=time.time(); rs = gen.ReadSet(seed=3, G=248_000_000, cov=30)
+rs.fastq_parallel('/dev/shm/c3e.fq', 0, min(${READS:-49600000}, rs.n_reads), threads=32); print('reads', min(${READS:-49600000}, rs.n_reads), 'written in %.1f s' % (time.time()-t))
+PY
+  ls -l /dev/shm/c3e.fq
+  export BFC_GPU_TIMING=1
+  for mm in 0 1 0 1; do echo "== unmapping behind the parser: $mm"; ( time BFC_INGEST_UNMAP_MIN=$((mm ? 268435456 : 1099511627776)) oracle/_ref/bfc-dropin -E -s 250m -k 33 -t${E2E_T:-64} /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -16; echo; done > gpurun_out/r5_e2e_ab.txt 2>&1
+  rm -f /dev/shm/c3e.fq; grep -E "==|Real time|^real|clean-up|waited" gpurun_out/r5_e2e_ab.txt
+fi

@@ -55,6 +55,36 @@ def test_group_host_batches(gpu_lib, g1, n_ranks, k, b, fm):
     grp.close(); oc.close()
 
 
+@pytest.mark.parametrize("n_ranks", [1, 2, 4])
+@pytest.mark.parametrize("lazy", [1, 0])
+def test_group_sizes_stay_on_the_device(gpu_lib, g1, n_ranks, lazy, monkeypatch):
+    """Round 5: with every rank in one process the slabs' fills travel beside the blocks as rows in device memory and the owner builds its
+    segment arrays from them on the device (k_pack_rows / k_seg_setup_mg): exchange and stage B of a global batch are enqueued before the host
+    has seen a size (`lazy_batches` counts them).  BFCG_MG_LAZY=0 is round 4's protocol (the host waits for stage A's sizes first).  Either way:
+    the oracle's filter, statistics and table, on FASTQ shares at -b30 where slab mode applies (2^F2 > 0)."""
+    monkeypatch.setenv("BFCG_MG_LAZY", str(lazy))
+    rs, (seq, qual, off) = g1
+    k, b = 33, 30 if n_ranks < 4 else 32  # (a rank that receives more than its regions take at full speed processes the sources in groups, from sizes on the host)
+    oc = _oracle(k, b, seq, qual, off)
+    n = rs.n_reads
+    grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=(n // 3 + 2) * (rs.L + 1) // n_ranks + 4096)
+    assert grp.info()["slab_mode"]
+    nb = 0
+    for a in range(0, n, n // 3 + 1):
+        e = min(n, a + n // 3 + 1)
+        grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
+        nb += 1
+    grp.sync()
+    assert grp.info()["lazy_batches"] == (nb if lazy else 0), grp.info()
+    _compare(grp, oc)
+    grp.reset()  # ... and a second pass over the same reads after a reset
+    for a in range(0, n, n // 3 + 1):
+        e = min(n, a + n // 3 + 1)
+        grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
+    _compare(grp, oc)
+    grp.close(); oc.close()
+
+
 def test_group_device_shares_uneven(gpu_lib, g1):
     """bfcg_group_count_batch_dev with ragged shares, a rank that contributes nothing, FASTA (no qualities) and a second pass after reset"""
     rs, (seq, qual, off) = g1

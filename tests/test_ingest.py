@@ -127,6 +127,35 @@ def test_gzip_and_small_batches(gpu_lib, tmp_path):
     assert c0[:6] == c4[:6] and c0[0] > 5
 
 
+def test_mapping_given_back_behind_the_parser(gpu_lib, tmp_path, monkeypatch):
+    """Round 5: a thread of its own unmaps what the batches have consumed (2 MiB-aligned) while the parser goes on -- large inputs only, unless
+    BFC_INGEST_UNMAP_MIN says otherwise.  12 MB of strict FASTQ in batches of ~0.5 MB: the same digests as the serial parser and as the fast
+    path with the one munmap at the end; then a wrapped record at 3/4 of the file -- the serial parser takes over behind unmapped pages."""
+    rng = np.random.default_rng(77)
+    data = _fastq(rng, 60000, 60, 120)
+    fn = str(tmp_path / "big.fq"); open(fn, "wb").write(data)
+    assert len(data) > (10 << 20)
+    serial = _digest(gpu_lib, fn, 500000, 0)
+    plain = _digest(gpu_lib, fn, 500000, 8)
+    monkeypatch.setenv("BFC_INGEST_UNMAP_MIN", "1")
+    for threads in (1, 4, 8):
+        got = _digest(gpu_lib, fn, 500000, threads)
+        assert got[:6] == serial[:6] and got[6] == serial[0], threads
+    assert plain[:6] == serial[:6]
+    cut = data.index(b"\n@", len(data) * 3 // 4) + 1
+    s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 130).tobytes(); q = rng.integers(34, 74, 130).astype(np.uint8).tobytes()
+    mixed = data[:cut] + b"@wrapped\n" + s[:70] + b"\n" + s[70:] + b"\n+\n" + q[:70] + b"\n" + q[70:] + b"\n" + data[cut:]
+    fn2 = str(tmp_path / "mixed.fq"); open(fn2, "wb").write(mixed)
+    monkeypatch.delenv("BFC_INGEST_UNMAP_MIN")
+    serial2 = _digest(gpu_lib, fn2, 500000, 0)
+    monkeypatch.setenv("BFC_INGEST_UNMAP_MIN", "1")
+    got2 = _digest(gpu_lib, fn2, 500000, 8)
+    assert got2[:6] == serial2[:6] and 0 < got2[6] < serial2[0]
+    planes_a = _planes_digest(fn, 500000, 8, 20, 1)  # ... and the planes written straight from the (partly unmapped) file
+    monkeypatch.delenv("BFC_INGEST_UNMAP_MIN")
+    assert planes_a == _planes_digest(fn, 500000, 8, 20, 1)
+
+
 def _mutate(rng, data):
     """random damage to a FASTA/FASTQ text: lines dropped, doubled, split, emptied, junk with '@' '>' '+' inside, CRLF, truncation"""
     lines = data.split(b"\n")
