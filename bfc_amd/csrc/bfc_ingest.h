@@ -202,7 +202,7 @@ static inline int next_record(parser_t *ps)
 typedef struct { uint64_t hdr; uint32_t len, seq_delta; } fq_rec_t; /* '@' position in the file; bases (CR stripped); sequence line - '@' */
 
 enum { FQ_OK = 0, FQ_CUT = 1, FQ_BAD = 2 };
-#define FQ_MAX_THREADS 64
+#define FQ_MAX_THREADS 256
 
 static inline const uint8_t *fq_eol(const uint8_t *p, const uint8_t *e) { const uint8_t *q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); return q ? q : e; }
 

@@ -83,3 +83,14 @@ PY
   for mm in 0 1 0 1; do echo "== unmapping behind the parser: $mm"; ( time BFC_INGEST_UNMAP_MIN=$((mm ? 268435456 : 1099511627776)) oracle/_ref/bfc-dropin -E -s 250m -k 33 -t${E2E_T:-64} /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -16; echo; done > gpurun_out/r5_e2e_ab.txt 2>&1
   rm -f /dev/shm/c3e.fq; grep -E "==|Real time|^real|clean-up|waited" gpurun_out/r5_e2e_ab.txt
 fi
+if has e2et; then  # the boundary with more parser threads (E2E_TS="64 128 256"), the whole c3 file
+  python - <<PY
+import sys, time; sys.path.insert(0,'.')
+from bfc_amd import gen
+rs = gen.ReadSet(seed=3, G=248_000_000, cov=30)
+rs.fastq_parallel('/dev/shm/c3e.fq', 0, min(${READS:-49600000}, rs.n_reads), threads=32)
+PY
+  export BFC_GPU_TIMING=1
+  for t in ${E2E_TS:-64 128 256 64 128}; do echo "== -t$t"; ( time oracle/_ref/bfc-dropin -E -s 250m -k 33 -t$t /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -16; echo; done > gpurun_out/r5_e2e_t.txt 2>&1
+  rm -f /dev/shm/c3e.fq; grep -E "==|Real time|^real|waited" gpurun_out/r5_e2e_t.txt
+fi

@@ -57,31 +57,34 @@ def test_group_host_batches(gpu_lib, g1, n_ranks, k, b, fm):
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 4])
 @pytest.mark.parametrize("lazy", [1, 0])
-def test_group_sizes_stay_on_the_device(gpu_lib, g1, n_ranks, lazy, monkeypatch):
+def test_group_sizes_stay_on_the_device(gpu_lib, n_ranks, lazy, monkeypatch):
     """Round 5: with every rank in one process the slabs' fills travel beside the blocks as rows in device memory and the owner builds its
     segment arrays from them on the device (k_pack_rows / k_seg_setup_mg): exchange and stage B of a global batch are enqueued before the host
     has seen a size (`lazy_batches` counts them).  BFCG_MG_LAZY=0 is round 4's protocol (the host waits for stage A's sizes first).  Either way:
-    the oracle's filter, statistics and table, on FASTQ shares at -b30 where slab mode applies (2^F2 > 0)."""
+    the oracle's filter, statistics and table -- 3 global batches of 60 000 reads of a 50 Mbp genome at -b30 (slabs fill evenly: no overflow),
+    the middle one FASTA (no qualities), one rank's share of the last one empty; then the same again after a reset."""
     monkeypatch.setenv("BFCG_MG_LAZY", str(lazy))
-    rs, (seq, qual, off) = g1
-    k, b = 33, 30 if n_ranks < 4 else 32  # (a rank that receives more than its regions take at full speed processes the sources in groups, from sizes on the host)
+    rng = np.random.default_rng(4100 + n_ranks)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, n = 150, 180_000
+    genome = rng.choice(acgt, 50_000_000 + L)
+    seq = genome[(rng.integers(0, 50_000_000, n)[:, None] + np.arange(L)[None, :])].astype(np.uint8).reshape(-1)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    qual[60_000 * L:120_000 * L] = 126  # (what the oracle sees for a record without qualities: every base high quality)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    k, b = 33, 30
     oc = _oracle(k, b, seq, qual, off)
-    n = rs.n_reads
-    grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=(n // 3 + 2) * (rs.L + 1) // n_ranks + 4096)
+    grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=60_000 * (L + 1) // n_ranks + 4096)
     assert grp.info()["slab_mode"]
-    nb = 0
-    for a in range(0, n, n // 3 + 1):
-        e = min(n, a + n // 3 + 1)
-        grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
-        nb += 1
-    grp.sync()
-    assert grp.info()["lazy_batches"] == (nb if lazy else 0), grp.info()
-    _compare(grp, oc)
-    grp.reset()  # ... and a second pass over the same reads after a reset
-    for a in range(0, n, n // 3 + 1):
-        e = min(n, a + n // 3 + 1)
-        grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
-    _compare(grp, oc)
+    for rnd in range(2):
+        for t in range(3):
+            a, e = t * 60_000, (t + 1) * 60_000
+            grp.count_host(gen.to_stream(seq[a * L:e * L], L, 10), None if t == 1 else gen.to_stream(qual[a * L:e * L], L, 33))
+        grp.sync()
+        assert grp.info()["slab_mode"]
+        assert grp.info()["lazy_batches"] == (3 * (rnd + 1) if lazy else 0), grp.info()
+        _compare(grp, oc)
+        grp.reset()
     grp.close(); oc.close()
 
 
