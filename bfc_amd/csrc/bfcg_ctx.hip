@@ -1097,21 +1097,23 @@ static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg
 // this rank (n_ranks rows of bfcg_mg_row_words words, written by the exchange that `wait` orders this behind); k_seg_setup_mg turns them into the
 // segment arrays on the device.  rec_bound: what the batch can hold at most (sizes the level-2 grid; surplus workgroups exit).  The batch is
 // enqueued and NOT finalised: bfcg_mg_process_finish does that once the caller has the sizes (the same call of the group, a moment later).
-// may this rank take a batch that way right now?  (level 2 in one pass -- its region slabs bound what a batch can write whatever the sizes turn out
-// to be --, no order stamps, no per-position debug output)
-extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c) { return c->mg_slab_ok && c->mg_op2 && c->mg_op2_allowed && c->cap2 && !c->B.seen_out && !c->P.track && c->h_rows[0] != 0; }
-extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, hipEvent_t *wait, int n_wait)
+// may this rank take batches that way?  A property of the context's parameters, not of its state (no order stamps, no per-position debug output):
+// the processes of a multi-process group must all answer alike.  (Level 2 in one pass or two: the slabs a source can fill -- nb1 x 8 x capacity
+// records -- are fewer than the level-2 buffers hold, so the bound sizes the grids and nothing can be overrun whatever the sizes turn out to be.)
+extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c) { return c->mg_slab_ok && !c->B.seen_out && !c->P.track && c->h_rows[0] != 0 && (uint64_t)8 * (1u << c->P.F1) * c->op_cap <= c->recv_cap; }
+// (only the sources [s_lo, s_hi) of the receive buffer: an overloaded owner applies the others in further passes, bfcg_mg_process_slabs with their sizes)
+extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, int s_lo, int s_hi, hipEvent_t *wait, int n_wait)
 {
 	const int N = c->n_ranks, nb_loc = (1 << c->P.F1) >> c->log2n, spb = N * 8, n_seg = nb_loc * spb, b = c->cur;
 	HIPCK(hipSetDevice(c->prm.device));
 	const size_t words = (size_t)3 * n_seg + 1 + nb_loc + 1;
 	if (words > c->seg_words) return set_err("internal: %zu segment words, room for %zu", words, c->seg_words);
-	if (!slab_cap || !bfcg_mg_async_ok(c)) return set_err("internal: bfcg_mg_process_slabs_dev needs slabs, a one-pass level 2 and no debug_seen");
+	if (!slab_cap || !bfcg_mg_async_ok(c)) return set_err("internal: bfcg_mg_process_slabs_dev needs slabs and no debug_seen");
 	if (rec_bound > c->recv_cap) rec_bound = c->recv_cap;
 	uint32_t *d = c->d_seg + (size_t)b * c->seg_words;
 	for (int i = 0; i < n_wait; ++i) HIPCK(hipStreamWaitEvent(c->st, wait[i], 0));
 	HIPCK(hipEventRecord(c->evt[b][6], c->st));
-	run_seg_setup_mg(c->P, c->rw / 4, d_rows_in, (uint32_t)(nb_loc * 8 + 2), N, slab_cap, d, nullptr, c->st);
+	run_seg_setup_mg(c->P, c->rw / 4, d_rows_in, (uint32_t)(nb_loc * 8 + 2), N, s_lo, s_hi, slab_cap, d, nullptr, c->st);
 	c->B.batch_hi = (unsigned long long)(c->n_batches + 1) << 32;
 	if (use_stream(c) != 0 || ensure_agg(c) != 0) return -1;
 	c->B.stream = c->stream_mode; c->B.stream_out = c->stream_out;

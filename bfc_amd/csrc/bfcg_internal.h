@@ -96,7 +96,7 @@ void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, cons
 // a rank of a group, slab mode without the host's sizes: the fills of stage A's slabs as one row per destination (behind run_stage_a_onepass, same stream);
 // the owner's segment arrays (seg_beg | seg_end | row_base | bucket_start, as mg_process_any lays them out) from all sources' rows
 void run_pack_rows(const KParams &P, const BatchBufs &B, int n_ranks, uint32_t row_w, uint32_t *rows, hipStream_t st);
-void run_seg_setup_mg(const KParams &P, int rw_dwords, const uint32_t *rows, uint32_t row_w, int n_ranks, uint32_t cap, uint32_t *seg, unsigned long long *total, hipStream_t st);
+void run_seg_setup_mg(const KParams &P, int rw_dwords, const uint32_t *rows, uint32_t row_w, int n_ranks, int s_lo, int s_hi, uint32_t cap, uint32_t *seg, unsigned long long *total, hipStream_t st);
 void run_batch(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, hipStream_t st, hipEvent_t *ev);
 int bloom_lds_bytes(const KParams &P);
 bool bloom3fm_geometry_ok(const KParams &P); // k_bloom3fm's conditions (16-byte records, k >= bf_shift + 9: block, h1, h2 are bits of y0; 4 hashes; regions of <= 256 blocks)

@@ -940,8 +940,9 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint32_t *__restrict__ 
 // the sizes: segment ((k * N + s) * 8 + x) = the slab of (source s, owned bucket k, XCD x) at its fixed place ((s * nb_loc + k) * 8 + x) x cap of the
 // receive buffer.  One workgroup; thread t = k * N + s owns 8 segments (nb_loc x N = 2^F1 <= 1024 threads).  A source whose stage A overflowed
 // empties the whole batch (every rank sees the same rows, so every rank's stage B of this batch moves nothing; the host finds the flag when it
-// reads its own copy of the rows and repeats the batch through the two passes).  total[0] = records received (read with the batch's statistics).
-__global__ __launch_bounds__(1024) void k_seg_setup_mg(const uint32_t *__restrict__ rows, uint32_t row_w, int N, int nb_loc, uint32_t cap, int tile2,
+// reads its own copy of the rows and repeats the batch through the two passes).  Only the sources [s_lo, s_hi) contribute: an owner that
+// receives more than its regions take at full speed applies the sources in consecutive groups (bfcg_mg.hip), the first of them this way.
+__global__ __launch_bounds__(1024) void k_seg_setup_mg(const uint32_t *__restrict__ rows, uint32_t row_w, int N, int s_lo, int s_hi, int nb_loc, uint32_t cap, int tile2,
                                                        uint32_t *__restrict__ seg_beg, uint32_t *__restrict__ seg_end, uint32_t *__restrict__ row_base,
                                                        uint32_t *__restrict__ bucket_start, unsigned long long *__restrict__ total)
 {
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(1024) void k_seg_setup_mg(const uint32_t *__restric
 #pragma unroll
 	for (int x = 0; x < 8; ++x) {
 		uint32_t l = 0;
-		if (t < nt && !poison) { l = rows[(size_t)s * row_w + (size_t)k * 8 + x]; if (l > cap) l = cap; }
+		if (t < nt && !poison && s >= s_lo && s < s_hi) { l = rows[(size_t)s * row_w + (size_t)k * 8 + x]; if (l > cap) l = cap; } // (sources outside [s_lo, s_hi): another pass takes them)
 		len[x] = l; nrow += (l + tile2 - 1) / tile2; recs += l;
 	}
 	s_rows[t] = nrow; s_recs[t] = recs;
@@ -2580,10 +2581,10 @@ void run_pack_rows(const KParams &P, const BatchBufs &B, int n_ranks, uint32_t r
 	const int nb1 = 1 << P.F1;
 	hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)n_ranks), dim3(256), 0, st, B.op_seg + (size_t)8 * nb1, B.op_flags, nb1 / n_ranks, B.op_cap, row_w, rows);
 }
-void run_seg_setup_mg(const KParams &P, int rw_dwords, const uint32_t *rows, uint32_t row_w, int n_ranks, uint32_t cap, uint32_t *seg, unsigned long long *total, hipStream_t st)
+void run_seg_setup_mg(const KParams &P, int rw_dwords, const uint32_t *rows, uint32_t row_w, int n_ranks, int s_lo, int s_hi, uint32_t cap, uint32_t *seg, unsigned long long *total, hipStream_t st)
 {
 	const int nb1 = 1 << P.F1, nb_loc = nb1 / n_ranks, n_seg = nb1 * 8;
-	hipLaunchKernelGGL(k_seg_setup_mg, dim3(1), dim3(1024), 0, st, rows, row_w, n_ranks, nb_loc, cap, rw_dwords == 5 ? 3072 : TILE2, seg, seg + n_seg, seg + 2 * n_seg, seg + 3 * n_seg + 1, total);
+	hipLaunchKernelGGL(k_seg_setup_mg, dim3(1), dim3(1024), 0, st, rows, row_w, n_ranks, s_lo, s_hi, nb_loc, cap, rw_dwords == 5 ? 3072 : TILE2, seg, seg + n_seg, seg + 2 * n_seg, seg + 3 * n_seg + 1, total);
 }
 
 void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,

@@ -34,7 +34,7 @@ extern "C" int bfcg_mg_row_words(bfcg_ctx_t *c);
 extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c);
 extern "C" int bfcg_mg_scatter_slabs_async(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_pos, void *d_send, uint32_t own_delta, uint32_t *d_rows_out, hipEvent_t *done);
 extern "C" int bfcg_mg_scatter_slabs_wait(bfcg_ctx_t *c, uint32_t *fills, int *overflow);
-extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, hipEvent_t *wait, int n_wait);
+extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, int s_lo, int s_hi, hipEvent_t *wait, int n_wait);
 extern "C" int bfcg_mg_process_finish(bfcg_ctx_t *c, const uint32_t *fills);
 extern "C" void bfcg_set_error(const char *msg);
 extern "C" double bfcg_mg_warm_factor(bfcg_ctx_t *c);
@@ -146,17 +146,18 @@ static int process_in_groups(bfcg_group_t *g, rank_t &R, const uint8_t *recv, co
 }
 
 // the same in slab mode: every source's slabs sit at fixed places, so a group of sources is simply the fills of the others set to zero
-static int process_in_groups_slabs(bfcg_group_t *g, rank_t &R, const uint8_t *recv, const uint32_t *fills, hipEvent_t *wait, int n_wait)
+// (s_begin, launched0: the sources before s_begin went through launched0 passes already -- the lazy protocol's first group, rank_batch)
+static int process_in_groups_slabs(bfcg_group_t *g, rank_t &R, const uint8_t *recv, const uint32_t *fills, hipEvent_t *wait, int n_wait, int s_begin = 0, int launched0 = 0)
 {
 	const int N = g->n_ranks, nb_loc = g->nb_loc;
 	const size_t per = (size_t)nb_loc * 8;
 	std::vector<uint64_t> per_src((size_t)N, 0);
 	uint64_t total = 0;
-	for (int s = 0; s < N; ++s) { for (size_t k = 0; k < per; ++k) per_src[s] += fills[(size_t)s * per + k]; total += per_src[s]; }
+	for (int s = s_begin; s < N; ++s) { for (size_t k = 0; k < per; ++k) per_src[s] += fills[(size_t)s * per + k]; total += per_src[s]; }
 	const uint64_t limit = (uint64_t)((double)g->kmer_limit * bfcg_mg_warm_factor(R.ctx));
-	if (g->prm.track_order || total <= limit || N == 1) return bfcg_mg_process_slabs(R.ctx, recv, fills, g->slab_cap, wait, n_wait);
+	if (!launched0 && (g->prm.track_order || total <= limit || N == 1)) return bfcg_mg_process_slabs(R.ctx, recv, fills, g->slab_cap, wait, n_wait);
 	std::vector<uint32_t> seg((size_t)N * per);
-	int s0 = 0, launched = 0;
+	int s0 = s_begin, launched = launched0;
 	while (s0 < N) {
 		uint64_t acc = per_src[s0]; int s1 = s0 + 1;
 		while (s1 < N && acc + per_src[s1] <= limit) acc += per_src[s1++];
@@ -174,6 +175,23 @@ static int process_in_groups_slabs(bfcg_group_t *g, rank_t &R, const uint8_t *re
 	}
 	if (!launched) return bfcg_mg_process_slabs(R.ctx, recv, fills, g->slab_cap, wait, n_wait);
 	return 0;
+}
+// The lazy protocol's first group of sources: [0, s1) with s1 the most sources whose BOUND fits what this rank's regions take at full speed -- a source
+// sends an owner at most its share's positions / N (k-mers <= positions; the hash spreads them evenly: + 5 %).  `pos[s]`: the shares' positions
+// where this process knows them (all ranks local), else every share is taken at the contexts' capacity.
+static int lazy_first_group(bfcg_group_t *g, rank_t &R)
+{
+	const int N = g->n_ranks;
+	if (N == 1 || g->prm.track_order) return N;
+	const uint64_t limit = (uint64_t)((double)g->kmer_limit * bfcg_mg_warm_factor(R.ctx));
+	uint64_t acc = 0;
+	int s1 = 0;
+	for (int s = 0; s < N; ++s) {
+		const uint64_t p = g->mp ? g->prm.max_batch_pos : g->r[s - g->first].in_pos, est = p / (uint64_t)N + p / (uint64_t)N / 20;
+		if (s1 > 0 && acc + est > limit) break;
+		acc += est; s1 = s + 1;
+	}
+	return s1;
 }
 
 // every rank's row of sizes: shared memory between the local ranks, an all-gather over RCCL between processes
@@ -233,11 +251,17 @@ static int rank_batch(bfcg_group_t *g, int i)
 		// below exactly as before -- the decision still falls inside this call, the caller's buffers are still his.
 		const size_t rw_ = (size_t)bfcg_mg_row_words(R.ctx);
 		hipEvent_t ev_a = 0;
-		if (ok && bfcg_mg_scatter_slabs_async(R.ctx, ds, dq, R.in_pos, send, (uint32_t)(R.send_cap / rb), R.d_rows_out[sb], &ev_a) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = 0; }
+		int a_ok = ok;
+		if (ok && bfcg_mg_scatter_slabs_async(R.ctx, ds, dq, R.in_pos, send, (uint32_t)(R.send_cap / rb), R.d_rows_out[sb], &ev_a) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); ok = a_ok = 0; }
 		pthread_barrier_wait(&g->bar); // every local rank has enqueued its stage A, or failed to
-		ok = !g->failed;
-		if (ok) {
-			GHIP(hipStreamWaitEvent(R.xs, ev_a, 0));
+		if (!g->mp) ok = !g->failed;
+		// Between processes a rank cannot tell its peers that it has failed before they post their sends and receives for it: it takes part in
+		// the exchange all the same, with rows that say "nothing of this may be used" (every owner's stage B of the batch then moves nothing),
+		// and the failure word of the sizes' all-gather below ends the run on every process in this same batch.
+		const int post = g->mp ? 1 : ok;
+		if (post) {
+			if (a_ok) GHIP(hipStreamWaitEvent(R.xs, ev_a, 0));
+			else GHIP(hipMemsetAsync(R.d_rows_out[sb], 0xff, sizeof(uint32_t) * (size_t)N * rw_, R.xs));
 			uint32_t *const rin = R.d_rows_in[g->t & 1];
 			GHIP(hipMemcpyAsync(rin + (size_t)me * rw_, R.d_rows_out[sb] + (size_t)me * rw_, sizeof(uint32_t) * rw_, hipMemcpyDeviceToDevice, R.xs)); // (the own block was written in place)
 			if (g->xp == XP_RCCL) {
@@ -264,29 +288,38 @@ static int rank_batch(bfcg_group_t *g, int i)
 			GHIP(hipEventRecord(R.ev_x, R.xs));
 		}
 		pthread_barrier_wait(&g->bar); // every sender's event is recorded: the owners may wait for them
+		// the owner's stage B, from the rows on the device: all sources, or -- where that is more than this rank's regions take at full speed --
+		// a first group of them chosen by what they can send at most; the others follow below, grouped by their sizes
+		const int s1 = lazy_first_group(g, R);
 		int enq = 0;
 		if (ok && !g->failed) {
 			std::vector<hipEvent_t> ev;
 			if (g->xp == XP_RCCL) ev.push_back(R.ev_x);
 			else for (int j = 0; j < g->n_local; ++j) ev.push_back(g->r[j].ev_x);
-			if (bfcg_mg_process_slabs_dev(R.ctx, recv, R.d_rows_in[g->t & 1], g->slab_cap, (uint64_t)N * g->blk, ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+			if (bfcg_mg_process_slabs_dev(R.ctx, recv, R.d_rows_in[g->t & 1], g->slab_cap, (uint64_t)N * g->blk, 0, s1, ev.data(), (int)ev.size()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
 			else enq = 1;
 		}
 		// ---- only now the host's copy of the sizes
 		int ovf = 0;
-		if (ok && bfcg_mg_scatter_slabs_wait(R.ctx, R.counts, &ovf) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); memset(R.counts, 0, sizeof(uint32_t) * cs); }
+		if (a_ok && bfcg_mg_scatter_slabs_wait(R.ctx, R.counts, &ovf) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); memset(R.counts, 0, sizeof(uint32_t) * cs); }
+		if (!a_ok) memset(R.counts, 0, sizeof(uint32_t) * cs);
 		R.counts[cs - 1] = ovf ? 1u : 0u;
 		R.counts[cs - 2] = g->failed ? 1u : 0u;
-		memcpy(g->all_counts + (size_t)me * cs, R.counts, sizeof(uint32_t) * cs);
+		publish_sizes(g, R); // (between processes: the all-gather, behind this batch's exchange on the same stream)
 		pthread_barrier_wait(&g->bar); // all local ranks have published their sizes
 		for (int p = 0; p < N; ++p) redo |= g->all_counts[(size_t)p * cs + cs - 1] != 0;
 		{
 			const size_t per = (size_t)nb_loc * 8;
-			std::vector<uint32_t> seg((size_t)N * per, 0u);
-			if (!redo) for (int s2 = 0; s2 < N; ++s2) memcpy(&seg[(size_t)s2 * per], &g->all_counts[(size_t)s2 * cs + (size_t)me * per], sizeof(uint32_t) * per);
-			if (enq && bfcg_mg_process_finish(R.ctx, seg.data()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+			std::vector<uint32_t> seg((size_t)N * per, 0u), first((size_t)N * per, 0u);
+			if (!redo && !g->failed) {
+				for (int s2 = 0; s2 < N; ++s2) memcpy(&seg[(size_t)s2 * per], &g->all_counts[(size_t)s2 * cs + (size_t)me * per], sizeof(uint32_t) * per);
+				memcpy(first.data(), seg.data(), sizeof(uint32_t) * (size_t)s1 * per);
+			}
+			if (enq && bfcg_mg_process_finish(R.ctx, first.data()) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
+			if (enq && !redo && !g->failed && s1 < N && process_in_groups_slabs(g, R, recv, seg.data(), 0, 0, s1, 1) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
 		}
 		pthread_barrier_wait(&g->bar); // (everybody has read the rows before anybody writes the next ones)
+		ok = !g->failed;
 		if (redo) { // the empty stage B and the exchange that carried the overflowed slabs: out of the way before the send buffer is written again
 			if (bfcg_sync(R.ctx) != 0) grp_err(g, "rank %d: %s", me, bfcg_last_error());
 			GHIP(hipStreamSynchronize(R.xs));
@@ -429,20 +462,13 @@ static void *rank_main(void *arg)
 	}
 }
 
-// May the next global batch keep the host out of its loop (rank_batch: `lazy`)?  Slab mode with every rank in this process; every context able to
-// take its stage B from rows on the device; and no rank so loaded that the owner would have to split what it receives by groups of sources
-// (process_in_groups_slabs decides that from the sizes, which the host then does not have in time: k-mers <= positions and the hash spreads them
-// evenly, so the shares' positions / N + 5 % bound what a rank receives).
+// May the next global batch keep the host out of its loop (rank_batch: `lazy`)?  Slab mode, and every context able to take its stage B from rows
+// on the device (checked when the group is created).
 static int lazy_possible(bfcg_group_t *g)
 {
-	if (!g->lazy_ok || !g->slabs || g->failed) return 0;
-	uint64_t pos = 0;
-	for (auto &R : g->r) { if (!bfcg_mg_async_ok(R.ctx)) return 0; pos += R.in_pos; }
-	if (g->n_ranks > 1) {
-		const uint64_t per = pos / (uint64_t)g->n_ranks + pos / (uint64_t)g->n_ranks / 20;
-		for (auto &R : g->r) if ((double)per > (double)g->kmer_limit * bfcg_mg_warm_factor(R.ctx)) return 0;
-	}
-	return 1;
+	// (nothing here may depend on a rank's state: the processes of a multi-process group decide alike, each for itself.  g->slabs changes only by
+	// decisions all ranks take together; a group that has failed walks through the protocol like the others and reports the failure in its row)
+	return g->lazy_ok && g->slabs;
 }
 
 static int run_job(bfcg_group_t *g)
@@ -533,7 +559,7 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		if (S + (rcap > S ? rcap : S) + 8192 >= 0xffffffffULL) g->slabs_ok = 0;
 		g->slabs = g->slabs_ok;
 		g->row_words = (size_t)g->nb1 * (g->slabs_ok ? 8 : 1) + 2;
-		{ const char *e2 = getenv("BFCG_MG_LAZY"); g->lazy_ok = g->slabs_ok && !g->mp && !(e2 && atoi(e2) == 0); } // (between processes the sizes' all-gather still gates a batch: DESIGN.md section 5)
+		{ const char *e2 = getenv("BFCG_MG_LAZY"); g->lazy_ok = g->slabs_ok && !(e2 && atoi(e2) == 0); for (auto &R : g->r) if (!bfcg_mg_async_ok(R.ctx)) g->lazy_ok = 0; }
 		g->lazy = 0; g->n_lazy = 0;
 	}
 	if (hipHostMalloc(&g->all_counts, sizeof(uint32_t) * (size_t)n_ranks * g->row_words, hipHostMallocDefault) != hipSuccess) { bfcg_set_error("hipHostMalloc failed"); bfcg_group_destroy(g); return NULL; }
@@ -596,7 +622,7 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 	if (g->mp) { // one rank per process: every process must have decided the same exchange layout (slab mode, slab capacity, words per row of sizes) --
 	             // each decides it from its own environment and context; an all-gather with different counts would hang or corrupt memory
 		rank_t &R = g->r[0];
-		const uint32_t mine[4] = {(uint32_t)g->slabs_ok, g->slab_cap, (uint32_t)g->row_words, (uint32_t)g->rec_bytes};
+		const uint32_t mine[4] = {(uint32_t)(g->slabs_ok | (g->lazy_ok << 1)), g->slab_cap, (uint32_t)g->row_words, (uint32_t)g->rec_bytes}; // (bit 1: the sizes stay on the device -- BFCG_MG_LAZY)
 		std::vector<uint32_t> all((size_t)4 * n_ranks, 0);
 		hipError_t he = hipSetDevice(R.device);
 		ncclResult_t ne = ncclSuccess;

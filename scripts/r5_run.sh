@@ -42,7 +42,7 @@ if has inproc; then
   python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/r5_bench_gpus2_plain.json 2>/dev/null; echo "plain --gpus 2 rc=$?"; cat gpurun_out/r5_bench_gpus2_plain.json
 fi
 if has c4; then timeout 900 python scripts/c4_run.py --batch-reads 16777216 > gpurun_out/r5_c4_16m.log 2>&1; tail -2 gpurun_out/r5_c4_16m.log | cut -c1-700; fi
-if has c5; then timeout 900 python scripts/c4_run.py --batch-reads 8388608 --filter-mode 1 --k 51 --trim 1 > gpurun_out/r5_c5_8m.log 2>&1; tail -3 gpurun_out/r5_c5_8m.log | cut -c1-700; fi
+if has c5; then timeout 900 python scripts/c4_run.py --batch-reads ${C5_BATCH:-16777216} --filter-mode 1 --k 51 --trim 1 > gpurun_out/r5_c5_${C5_BATCH:-16777216}.log 2>&1; tail -3 gpurun_out/r5_c5_${C5_BATCH:-16777216}.log | cut -c1-700; fi
 if has prof; then
   PMC=2 STEPS=1 bash scripts/prof_round2.sh c3 > gpurun_out/prof_c3.out 2>&1; tail -3 gpurun_out/prof_c3.out | cut -c1-200
   ROUND=5 python tools/make_round_md.py gpurun_out/prof_c3 c3 > gpurun_out/round5_c3.md; cp profiles/round5_c3_pmc.json gpurun_out/ 2>/dev/null

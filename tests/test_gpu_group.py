@@ -88,6 +88,34 @@ def test_group_sizes_stay_on_the_device(gpu_lib, n_ranks, lazy, monkeypatch):
     grp.close(); oc.close()
 
 
+def test_group_lazy_sizes_with_overloaded_owners(gpu_lib):
+    """The lazy protocol where an owner receives more than its regions take at full speed (-b30 over 4 ranks: 2048 regions per rank, a global
+    batch of 150 000 reads brings each ~4.4 M k-mers): the FIRST group of sources -- chosen by what they can send at most -- is applied from the
+    rows on the device before the host has a size, the others in further passes grouped by their sizes.  Same result as one batch."""
+    rng = np.random.default_rng(4242)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, per, nb, N = 150, 150_000, 3, 4
+    n = per * nb
+    genome = rng.choice(acgt, 60_000_000 + L)
+    seq = genome[(rng.integers(0, 60_000_000, n)[:, None] + np.arange(L)[None, :])].astype(np.uint8).reshape(-1)
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    k, b = 33, 30
+    oc = _oracle(k, b, seq, qual, off)
+    grp = gpu_lib.GpuGroup(k, b, [0] * N, max_batch_pos=per * (L + 1) // N + 4096)
+    launches = []
+    for t in range(nb):
+        a, e = t * per, (t + 1) * per
+        grp.count_host(gen.to_stream(seq[a * L:e * L], L, 10), gen.to_stream(qual[a * L:e * L], L, 33))
+        grp.sync()
+        launches.append([grp.ctx(i).stage_ms()[1] for i in range(N)])
+    assert grp.info()["slab_mode"] and grp.info()["lazy_batches"] == nb, grp.info()
+    assert all(v >= 2 for v in launches[0]), launches  # the cold batch: several passes per rank
+    assert grp.stats()["slow_buckets"] == 0
+    _compare(grp, oc)
+    grp.close(); oc.close()
+
+
 def test_group_device_shares_uneven(gpu_lib, g1):
     """bfcg_group_count_batch_dev with ragged shares, a rank that contributes nothing, FASTA (no qualities) and a second pass after reset"""
     rs, (seq, qual, off) = g1
