@@ -1100,7 +1100,7 @@ static int mg_process_any(bfcg_ctx_t *c, const void *d_recv, const uint32_t *seg
 // may this rank take batches that way?  A property of the context's parameters, not of its state (no order stamps, no per-position debug output):
 // the processes of a multi-process group must all answer alike.  (Level 2 in one pass or two: the slabs a source can fill -- nb1 x 8 x capacity
 // records -- are fewer than the level-2 buffers hold, so the bound sizes the grids and nothing can be overrun whatever the sizes turn out to be.)
-extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c) { return c->mg_slab_ok && !c->B.seen_out && !c->P.track && c->h_rows[0] != 0 && (uint64_t)8 * (1u << c->P.F1) * c->op_cap <= c->recv_cap; }
+extern "C" int bfcg_mg_async_ok(bfcg_ctx_t *c) { return c->mg_slab_ok && !c->B.seen_out && !c->P.track && c->h_rows[0] != 0 && (c->n_ranks == 1 || (uint64_t)8 * (1u << c->P.F1) * c->op_cap <= c->recv_cap); } // (one rank: what it "receives" is its own batch, <= max_batch_pos = its capacity)
 // (only the sources [s_lo, s_hi) of the receive buffer: an overloaded owner applies the others in further passes, bfcg_mg_process_slabs with their sizes)
 extern "C" int bfcg_mg_process_slabs_dev(bfcg_ctx_t *c, const void *d_recv, const uint32_t *d_rows_in, uint32_t slab_cap, uint64_t rec_bound, int s_lo, int s_hi, hipEvent_t *wait, int n_wait)
 {
