@@ -118,6 +118,7 @@ SYMBOLS = {
     "bfcg_stats": (C.c_int, [C.c_void_p, u64p]),
     "bfcg_progress": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_int]),
     "bfcg_partition_info": (C.c_int, [C.c_void_p, u64p]),
+    "bfcg_s1wc_launches": (C.c_uint64, []),
     "bfcg_table_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "bfcg_last_batch_ms": (C.c_int, [C.c_void_p, f32p]),
     "bfcg_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), u64p, C.c_int]),

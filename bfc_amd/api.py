@@ -321,6 +321,10 @@ class GpuCounter:
         self.L.bfcg_partition_info(self.ctx, out)
         return dict(one_pass=bool(out[0] & 1), level2_one_pass=bool(out[0] & 2), replayed_batches=int(out[1]))
 
+    def s1wc_launches(self):
+        """Launches of k_scatter1_wc (level 1 through write-combining buffers in LDS) by this process so far."""
+        return int(self.L.bfcg_s1wc_launches())
+
     def last_batch_ms(self):
         out = np.zeros(6, dtype=np.float32)
         self.L.bfcg_last_batch_ms(self.ctx, out.ctypes.data_as(f32p))

@@ -326,6 +326,8 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 		c->onepass_ok = n_ranks == 1 && P.F2 > 0 && !(e && atoi(e) == 0); // level 2 gathers a bucket's slabs: filters of 2^26 bits and more
 		uint64_t cap = (B.max_kmers + B.max_kmers / 8) / ((uint64_t)nb1 * 8) + 1;
 		while (cap * nb1 * 8 > 0xffffffffULL) --cap;
+		if (cap >= 1024) cap &= ~31ULL; // (32 records of 12 bytes are three 128-byte lines: k_scatter1_wc's chunks then begin on sector boundaries in every slab;
+		else if (cap >= 8) cap &= ~3ULL; //  four records are three 16-byte pieces: what its copy-out needs at least)
 		c->op_cap = (uint32_t)cap;
 		// a slab should expect ~1000 records or more: below that its fill scatters by more than the head room, and the batch would be replayed
 		c->op_min_pos = (e = getenv("BFCG_ONEPASS_MIN_TILES")) ? (uint64_t)atoi(e) * 4096 : (uint64_t)nb1 * 8 * 1024;
@@ -439,6 +441,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	for (int b = 0; b < 2; ++b) HIPCKN(hipHostMalloc(&c->h_snap[b], sizeof(unsigned long long) * ST_N * (ST_SLOTS + 1)));
 	const double t_c2 = dbg_now();
 	HIPCKN(set_bloom_lds_attr(P));
+	HIPCKN(set_scatter1wc_lds_attr());
 	const double t_c3 = dbg_now();
 	if (bfcg_reset(c) != 0) { bfcg_destroy(c); return NULL; }
 	if (timing) fprintf(stderr, "[T::bfcg_create] HIP runtime up %.3f s, device buffers %.3f s, kernel attributes %.3f s, filter and table cleared %.3f s\n", t_c1 - t_c0, t_c2 - t_c1, t_c3 - t_c2, dbg_now() - t_c3);

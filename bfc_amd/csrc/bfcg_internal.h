@@ -113,6 +113,7 @@ void run_seg_rehash(const KParams &P, const unsigned long long *old_tab, int old
 void run_seg_replay(const KParams &P, unsigned long long *seg_tab, const uint64_t *src, uint64_t n, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
 void run_seg_to_table(const KParams &P, const unsigned long long *seg_tab, uint32_t n_fine, unsigned long long *tab, unsigned long long *stats, uint64_t *ovf, uint32_t ovf_cap, hipStream_t st);
 hipError_t set_seg_lds_attr(void);
+hipError_t set_scatter1wc_lds_attr(void); // bfcg_scatter1wc.hip (k_scatter1_wc: level 1 through write-combining buffers in LDS)
 // apply the pages 0..pages-1 of the hand-over log to the segments (no bloom pass): before a batch that cannot use the log, and when the pipeline is drained
 void run_commit_pages(const KParams &P, const BatchBufs &B, uint32_t n_fine, uint32_t pages, hipStream_t st);
 #define BFCG_SEG_MAX_SHIFT 14 /* a segment's BLOCK must fit a CU's LDS: 2^14 slots = 128 KiB */

@@ -1,0 +1,324 @@
+// bfcg_scatter1wc.hip -- k_scatter1_wc (round 5): level 1 of the partition through WRITE-COMBINING BUFFERS in LDS.
+//
+// What it replaces on the default path: k_scatter1's tile skeleton (bfcg_kernels.hip) -- rank every record of a tile by a returning LDS add,
+// scan the bucket counters, reserve a place per (tile, bucket) run, stage the tile in bucket order, copy it out run by run: five barriers per
+// tile, ~61 of the kernel's 175 lane-instructions per k-mer, and runs of ~6 records = 77 bytes that leave as partial lines (WRITE_SIZE 1.54 x the
+// records; profiles/round5_c3.md).  Semantics are the same: count.c:72-89 (rolling k-mers, quality mask) and kmer.h:79-88 (the canonical hash)
+// per position -> a 12-byte record (y0 minus its bucket bits | y1 | quality flag | file index) in the slab of its level-1 bucket; the order
+// inside a slab is irrelevant because every record carries its file index.
+//
+// Here a workgroup of 1024 threads (one per CU) lives for the whole batch and owns, per bucket, ONE buffer of CAP records in LDS (2^13 records
+// in all: 96 KiB).  A record takes the slot a returning LDS add on the bucket's fill hands out and is written straight into the buffer; a full
+// buffer leaves as one CHUNK of CAP x 12 contiguous bytes (192 at 512 buckets: whole 32-byte sectors, whole lines for two chunks in three)
+// into room that the bucket's owner lane reserved from the slab's cursor one GROUP of chunks ahead.  A round (one tile of 4096 positions, four per
+// thread) has TWO barriers:
+//
+//   P1  every thread: the puts that found their buffer full in the previous round (slot - CAP: the buffer was flushed meanwhile), then the
+//       k-mers of its four positions: hash, record, slot = fill[bucket]++; slot < CAP: put; slot < 2 CAP: keep it in registers for the next P1;
+//       beyond that (one bucket drew more than two buffers' worth in one round: 3 in 10 000 (bucket, round) pairs on hashed k-mers) the lane
+//       reserves a chunk of its own and stores the record with CAP - 1 dead records behind it
+//   --- barrier A
+//   P2  roles by wave, nothing in common between them:
+//       waves 0-4   the NEXT tile's bit planes from the bases and qualities requested a round ago; request those of the tile after it; thread 0
+//                   settles the tile draw it issued a round ago and issues the next (these waves load and never store)
+//       waves 8-15  lane i owns bucket i: fill >= CAP -> (bucket, destination) into the wave's own list (ballot + mbcnt, no atomics), fill -= CAP,
+//                   the chunk pointer moves on; then the wave copies its list's chunks, 16 bytes per lane (these waves store; the only thing
+//                   they ever wait for is the reservation of the next group, requested when the last but one chunk of the current group is
+//                   handed out and consumed at the START of a later P2 -- when everything the wave has in flight is a round old)
+//   --- barrier B
+//
+// Loads, returning atomics and stores share one in-order counter on this chip (vmcnt): the roles are cut so that no wave waits for a load
+// behind its own fresh stores.  The slabs, their cursors, the dead records (all ones) in what was reserved and not filled, the overflow flag
+// and the statistics are exactly k_scatter1's (OnePass, bfcg_k1.h): k_seg_setup and level 2 read this kernel's output as they read that one's.
+// A tile belongs to an XCD for the DRAW (own counter first, then the others'), but every record of a workgroup goes to its home XCD's slabs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "kmer_dev.h"
+#include "bfcg_internal.h"
+#include "bfcg_dev.h"
+#include "bfcg_k1.h"
+
+using namespace bfcg;
+
+namespace {
+
+constexpr int WC_TILE = 4096, WC_BT = 1024, WC_S = WC_TILE / WC_BT, WC_RECS = 8192; // positions per round, threads, positions per thread, records in the buffers
+constexpr uint32_t WC_NONE = 0xffffffffu;
+
+template <typename W, int CAPL, int KC>
+__global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
+                                                       uint32_t *__restrict__ out, OnePass OP, uint32_t G)
+{
+	constexpr int TILE = WC_TILE, BT = WC_BT, S = WC_S;
+	constexpr uint32_t CAP = 1u << CAPL, NB = WC_RECS >> CAPL, PIECES = CAP * 3 / 4; // records per buffer, buckets, 16-byte pieces of a chunk
+	constexpr int PW = (TILE + 64) / 32 + 2, NC16 = (TILE + 64) / 16, NCH = NC16 + 1;
+	constexpr int OWN0 = 512;                        // first owner thread: lane i of waves 8.. owns bucket i
+	constexpr int NOW = (NB + WAVE - 1) / WAVE;      // owner (= copying) waves
+	static_assert(NCH <= OWN0 && OWN0 + NB <= BT && NB % WAVE == 0, "roles by wave");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_wc[];
+	uint32_t *buf = reinterpret_cast<uint32_t *>(smem_wc); // NB buffers of CAP records of 3 dwords
+	__shared__ uint32_t fill[NB];
+	__shared__ uint2 wl[NOW][WAVE];                 // per owner wave: this round's flushes (bucket, destination in 16-byte units)
+	__shared__ uint32_t planes[2 * 4 * PW];
+	__shared__ uint32_t s_draw[4];
+	const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+	const uint32_t RES = G << CAPL;                  // records per reservation
+	const uint32_t home = blockIdx.x & 7u;
+	const int64_t n_tiles = (n_pos + TILE - 1) / TILE;
+	const int b1_shift = P.R + P.F2;
+	const Pack3 PK = pack3_geom(P);
+	const W m = kmask<W>(P.k);
+
+	// ---- tile draws (k_scatter1's: one counter per XCD behind the cursors; own XCD first)
+	uint32_t *const tile_ctr = OP.cursor + (size_t)8 * NB * 32;
+	uint32_t draw_a = 0;
+	auto draw_issue = [&]() -> uint32_t { return draw_a < 8u ? atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u) : 0u; };
+	auto draw_settle = [&](uint32_t t) -> uint32_t {
+		while (draw_a < 8u) {
+			const uint32_t x = (blockIdx.x + draw_a) & 7u;
+			if ((int64_t)t * 8 + x < n_tiles) return t * 8u + x;
+			if (++draw_a < 8u) {
+				t = atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u);
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), here: otherwise the compiler's wait for this rare answer lands in front of the first reuse of its register -- inside P1's hashing, every round
+			}
+		}
+		return WC_NONE;
+	};
+	uint32_t draw = 0;
+	if (tid == 0) {
+		s_draw[0] = draw_settle(draw_issue()); s_draw[1] = draw_settle(draw_issue()); s_draw[2] = draw_settle(draw_issue());
+		draw = draw_issue();
+	}
+	for (int i = tid; i < (int)NB; i += BT) fill[i] = 0;
+	__syncthreads();
+	uint32_t t_cur = s_draw[0], t_next = s_draw[1], t_pf = s_draw[2];
+	if (t_cur == WC_NONE) return; // (nothing was reserved yet)
+
+	// ---- the input side (k_scatter1's): aligned 16-byte blocks at any offset, planes in block-stream coordinates
+	const int mis = (int)((uintptr_t)seq & 15);
+	const uint8_t *const sb = seq - mis, *const qb = qual ? qual - mis : nullptr;
+	const int64_t v_end = n_pos + mis, v_last = (v_end - 1) & ~(int64_t)15;
+	uint4 pf_s = make_uint4(0, 0, 0, 0), pf_q = make_uint4(0, 0, 0, 0);
+	const int pf_c = tid < NCH ? tid : NCH - 1;
+	auto prefetch = [&](uint32_t t) {
+		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)pf_c * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
+		pf_s = *reinterpret_cast<const uint4 *>(sb + at);
+		if (qual) pf_q = *reinterpret_cast<const uint4 *>(qb + at);
+	};
+	auto make_planes = [&](uint32_t t, uint32_t *pl) { // threads 0 .. NCH - 1
+		const int c = tid;
+		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)c * 16;
+		uint4 s4 = pf_s, q4 = pf_q;
+		if (v < mis || v + 16 > v_end) { // a block at the ragged ends of the batch: bytes outside it read as separators (qualities: 0)
+			const int lo = v >= mis ? 0 : mis - v >= 16 ? 16 : (int)(mis - v), hi = v_end - v >= 16 ? 16 : v_end - v <= 0 ? 0 : (int)(v_end - v);
+			const uint32_t bm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+			auto keep = [&](int d) { return (((bm >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu; };
+			const uint32_t k0 = keep(0), k1 = keep(1), k2 = keep(2), k3 = keep(3);
+			s4.x = (s4.x & k0) | (0x0a0a0a0au & ~k0); s4.y = (s4.y & k1) | (0x0a0a0a0au & ~k1); s4.z = (s4.z & k2) | (0x0a0a0a0au & ~k2); s4.w = (s4.w & k3) | (0x0a0a0a0au & ~k3);
+			q4.x &= k0; q4.y &= k1; q4.z &= k2; q4.w &= k3;
+		}
+		uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
+		bases4x(s4.x, 0, m0, m1, mn); bases4x(s4.y, 4, m0, m1, mn); bases4x(s4.z, 8, m0, m1, mn); bases4x(s4.w, 12, m0, m1, mn);
+		if (qual) {
+			const int T = P.q + 33;
+			if (T >= 1 && T <= 127) {
+				const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
+				quals4x(q4.x, 0, add, mq); quals4x(q4.y, 4, add, mq); quals4x(q4.z, 8, add, mq); quals4x(q4.w, 12, add, mq);
+			} else { quals16(q4.x, 0, P.q, mq); quals16(q4.y, 4, P.q, mq); quals16(q4.z, 8, P.q, mq); quals16(q4.w, 12, P.q, mq); }
+		} else mq = 0xffffu;
+		unsigned short *p16 = reinterpret_cast<unsigned short *>(pl);
+		if (c < NC16) {
+			p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
+			p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
+		} else { // the last block's piece shares its word with the first spare piece
+			pl[0 * PW + PW - 2] = m0; pl[1 * PW + PW - 2] = m1; pl[2 * PW + PW - 2] = mn; pl[3 * PW + PW - 2] = mq;
+		}
+		if (c < 4) pl[c * PW + PW - 1] = 0;
+	};
+
+	// ---- the buckets' owners: lane i of waves 8.. owns bucket i -- its slab's base, the chunk it hands out next, chunks left in the group, the next group
+	const bool owner = tid >= OWN0 && tid < OWN0 + (int)NB;
+	const uint32_t ob = owner ? (uint32_t)(tid - OWN0) : 0u, ow = ob / WAVE;
+	const uint32_t slab = (ob * 8u + home) * OP.cap + (ob - OP.own_lo < OP.own_n ? OP.own_delta : 0u);
+	uint32_t *const my_cursor = &OP.cursor[((size_t)home * NB + ob) * 32];
+	uint32_t pos = 0, left = G, npos = 0;
+	bool sw = false, req = false;
+	auto claim = [&](uint32_t base, uint32_t n) -> uint32_t { // a reservation's answer: a full slab poisons the batch (it is replayed), write where it does no harm
+		if (base + n > OP.cap) { OP.flags[0] = 1; return 0u; }
+		return base;
+	};
+	if (owner) pos = claim(atomicAdd(my_cursor, RES), RES);
+
+	uint4 *const out16 = reinterpret_cast<uint4 *>(out);
+	const uint4 *const buf16 = reinterpret_cast<const uint4 *>(smem_wc);
+	auto copy_list = [&](uint32_t n) { // this wave's list of n chunks: 16 bytes per lane and step
+		for (uint32_t x = lane; x < n * PIECES; x += WAVE) {
+			const uint32_t j = x / PIECES, p = x - j * PIECES;
+			const uint2 e = wl[ow][j];
+			out16[(size_t)e.y + p] = buf16[e.x * PIECES + p];
+		}
+	};
+
+	if (tid < NCH) { prefetch(t_cur); make_planes(t_cur, planes); if (t_next != WC_NONE) prefetch(t_next); }
+	__syncthreads();
+
+	RecW<3> w[S];
+	uint32_t pend[S]; // a record that found its buffer full: where it goes once the buffer has been flushed (record index in buf), else WC_NONE
+#pragma unroll
+	for (int j = 0; j < S; ++j) pend[j] = WC_NONE;
+	uint32_t n_k = 0, n_h = 0;
+	int cur = 0;
+	auto put = [&](uint32_t o, const RecW<3> &r) { uint32_t *p = buf + o * 3u; p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; };
+
+	for (;;) {
+		// ---------------- P1
+#pragma unroll
+		for (int j = 0; j < S; ++j) if (pend[j] != WC_NONE) { put(pend[j], w[j]); pend[j] = WC_NONE; }
+		const uint32_t *pl = planes + cur * 4 * PW;
+		uint32_t sl[S], bo[S]; // slot; bucket << CAPL
+#pragma unroll
+		for (int j = 0; j < S; ++j) {
+			int r = j * BT + tid;
+			asm volatile("" : "+v"(r)); // (opaque: nothing of a body is hoisted out of the round loop)
+			bool hi, have;
+			U2 y0, y1;
+			if constexpr (sizeof(W) == 8) have = kmer_at2<TILE, KC>(pl, r + mis, P.k, y0, y1, hi);
+			else {
+				W a0, a1;
+				have = kmer_at<W, TILE>(pl, r + mis, P.k, m, a0, a1, hi);
+				y0.lo = (uint32_t)a0; y0.hi = 0; y1.lo = (uint32_t)a1; y1.hi = 0;
+			}
+			sl[j] = WC_NONE; bo[j] = 0;
+			if (have) {
+				const uint32_t b = (y0.lo >> b1_shift) & (NB - 1u);
+				pack3_fast(w[j], PK, y0, y1, P.idx_rank | (t_cur * (uint32_t)TILE + (uint32_t)r), hi);
+				sl[j] = atomicAdd(&fill[b], 1u); bo[j] = b << CAPL;
+				++n_k; n_h += hi;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < S; ++j) {
+			if (sl[j] < CAP) put(bo[j] + sl[j], w[j]);
+			else if (sl[j] < 2u * CAP) pend[j] = bo[j] + sl[j] - CAP;
+			else if (sl[j] != WC_NONE) { // more than two buffers' worth for one bucket in one round: a chunk of its own, the record and CAP - 1 dead ones
+				const uint32_t b = bo[j] >> CAPL;
+				const uint32_t base = claim(atomicAdd(&OP.cursor[((size_t)home * NB + b) * 32], CAP), CAP);
+				uint32_t *d = out + (size_t)((b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u) + base) * 3u;
+				d[0] = w[j].d[0]; d[1] = w[j].d[1]; d[2] = w[j].d[2];
+				for (uint32_t z = 3; z < CAP * 3u; ++z) d[z] = 0xffffffffu;
+			}
+		}
+		__syncthreads(); // ---------------- A: every slot of this round is drawn, every put below CAP is in its buffer
+		// ---------------- P2
+		if (tid < NCH) {
+			if (tid == 0) { s_draw[3] = draw_settle(draw); draw = draw_issue(); } // (the draw issued a round ago; the next one)
+			if (t_next != WC_NONE) {
+				make_planes(t_next, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
+				if (t_pf != WC_NONE) prefetch(t_pf);
+			}
+		} else if (owner) {
+			if (sw) { pos = claim(npos, RES); left = G; sw = false; req = false; } // (requested at least one flush ago; everything this wave has in flight is a round old)
+			const uint32_t f = fill[ob];
+			const bool due = f >= CAP;
+			const unsigned long long dm = __ballot(due);
+			if (due) {
+				const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+				wl[ow][my] = make_uint2(ob, ((slab + pos) >> 2) * 3u);
+				fill[ob] = (f < 2u * CAP ? f : 2u * CAP) - CAP;
+				pos += CAP;
+				if (--left == 0) sw = true;
+			}
+			if (left <= 1u && !req) { npos = atomicAdd(my_cursor, RES); req = true; }
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			copy_list((uint32_t)__popcll(dm));
+		}
+		__syncthreads(); // ---------------- B: the flushed buffers are free, the next tile's planes stand
+		t_cur = t_next; t_next = t_pf; t_pf = s_draw[3]; cur ^= 1;
+		if (t_cur == WC_NONE) break;
+	}
+
+	// ---- the end: what is left in the buffers leaves padded with dead records; what was reserved and not used is dead
+#pragma unroll
+	for (int j = 0; j < S; ++j) if (pend[j] != WC_NONE) put(pend[j], w[j]);
+	__syncthreads();
+	if (owner) {
+		if (sw) { pos = claim(npos, RES); left = G; sw = false; req = false; }
+		const uint32_t f = fill[ob]; // <= CAP
+		for (uint32_t z = f; z < CAP; ++z) { uint32_t *p = buf + ((ob << CAPL) + z) * 3u; p[0] = 0xffffffffu; p[1] = 0xffffffffu; p[2] = 0xffffffffu; }
+		wl[ow][lane] = make_uint2(ob, ((slab + pos) >> 2) * 3u);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		copy_list(WAVE);
+		const uint4 dead = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+		uint4 *d = out16 + (size_t)(((slab + pos + CAP) >> 2) * 3u);
+		for (uint32_t z = 0; z < (left - 1u) * PIECES; ++z) d[z] = dead; // the rest of the current group
+		if (req) { // a group that was requested and never begun
+			const uint32_t base = npos;
+			if (base + RES > OP.cap) OP.flags[0] = 1; // (k_seg_setup reads the slab up to min(cursor, capacity): a piece of this group would lie inside it, unwritten)
+			else { d = out16 + (size_t)(((slab + base) >> 2) * 3u); for (uint32_t z = 0; z < G * PIECES; ++z) d[z] = dead; }
+		}
+	}
+	{ // the statistics k_hist1 keeps in the two-pass partition: k-mers, high-quality k-mers (as k_scatter1's one-pass variant does)
+		for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
+		if (lane == 0 && n_k) {
+			unsigned long long *st = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+			atomicAdd(&st[ST_KMERS], (unsigned long long)n_k); atomicAdd(&st[ST_HIGH], (unsigned long long)n_h);
+		}
+	}
+}
+
+template <typename W, int CAPL, int KC>
+void launch_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)
+{
+	hipLaunchKernelGGL((k_scatter1_wc<W, CAPL, KC>), dim3(grid), dim3(WC_BT), (size_t)WC_RECS * 12, st, P, seq, qual, n_pos, out, OP, G);
+}
+
+} // namespace
+
+namespace bfcg {
+
+hipError_t set_scatter1wc_lds_attr(void)
+{
+	hipError_t e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint64_t, 4, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint64_t, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint64_t, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint32_t, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint32_t, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
+	return e;
+}
+
+// Whether a one-pass stage A of this geometry can run k_scatter1_wc: 12-byte records packed from halves with the level-1 bucket a bit field of
+// y0's low word (scatter1_fast, checked by the caller), 2^8 or 2^9 level-1 buckets (2^13 records of buffers in 96 KiB: 32 or 16 per bucket),
+// slabs that begin on 16-byte boundaries, and slabs large enough for what the workgroups leave unused (a group and a partial buffer per
+// workgroup and bucket at the end: dead records).  BFCG_S1_WC=0: never; =2: whenever the geometry allows (tests: tiny slabs overflow and are replayed).
+bool scatter1_wc_ok(const KParams &P, const OnePass &OP, unsigned n_wgs, uint32_t *G_out)
+{
+	const char *e = getenv("BFCG_S1_WC");
+	const int mode = e ? atoi(e) : 1;
+	if (mode == 0) return false;
+	if (P.F1 != 8 && P.F1 != 9) return false;
+	if ((OP.cap & 3u) || (OP.own_delta & 3u)) return false;
+	const uint32_t capl = 13 - P.F1, cap_rec = 1u << capl;
+	uint32_t G = OP.chunk >> capl; if (G < 1) G = 1; if (G > 4) G = 4;
+	if (mode != 2 && (uint64_t)(n_wgs / 8 + 1) * (G * cap_rec + cap_rec) * 8 > OP.cap) return false;
+	*G_out = G;
+	return true;
+}
+
+static unsigned long long g_wc_launches = 0; // (process-wide, for the tests: did a run take this kernel at all)
+
+void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)
+{
+	__atomic_fetch_add(&g_wc_launches, 1ull, __ATOMIC_RELAXED);
+	if (P.k > 32) {
+		if (P.F1 == 9) { if (P.k == 33) launch_wc<uint64_t, 4, 33>(P, seq, qual, n_pos, out, OP, G, grid, st); else launch_wc<uint64_t, 4, 0>(P, seq, qual, n_pos, out, OP, G, grid, st); }
+		else launch_wc<uint64_t, 5, 0>(P, seq, qual, n_pos, out, OP, G, grid, st);
+	} else {
+		if (P.F1 == 9) launch_wc<uint32_t, 4, 0>(P, seq, qual, n_pos, out, OP, G, grid, st);
+		else launch_wc<uint32_t, 5, 0>(P, seq, qual, n_pos, out, OP, G, grid, st);
+	}
+}
+
+} // namespace bfcg
+
+extern "C" uint64_t bfcg_s1wc_launches(void) { return __atomic_load_n(&bfcg::g_wc_launches, __ATOMIC_RELAXED); }

@@ -218,6 +218,8 @@ int bfcg_table_info(bfcg_ctx_t *c, int out[4]);
  * use, bit 1 = level 2 runs in one pass too (a slab per bloom region, no k_hist2); out[1] batches that had to be replayed through the two-pass
  * partition so far (input with few, often repeated k-mers overflows a one-pass slab) */
 int bfcg_partition_info(bfcg_ctx_t *c, uint64_t out[2]);
+/* launches of k_scatter1_wc (level 1 of the one-pass partition through write-combining buffers in LDS: bfcg_scatter1wc.hip) by this process so far */
+uint64_t bfcg_s1wc_launches(void);
 /* batches handled without aggregation (k-mers that hardly repeat inside a batch: seen k-mers are streamed to the table kernel) */
 uint64_t bfcg_stream_batches(bfcg_ctx_t *c);
 

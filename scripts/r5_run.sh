@@ -94,3 +94,10 @@ PY
   for t in ${E2E_TS:-64 128 256 64 128}; do echo "== -t$t"; ( time oracle/_ref/bfc-dropin -E -s 250m -k 33 -t$t /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -16; echo; done > gpurun_out/r5_e2e_t.txt 2>&1
   rm -f /dev/shm/c3e.fq; grep -E "==|Real time|^real|waited" gpurun_out/r5_e2e_t.txt
 fi
+if has wc; then  # k_scatter1_wc: its fuzz family, then c3 with the tile kernel (BFCG_S1_WC=0) against the write-combining one (default), one box
+  timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x -k "write_combining" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_wc_fuzz.log; tail -15 gpurun_out/r5_wc_fuzz.log
+  for v in ${WC_AB:-0 1 0 1}; do
+    BFCG_S1_WC=$v timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary ${AB_ARGS:---no-secondary} > gpurun_out/r5_wc_$v.json 2> gpurun_out/r5_wc_$v.log; echo "BFCG_S1_WC=$v rc=$?"
+    summ gpurun_out/r5_wc_$v.json; tail -3 gpurun_out/r5_wc_$v.log | cut -c1-300
+  done
+fi

@@ -193,6 +193,44 @@ def test_random_configuration_k33_on_tiny_slabs(gpu_lib, seed, monkeypatch):
     _check(gpu_lib, prm, seq, qual, off, cuts, kw)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch):
+    """k_scatter1_wc (round 5, bfcg_scatter1wc.hip): level 1 of the one-pass partition through write-combining buffers in LDS -- a buffer of 16 or 32
+    records per bucket, full buffers leave as whole chunks into room reserved a group ahead, what finds its buffer full waits a round in
+    registers, what finds it full twice over takes a chunk of its own, dead records in everything reserved and not filled.  Forced (BFCG_S1_WC=2)
+    onto draws whose slabs expect a handful of records, with 8 / 16 / 64 workgroups sharing them and 2^8 / 2^9 level-1 buckets: every path of the
+    kernel runs -- spills on the low-complexity draws, slabs that overflow because of the padding (replayed through two passes), tiles stolen
+    from other XCDs' counters, batches of less than one tile -- for k = 33 at compile time, k = 35 at run time and k <= 32 on one word.  Bit for
+    bit the oracle's filter(s), statistics and table, like every other draw."""
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    monkeypatch.setenv("BFCG_S1_WC", "2")
+    monkeypatch.setenv("BFCG_S1_WC_WGS", str([8, 16, 64][seed % 3]))
+    monkeypatch.setenv("BFCG_F1", str(8 + (seed & 1)))
+    if seed % 4 == 3:
+        monkeypatch.setenv("BFCG_S1_CHUNK", "64")  # (four chunks of 16 per reservation)
+    prm, seq, qual, off, cuts, kw = _draw(52000 + seed, scale=12, b_range=(28, 34))
+    prm = dict(prm, k=[33, 33, 35, 31, 27][seed % 5])
+    prm["l_pre"] = min(prm["l_pre"], 2 * prm["k"] - 2)
+    kw.pop("region_shift", None)  # (regions of 2^8 blocks: the level split asked for above exists for every filter drawn)
+    _check(gpu_lib, prm, seq, qual, off, cuts, kw)
+
+
+def test_write_combining_level1_was_exercised(gpu_lib, monkeypatch):
+    """the family above is only worth its name if the kernel runs: one fixed draw, the process-wide launch counter before and after"""
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    monkeypatch.setenv("BFCG_S1_WC", "2")
+    monkeypatch.setenv("BFCG_S1_WC_WGS", "16")
+    monkeypatch.setenv("BFCG_F1", "9")
+    prm, seq, qual, off, cuts, kw = _draw(52001, scale=12, b_range=(30, 31))
+    kw.pop("region_shift", None)
+    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
+    before = g.s1wc_launches(); g.close()
+    _check(gpu_lib, dict(prm, k=33, fm=0, l_pre=20), seq, qual, off, cuts, kw)
+    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
+    after = g.s1wc_launches(); g.close()
+    assert after > before, (before, after)
+
+
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("f1", [2, 7, 10])
 def test_random_configuration_uneven_level_split(gpu_lib, seed, f1, monkeypatch):
