@@ -21,14 +21,19 @@
 //   P2  roles by wave, nothing in common between them:
 //       waves 0-4   the NEXT tile's bit planes from the bases and qualities requested a round ago; request those of the tile after it; thread 0
 //                   settles the tile draw it issued a round ago and issues the next (these waves load and never store)
+//       waves 5-7   the RESERVERS, one of them per round in turn: a bucket whose owner asked for its next group (a word in LDS) gets it by a
+//                   returning atomic on the slab's cursor; the answer is published in LDS at the wave's next turn, three rounds later (these
+//                   waves issue returning atomics and nothing else: what they wait for is three rounds old)
 //       waves 8-15  lane i owns bucket i: fill >= CAP -> (bucket, destination) into the wave's own list (ballot + mbcnt, no atomics), fill -= CAP,
-//                   the chunk pointer moves on; then the wave copies its list's chunks, 16 bytes per lane (these waves store; the only thing
-//                   they ever wait for is the reservation of the next group, requested when the last but one chunk of the current group is
-//                   handed out and consumed at the START of a later P2 -- when everything the wave has in flight is a round old)
+//                   the chunk pointer moves on -- into the next group, taken from LDS, when the current one is used up; the next but one is
+//                   asked for as soon as a group is begun; then the wave copies its list's chunks, 16 bytes per lane (these waves store and
+//                   never wait for memory: a store is acknowledged ~5 us after its issue on this chip, more than a round -- the first cut, whose
+//                   owners reserved for themselves, spent 5 200 of a round's 14 800 cycles in that wait; profiles/round5_k_scatter1_wc.md)
 //   --- barrier B
 //
 // Loads, returning atomics and stores share one in-order counter on this chip (vmcnt): the roles are cut so that no wave waits for a load
-// behind its own fresh stores.  The slabs, their cursors, the dead records (all ones) in what was reserved and not filled, the overflow flag
+// or an atomic behind its own fresh stores.  An owner whose next group is not there when it needs it (a bucket that fills four buffers in
+// five rounds: 3 in 1 000 groups) reserves for itself and waits.  The slabs, their cursors, the dead records (all ones) in what was reserved and not filled, the overflow flag
 // and the statistics are exactly k_scatter1's (OnePass, bfcg_k1.h): k_seg_setup and level 2 read this kernel's output as they read that one's.
 // A tile belongs to an XCD for the DRAW (own counter first, then the others'), but every record of a workgroup goes to its home XCD's slabs.
 #include <hip/hip_runtime.h>
@@ -62,6 +67,9 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	__shared__ uint2 wl[NOW][WAVE];                 // per owner wave: this round's flushes (bucket, destination in 16-byte units)
 	__shared__ uint32_t planes[2 * 4 * PW];
 	__shared__ uint32_t s_draw[4];
+	// owner -> reservers: rq[b] = 1: bucket b's next group, please (the reserver that takes the request up clears it); reservers -> owner: res[b] = the
+	// group's base in the slab, then rdy[b] = 1 (the owner clears it when it takes the group).  An owner has at most one request open.
+	__shared__ uint32_t rq[NB], rdy[NB], res[NB];
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1);
 	const uint32_t RES = G << CAPL;                  // records per reservation
 	const uint32_t home = blockIdx.x & 7u;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 		s_draw[0] = draw_settle(draw_issue()); s_draw[1] = draw_settle(draw_issue()); s_draw[2] = draw_settle(draw_issue());
 		draw = draw_issue();
 	}
-	for (int i = tid; i < (int)NB; i += BT) fill[i] = 0;
+	for (int i = tid; i < (int)NB; i += BT) { fill[i] = 0; rq[i] = 0; rdy[i] = 0; }
 	__syncthreads();
 	uint32_t t_cur = s_draw[0], t_next = s_draw[1], t_pf = s_draw[2];
 	if (t_cur == WC_NONE) return; // (nothing was reserved yet)
@@ -142,21 +150,35 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	const uint32_t ob = owner ? (uint32_t)(tid - OWN0) : 0u, ow = ob / WAVE;
 	const uint32_t slab = (ob * 8u + home) * OP.cap + (ob - OP.own_lo < OP.own_n ? OP.own_delta : 0u);
 	uint32_t *const my_cursor = &OP.cursor[((size_t)home * NB + ob) * 32];
-	uint32_t pos = 0, left = G, npos = 0;
-	bool sw = false, req = false;
+	uint32_t pos = 0, left = G;
+	bool open = false; // a request for the next group is on its way (rq, a reserver's register, or res / rdy)
+	const uint32_t sig = G > 1u ? G - 1u : 1u; // ask for the next group when this many chunks of the current one are left (as soon as it is begun)
 	auto claim = [&](uint32_t base, uint32_t n) -> uint32_t { // a reservation's answer: a full slab poisons the batch (it is replayed), write where it does no harm
 		if (base + n > OP.cap) { OP.flags[0] = 1; return 0u; }
 		return base;
 	};
 	if (owner) pos = claim(atomicAdd(my_cursor, RES), RES);
+	// ---- the reservers: waves RSV0 .. RSV0 + NRW - 1, wave r active in rounds = r (mod NRW); lane l serves buckets l, l + 64, ...
+	constexpr int RSV0 = 5, NRW = 3, NRS = NB / WAVE / 2; // (a lane serves NRS PAIRS of buckets l + 128 s, l + 128 s + 64 and takes up one request per pair and turn)
+	const int rsv = tid >= RSV0 * WAVE && tid < (RSV0 + NRW) * WAVE ? tid / WAVE - RSV0 : -1;
+	uint32_t rv[NRS], infl = 0; // answers on their way: bit s of infl = rv[s] is one, bit 8 + s = it is the pair's second bucket's
+#pragma unroll
+	for (int u = 0; u < NRS; ++u) rv[u] = 0;
+	uint32_t round = 0;
 
 	uint4 *const out16 = reinterpret_cast<uint4 *>(out);
 	const uint4 *const buf16 = reinterpret_cast<const uint4 *>(smem_wc);
-	auto copy_list = [&](uint32_t n) { // this wave's list of n chunks: 16 bytes per lane and step
-		for (uint32_t x = lane; x < n * PIECES; x += WAVE) {
-			const uint32_t j = x / PIECES, p = x - j * PIECES;
-			const uint2 e = wl[ow][j];
-			out16[(size_t)e.y + p] = buf16[e.x * PIECES + p];
+	auto copy_list = [&](uint32_t n) { // this wave's list of n chunks: 16 bytes per lane and step, two steps' loads in flight
+		const uint32_t np = n * PIECES;
+		for (uint32_t x = lane; x < np; x += 2 * WAVE) {
+			const uint32_t x1 = x + WAVE;
+			const bool two = x1 < np;
+			const uint32_t j0 = x / PIECES, p0 = x - j0 * PIECES, j1 = two ? x1 / PIECES : j0, p1 = two ? x1 - j1 * PIECES : p0;
+			const uint2 e0 = wl[ow][j0], e1 = wl[ow][j1];
+			const uint4 v0 = buf16[e0.x * PIECES + p0], v1 = buf16[e1.x * PIECES + p1];
+			if (BFCG_ABL(P, 256)) { if (v0.x == 0x12345678u && v1.y == 0x9abcdef0u) out16[0] = v0; continue; } // (measurement: the copy's LDS side without its stores)
+			out16[(size_t)e0.y + p0] = v0;
+			if (two) out16[(size_t)e1.y + p1] = v1;
 		}
 	};
 
@@ -171,6 +193,9 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	int cur = 0;
 	auto put = [&](uint32_t o, const RecW<3> &r) { uint32_t *p = buf + o * 3u; p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; };
 
+#ifdef BFCG_MEASURE // phase clocks (scripts/s1wc_phases.py): thread 0 and the first owner lane, summed per workgroup into the statistics' spare words
+	unsigned long long tm_p1 = 0, tm_p2 = 0, tm_ld = 0, tm_ow = 0, tm_w8 = 0, tm_n = 0, tm_t = __builtin_readcyclecounter();
+#endif
 	for (;;) {
 		// ---------------- P1
 #pragma unroll
@@ -209,7 +234,13 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 				for (uint32_t z = 3; z < CAP * 3u; ++z) d[z] = 0xffffffffu;
 			}
 		}
+#ifdef BFCG_MEASURE
+		if (tid == OWN0) tm_w8 += __builtin_readcyclecounter() - tm_t;
+#endif
 		__syncthreads(); // ---------------- A: every slot of this round is drawn, every put below CAP is in its buffer
+#ifdef BFCG_MEASURE
+		{ const unsigned long long now = __builtin_readcyclecounter(); tm_p1 += now - tm_t; tm_t = now; }
+#endif
 		// ---------------- P2
 		if (tid < NCH) {
 			if (tid == 0) { s_draw[3] = draw_settle(draw); draw = draw_issue(); } // (the draw issued a round ago; the next one)
@@ -217,8 +248,31 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 				make_planes(t_next, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
 				if (t_pf != WC_NONE) prefetch(t_pf);
 			}
+		} else if (rsv >= 0) {
+			if ((int)(round % NRW) == rsv) {
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), once and for what is NRW rounds old (said here: the compiler's own waits would sit between the new requests below)
+#pragma unroll
+				for (int u = 0; u < NRS; ++u) { // first every answer asked for at this wave's last turn, NRW rounds ago (one wait, for what is long there) ...
+					if (infl & (1u << u)) {
+						const uint32_t b = (uint32_t)lane + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
+						res[b] = rv[u];
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						rdy[b] = 1u;
+					}
+				}
+				infl = 0;
+#pragma unroll
+				for (int u = 0; u < NRS; ++u) { // ... then the new requests (nothing below waits for them)
+					const uint32_t b0 = (uint32_t)lane + (uint32_t)u * 2u * WAVE, b1 = b0 + WAVE;
+					const bool n0 = rq[b0] != 0u, n1 = rq[b1] != 0u;
+					if (n0 | n1) {
+						const uint32_t b = n0 ? b0 : b1;
+						rv[u] = atomicAdd(&OP.cursor[((size_t)home * NB + b) * 32], RES);
+						rq[b] = 0u; infl |= (n0 ? 0x1u : 0x101u) << u;
+					}
+				}
+			}
 		} else if (owner) {
-			if (sw) { pos = claim(npos, RES); left = G; sw = false; req = false; } // (requested at least one flush ago; everything this wave has in flight is a round old)
 			const uint32_t f = fill[ob];
 			const bool due = f >= CAP;
 			const unsigned long long dm = __ballot(due);
@@ -227,14 +281,29 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 				wl[ow][my] = make_uint2(ob, ((slab + pos) >> 2) * 3u);
 				fill[ob] = (f < 2u * CAP ? f : 2u * CAP) - CAP;
 				pos += CAP;
-				if (--left == 0) sw = true;
+				if (--left == 0) { // the next group
+					uint32_t base;
+					if (open && rdy[ob] != 0u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); base = res[ob]; rdy[ob] = 0u; open = false; }
+					else { // not there yet (or never asked for: the first groups of G = 1): this lane reserves for itself and waits, behind its wave's stores
+						base = atomicAdd(my_cursor, RES);
+						__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) here, not in front of the register's next use
+					}
+					pos = claim(base, RES); left = G;
+				}
 			}
-			if (left <= 1u && !req) { npos = atomicAdd(my_cursor, RES); req = true; }
+			if (left <= sig && !open) { rq[ob] = 1u; open = true; }
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			copy_list((uint32_t)__popcll(dm));
+			if (!BFCG_ABL(P, 512)) copy_list((uint32_t)__popcll(dm));
 		}
+#ifdef BFCG_MEASURE
+		if (tid == 0) tm_ld += __builtin_readcyclecounter() - tm_t;
+		if (tid == OWN0) tm_ow += __builtin_readcyclecounter() - tm_t;
+#endif
 		__syncthreads(); // ---------------- B: the flushed buffers are free, the next tile's planes stand
-		t_cur = t_next; t_next = t_pf; t_pf = s_draw[3]; cur ^= 1;
+#ifdef BFCG_MEASURE
+		{ const unsigned long long now = __builtin_readcyclecounter(); tm_p2 += now - tm_t; tm_t = now; ++tm_n; }
+#endif
+		t_cur = t_next; t_next = t_pf; t_pf = s_draw[3]; cur ^= 1; ++round;
 		if (t_cur == WC_NONE) break;
 	}
 
@@ -242,22 +311,35 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 #pragma unroll
 	for (int j = 0; j < S; ++j) if (pend[j] != WC_NONE) put(pend[j], w[j]);
 	__syncthreads();
+	const uint4 dead = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+	auto dead_group = [&](uint32_t b_slab, uint32_t base) { // a group that was reserved and never begun
+		if (base + RES > OP.cap) { OP.flags[0] = 1; return; } // (k_seg_setup reads the slab up to min(cursor, capacity): a piece of this group would lie inside it, unwritten)
+		uint4 *d = out16 + (size_t)(((b_slab + base) >> 2) * 3u);
+		for (uint32_t z = 0; z < G * PIECES; ++z) d[z] = dead;
+	};
 	if (owner) {
-		if (sw) { pos = claim(npos, RES); left = G; sw = false; req = false; }
 		const uint32_t f = fill[ob]; // <= CAP
 		for (uint32_t z = f; z < CAP; ++z) { uint32_t *p = buf + ((ob << CAPL) + z) * 3u; p[0] = 0xffffffffu; p[1] = 0xffffffffu; p[2] = 0xffffffffu; }
 		wl[ow][lane] = make_uint2(ob, ((slab + pos) >> 2) * 3u);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		copy_list(WAVE);
-		const uint4 dead = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
 		uint4 *d = out16 + (size_t)(((slab + pos + CAP) >> 2) * 3u);
 		for (uint32_t z = 0; z < (left - 1u) * PIECES; ++z) d[z] = dead; // the rest of the current group
-		if (req) { // a group that was requested and never begun
-			const uint32_t base = npos;
-			if (base + RES > OP.cap) OP.flags[0] = 1; // (k_seg_setup reads the slab up to min(cursor, capacity): a piece of this group would lie inside it, unwritten)
-			else { d = out16 + (size_t)(((slab + base) >> 2) * 3u); for (uint32_t z = 0; z < G * PIECES; ++z) d[z] = dead; }
+		if (open && rdy[ob] != 0u) dead_group(slab, res[ob]); // a group that was published and never taken
+	} else if (rsv >= 0) { // groups whose answers never were published
+#pragma unroll
+		for (int u = 0; u < NRS; ++u) if (infl & (1u << u)) {
+			const uint32_t b = (uint32_t)lane + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
+			dead_group((b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u), rv[u]);
 		}
 	}
+#ifdef BFCG_MEASURE
+	if (tid == 0 || tid == OWN0) {
+		unsigned long long *st = OP.stats + (size_t)(blockIdx.x & (ST_SLOTS - 1)) * ST_N;
+		if (tid == 0) { atomicAdd(&st[10], tm_p1); atomicAdd(&st[11], tm_p2); atomicAdd(&st[12], tm_ld); atomicAdd(&st[15], tm_n); }
+		else { atomicAdd(&st[13], tm_ow); atomicAdd(&st[14], tm_w8); }
+	}
+#endif
 	{ // the statistics k_hist1 keeps in the two-pass partition: k-mers, high-quality k-mers (as k_scatter1's one-pass variant does)
 		for (int o = 32; o; o >>= 1) { n_k += __shfl_down(n_k, o); n_h += __shfl_down(n_h, o); }
 		if (lane == 0 && n_k) {

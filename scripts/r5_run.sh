@@ -101,3 +101,6 @@ if has wc; then  # k_scatter1_wc: its fuzz family, then c3 with the tile kernel 
     summ gpurun_out/r5_wc_$v.json; tail -3 gpurun_out/r5_wc_$v.log | cut -c1-300
   done
 fi
+if has wcph; then  # k_scatter1_wc's phase clocks (the -DBFCG_MEASURE library, built before the call): cycles per round, P1 / P2
+  for e in ${WCPH_ENVS:-X=1}; do env $e TAG=$e timeout 300 python scripts/s1wc_phases.py 2>&1 | tail -2; done | tee gpurun_out/r5_wc_phases.txt
+fi
