@@ -19,8 +19,8 @@
 //       reserves a chunk of its own and stores the record with CAP - 1 dead records behind it
 //   --- barrier A
 //   P2  roles by wave, nothing in common between them:
-//       waves 0-4   the NEXT tile's bit planes from the bases and qualities requested a round ago; request those of the tile after it; thread 0
-//                   settles the tile draw it issued a round ago and issues the next (these waves load and never store)
+//       waves 0-4   the NEXT tile's three base planes from the bases requested a round ago (the quality plane: 261 lanes of waves 8-12, beside
+//                   their owner work); request those of the tile after it; thread 0 settles the tile draw it issued a round ago and issues the next
 //       waves 5-7   the RESERVERS, one of them per round in turn: a bucket whose owner asked for its next group (a word in LDS) gets it by a
 //                   returning atomic on the slab's cursor; the answer is published in LDS at the wave's next turn, three rounds later (these
 //                   waves issue returning atomics and nothing else: what they wait for is three rounds old)
@@ -60,13 +60,15 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	constexpr int PW = (TILE + 64) / 32 + 2, NC16 = (TILE + 64) / 16, NCH = NC16 + 1;
 	constexpr int OWN0 = 512;                        // first owner thread: lane i of waves 8.. owns bucket i
 	constexpr int NOW = (NB + WAVE - 1) / WAVE;      // owner (= copying) waves
-	static_assert(NCH <= OWN0 && OWN0 + NB <= BT && NB % WAVE == 0, "roles by wave");
+	static_assert(NCH <= 5 * WAVE && OWN0 + NCH <= BT && OWN0 + NB <= BT && NB % WAVE == 0, "roles by wave");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_wc[];
 	uint32_t *buf = reinterpret_cast<uint32_t *>(smem_wc); // NB buffers of CAP records of 3 dwords
 	__shared__ uint32_t fill[NB];
-	__shared__ uint2 wl[NOW][WAVE];                 // per owner wave: this round's flushes (bucket, destination in 16-byte units)
+	__shared__ uint2 wl[NB];                        // this round's flushes (bucket, destination in 16-byte units), nq[round & 1] of them
+	__shared__ uint32_t nq[2];
 	__shared__ uint32_t planes[2 * 4 * PW];
 	__shared__ uint32_t s_draw[4];
+	__shared__ uint32_t s_draw_a;                   // (thread 0) XCDs whose tile counters this workgroup has found exhausted, counted from its own
 	// owner -> reservers: rq[b] = 1: bucket b's next group, please (the reserver that takes the request up clears it); reservers -> owner: res[b] = the
 	// group's base in the slab, then rdy[b] = 1 (the owner clears it when it takes the group).  An owner has at most one request open.
 	__shared__ uint32_t rq[NB], rdy[NB], res[NB];
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 
 	// ---- tile draws (k_scatter1's: one counter per XCD behind the cursors; own XCD first)
 	uint32_t *const tile_ctr = OP.cursor + (size_t)8 * NB * 32;
-	uint32_t draw_a = 0;
+#define draw_a s_draw_a
+	if (tid == 0) s_draw_a = 0;
 	auto draw_issue = [&]() -> uint32_t { return draw_a < 8u ? atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u) : 0u; };
 	auto draw_settle = [&](uint32_t t) -> uint32_t {
 		while (draw_a < 8u) {
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 		draw = draw_issue();
 	}
 	for (int i = tid; i < (int)NB; i += BT) { fill[i] = 0; rq[i] = 0; rdy[i] = 0; }
+	if (tid < 2) nq[tid] = 0;
 	__syncthreads();
 	uint32_t t_cur = s_draw[0], t_next = s_draw[1], t_pf = s_draw[2];
 	if (t_cur == WC_NONE) return; // (nothing was reserved yet)
@@ -107,57 +111,72 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	const int mis = (int)((uintptr_t)seq & 15);
 	const uint8_t *const sb = seq - mis, *const qb = qual ? qual - mis : nullptr;
 	const int64_t v_end = n_pos + mis, v_last = (v_end - 1) & ~(int64_t)15;
-	uint4 pf_s = make_uint4(0, 0, 0, 0), pf_q = make_uint4(0, 0, 0, 0);
-	const int pf_c = tid < NCH ? tid : NCH - 1;
-	auto prefetch = [&](uint32_t t) {
-		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)pf_c * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
-		pf_s = *reinterpret_cast<const uint4 *>(sb + at);
-		if (qual) pf_q = *reinterpret_cast<const uint4 *>(qb + at);
+	// A 16-byte block of the tile is the work of TWO lanes: thread c < NCH turns its bases into three plane pieces, thread OWN0 + c its qualities
+	// into the fourth (one lane for both was a chain of ~300 instructions in five waves: 2 300 cycles of every round's P2).
+	const bool ld_b = tid < NCH, ld_q = qual != nullptr && tid >= OWN0 && tid < OWN0 + NCH;
+	uint4 pf = make_uint4(0, 0, 0, 0);
+	auto prefetch = [&](uint32_t t) { // (threads with ld_b or ld_q)
+		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)(ld_b ? tid : tid - OWN0) * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
+		pf = *reinterpret_cast<const uint4 *>((ld_b ? sb : qb) + at);
 	};
-	auto make_planes = [&](uint32_t t, uint32_t *pl) { // threads 0 .. NCH - 1
+	auto ragged = [&](int64_t v, uint32_t &k0, uint32_t &k1, uint32_t &k2, uint32_t &k3) -> bool { // a block at the ragged ends of the batch: byte masks of what belongs to it
+		if (!(v < mis || v + 16 > v_end)) return false;
+		const int lo = v >= mis ? 0 : mis - v >= 16 ? 16 : (int)(mis - v), hi = v_end - v >= 16 ? 16 : v_end - v <= 0 ? 0 : (int)(v_end - v);
+		const uint32_t bm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+		auto keep = [&](int d) { return (((bm >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu; };
+		k0 = keep(0); k1 = keep(1); k2 = keep(2); k3 = keep(3);
+		return true;
+	};
+	auto planes_b = [&](uint32_t t, uint32_t *pl) { // threads with ld_b: low bit, high bit, not-ACGT (and an all-ones quality piece for FASTA)
 		const int c = tid;
 		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)c * 16;
-		uint4 s4 = pf_s, q4 = pf_q;
-		if (v < mis || v + 16 > v_end) { // a block at the ragged ends of the batch: bytes outside it read as separators (qualities: 0)
-			const int lo = v >= mis ? 0 : mis - v >= 16 ? 16 : (int)(mis - v), hi = v_end - v >= 16 ? 16 : v_end - v <= 0 ? 0 : (int)(v_end - v);
-			const uint32_t bm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-			auto keep = [&](int d) { return (((bm >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu; };
-			const uint32_t k0 = keep(0), k1 = keep(1), k2 = keep(2), k3 = keep(3);
+		uint4 s4 = pf;
+		uint32_t k0, k1, k2, k3;
+		if (ragged(v, k0, k1, k2, k3)) { // bytes outside the batch read as separators
 			s4.x = (s4.x & k0) | (0x0a0a0a0au & ~k0); s4.y = (s4.y & k1) | (0x0a0a0a0au & ~k1); s4.z = (s4.z & k2) | (0x0a0a0a0au & ~k2); s4.w = (s4.w & k3) | (0x0a0a0a0au & ~k3);
-			q4.x &= k0; q4.y &= k1; q4.z &= k2; q4.w &= k3;
 		}
-		uint32_t m0 = 0, m1 = 0, mn = 0, mq = 0;
+		uint32_t m0 = 0, m1 = 0, mn = 0;
 		bases4x(s4.x, 0, m0, m1, mn); bases4x(s4.y, 4, m0, m1, mn); bases4x(s4.z, 8, m0, m1, mn); bases4x(s4.w, 12, m0, m1, mn);
-		if (qual) {
-			const int T = P.q + 33;
-			if (T >= 1 && T <= 127) {
-				const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
-				quals4x(q4.x, 0, add, mq); quals4x(q4.y, 4, add, mq); quals4x(q4.z, 8, add, mq); quals4x(q4.w, 12, add, mq);
-			} else { quals16(q4.x, 0, P.q, mq); quals16(q4.y, 4, P.q, mq); quals16(q4.z, 8, P.q, mq); quals16(q4.w, 12, P.q, mq); }
-		} else mq = 0xffffu;
 		unsigned short *p16 = reinterpret_cast<unsigned short *>(pl);
 		if (c < NC16) {
-			p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1;
-			p16[2 * PW * 2 + c] = (unsigned short)mn; p16[3 * PW * 2 + c] = (unsigned short)mq;
+			p16[0 * PW * 2 + c] = (unsigned short)m0; p16[1 * PW * 2 + c] = (unsigned short)m1; p16[2 * PW * 2 + c] = (unsigned short)mn;
+			if (!qual) p16[3 * PW * 2 + c] = (unsigned short)0xffffu;
 		} else { // the last block's piece shares its word with the first spare piece
-			pl[0 * PW + PW - 2] = m0; pl[1 * PW + PW - 2] = m1; pl[2 * PW + PW - 2] = mn; pl[3 * PW + PW - 2] = mq;
+			pl[0 * PW + PW - 2] = m0; pl[1 * PW + PW - 2] = m1; pl[2 * PW + PW - 2] = mn;
+			if (!qual) pl[3 * PW + PW - 2] = 0xffffu;
 		}
 		if (c < 4) pl[c * PW + PW - 1] = 0;
+	};
+	auto planes_q = [&](uint32_t t, uint32_t *pl) { // threads with ld_q: quality >= q (count.c:85's signed compare)
+		const int c = tid - OWN0;
+		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)c * 16;
+		uint4 q4 = pf;
+		uint32_t k0, k1, k2, k3;
+		if (ragged(v, k0, k1, k2, k3)) { q4.x &= k0; q4.y &= k1; q4.z &= k2; q4.w &= k3; } // (qualities outside the batch: 0)
+		uint32_t mq = 0;
+		const int T = P.q + 33;
+		if (T >= 1 && T <= 127) {
+			const uint32_t add = (uint32_t)(128 - T) * 0x01010101u;
+			quals4x(q4.x, 0, add, mq); quals4x(q4.y, 4, add, mq); quals4x(q4.z, 8, add, mq); quals4x(q4.w, 12, add, mq);
+		} else { quals16(q4.x, 0, P.q, mq); quals16(q4.y, 4, P.q, mq); quals16(q4.z, 8, P.q, mq); quals16(q4.w, 12, P.q, mq); }
+		if (c < NC16) reinterpret_cast<unsigned short *>(pl)[3 * PW * 2 + c] = (unsigned short)mq;
+		else pl[3 * PW + PW - 2] = mq;
 	};
 
 	// ---- the buckets' owners: lane i of waves 8.. owns bucket i -- its slab's base, the chunk it hands out next, chunks left in the group, the next group
 	const bool owner = tid >= OWN0 && tid < OWN0 + (int)NB;
-	const uint32_t ob = owner ? (uint32_t)(tid - OWN0) : 0u, ow = ob / WAVE;
-	const uint32_t slab = (ob * 8u + home) * OP.cap + (ob - OP.own_lo < OP.own_n ? OP.own_delta : 0u);
-	uint32_t *const my_cursor = &OP.cursor[((size_t)home * NB + ob) * 32];
-	uint32_t pos = 0, left = G;
-	bool open = false; // a request for the next group is on its way (rq, a reserver's register, or res / rdy)
+	// (recomputed where they are used -- the kernel runs at the register limit of its 1024 threads: ob = the bucket an owner thread owns, its slab's base)
+#define ob ((uint32_t)(tid - OWN0))
+	auto slab_of = [&](uint32_t b) -> uint32_t { return (b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u); };
+	// An owner's state in one register (the kernel runs at the register limit of its 1024 threads): the chunk it hands out next (a multiple of
+	// CAP >= 16) | a request for the next group is on its way (rq, a reserver's register, or res / rdy) << 3 | chunks left in the group (G <= 4)
+	uint32_t ost = G;
 	const uint32_t sig = G > 1u ? G - 1u : 1u; // ask for the next group when this many chunks of the current one are left (as soon as it is begun)
 	auto claim = [&](uint32_t base, uint32_t n) -> uint32_t { // a reservation's answer: a full slab poisons the batch (it is replayed), write where it does no harm
 		if (base + n > OP.cap) { OP.flags[0] = 1; return 0u; }
 		return base;
 	};
-	if (owner) pos = claim(atomicAdd(my_cursor, RES), RES);
+	if (owner) ost |= claim(atomicAdd(&OP.cursor[((size_t)home * NB + ob) * 32], RES), RES);
 	// ---- the reservers: waves RSV0 .. RSV0 + NRW - 1, wave r active in rounds = r (mod NRW); lane l serves buckets l, l + 64, ...
 	constexpr int RSV0 = 5, NRW = 3, NRS = NB / WAVE / 2; // (a lane serves NRS PAIRS of buckets l + 128 s, l + 128 s + 64 and takes up one request per pair and turn)
 	const int rsv = tid >= RSV0 * WAVE && tid < (RSV0 + NRW) * WAVE ? tid / WAVE - RSV0 : -1;
@@ -168,21 +187,44 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 
 	uint4 *const out16 = reinterpret_cast<uint4 *>(out);
 	const uint4 *const buf16 = reinterpret_cast<const uint4 *>(smem_wc);
-	auto copy_list = [&](uint32_t n) { // this wave's list of n chunks: 16 bytes per lane and step, two steps' loads in flight
+	// The flushed chunks leave in 16-byte pieces, up to NPC per thread and round: read from the buffers into registers between barriers B and C
+	// (nothing but LDS reads there), stored at the top of the next P1 -- where a wave that the memory pipeline holds up at the issue of its
+	// stores (2 400 cycles per round when the owner waves stored inside P2, everyone else waiting at the barrier) leaves its SIMD to the
+	// three other waves' hashing.  More chunks than NPC x 1024 pieces in one round (256 of 512 buckets due at once): the rest is stored from P3.
+	constexpr int NPC = 3;
+	uint4 pv[NPC]; uint32_t pa[NPC];
+#pragma unroll
+	for (int i = 0; i < NPC; ++i) { pv[i] = make_uint4(0, 0, 0, 0); pa[i] = WC_NONE; }
+	auto take_pieces = [&](uint32_t n) { // P3
 		const uint32_t np = n * PIECES;
-		for (uint32_t x = lane; x < np; x += 2 * WAVE) {
-			const uint32_t x1 = x + WAVE;
-			const bool two = x1 < np;
-			const uint32_t j0 = x / PIECES, p0 = x - j0 * PIECES, j1 = two ? x1 / PIECES : j0, p1 = two ? x1 - j1 * PIECES : p0;
-			const uint2 e0 = wl[ow][j0], e1 = wl[ow][j1];
-			const uint4 v0 = buf16[e0.x * PIECES + p0], v1 = buf16[e1.x * PIECES + p1];
-			if (BFCG_ABL(P, 256)) { if (v0.x == 0x12345678u && v1.y == 0x9abcdef0u) out16[0] = v0; continue; } // (measurement: the copy's LDS side without its stores)
-			out16[(size_t)e0.y + p0] = v0;
-			if (two) out16[(size_t)e1.y + p1] = v1;
+#pragma unroll
+		for (int i = 0; i < NPC; ++i) {
+			const uint32_t x = (uint32_t)tid + (uint32_t)i * BT;
+			pa[i] = WC_NONE;
+			if (x < np) {
+				const uint32_t j = x / PIECES, p = x - j * PIECES;
+				const uint2 e = wl[j];
+				// (24-bit multiplies: the compiler's v_mad_u64_u32 for a 32-bit product + offset takes ANY register as the undefined high half of
+				// its addend -- here the one the tile draw's atomic returns to, and with it an s_waitcnt vmcnt(0) for this thread's fresh stores)
+				pv[i] = *reinterpret_cast<const uint4 *>(smem_wc + (__umul24(e.x, PIECES * 16u) + p * 16u)); pa[i] = e.y + p;
+			}
+		}
+		for (uint32_t x = (uint32_t)tid + (uint32_t)NPC * BT; x < np; x += BT) { // (rare)
+			const uint32_t j = x / PIECES, p = x - j * PIECES;
+			const uint2 e = wl[j];
+			out16[(size_t)e.y + p] = buf16[e.x * PIECES + p];
 		}
 	};
+	auto store_pieces = [&]() { // top of P1 (and once behind the last round)
+#pragma unroll
+		for (int i = 0; i < NPC; ++i) if (pa[i] != WC_NONE && !BFCG_ABL(P, 256)) out16[(size_t)pa[i]] = pv[i];
+	};
 
-	if (tid < NCH) { prefetch(t_cur); make_planes(t_cur, planes); if (t_next != WC_NONE) prefetch(t_next); }
+	if (ld_b | ld_q) {
+		prefetch(t_cur);
+		if (ld_b) planes_b(t_cur, planes); else planes_q(t_cur, planes);
+		if (t_next != WC_NONE) prefetch(t_next);
+	}
 	__syncthreads();
 
 	RecW<3> w[S];
@@ -191,13 +233,14 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	for (int j = 0; j < S; ++j) pend[j] = WC_NONE;
 	uint32_t n_k = 0, n_h = 0;
 	int cur = 0;
-	auto put = [&](uint32_t o, const RecW<3> &r) { uint32_t *p = buf + o * 3u; p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; };
+	auto put = [&](uint32_t o, const RecW<3> &r) { uint32_t *p = reinterpret_cast<uint32_t *>(smem_wc + __umul24(o, 12u)); p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; };
 
 #ifdef BFCG_MEASURE // phase clocks (scripts/s1wc_phases.py): thread 0 and the first owner lane, summed per workgroup into the statistics' spare words
 	unsigned long long tm_p1 = 0, tm_p2 = 0, tm_ld = 0, tm_ow = 0, tm_w8 = 0, tm_n = 0, tm_t = __builtin_readcyclecounter();
 #endif
 	for (;;) {
 		// ---------------- P1
+		store_pieces();
 #pragma unroll
 		for (int j = 0; j < S; ++j) if (pend[j] != WC_NONE) { put(pend[j], w[j]); pend[j] = WC_NONE; }
 		const uint32_t *pl = planes + cur * 4 * PW;
@@ -229,7 +272,7 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 			else if (sl[j] != WC_NONE) { // more than two buffers' worth for one bucket in one round: a chunk of its own, the record and CAP - 1 dead ones
 				const uint32_t b = bo[j] >> CAPL;
 				const uint32_t base = claim(atomicAdd(&OP.cursor[((size_t)home * NB + b) * 32], CAP), CAP);
-				uint32_t *d = out + (size_t)((b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u) + base) * 3u;
+				uint32_t *d = out + (size_t)(slab_of(b) + base) * 3u;
 				d[0] = w[j].d[0]; d[1] = w[j].d[1]; d[2] = w[j].d[2];
 				for (uint32_t z = 3; z < CAP * 3u; ++z) d[z] = 0xffffffffu;
 			}
@@ -242,10 +285,10 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 		{ const unsigned long long now = __builtin_readcyclecounter(); tm_p1 += now - tm_t; tm_t = now; }
 #endif
 		// ---------------- P2
-		if (tid < NCH) {
+		if (ld_b) {
 			if (tid == 0) { s_draw[3] = draw_settle(draw); draw = draw_issue(); } // (the draw issued a round ago; the next one)
 			if (t_next != WC_NONE) {
-				make_planes(t_next, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
+				planes_b(t_next, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
 				if (t_pf != WC_NONE) prefetch(t_pf);
 			}
 		} else if (rsv >= 0) {
@@ -276,30 +319,42 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 			const uint32_t f = fill[ob];
 			const bool due = f >= CAP;
 			const unsigned long long dm = __ballot(due);
+			uint32_t qb = 0;
+			if (dm) { // one LDS atomic per wave for its places in the round's list
+				if (lane == (int)__builtin_ctzll(dm)) qb = atomicAdd(&nq[round & 1u], (uint32_t)__popcll(dm));
+				qb = __shfl(qb, (int)__builtin_ctzll(dm));
+			}
 			if (due) {
-				const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-				wl[ow][my] = make_uint2(ob, ((slab + pos) >> 2) * 3u);
+				const uint32_t my = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+				wl[my] = make_uint2(ob, ((slab_of(ob) + (ost & ~15u)) >> 2) * 3u);
 				fill[ob] = (f < 2u * CAP ? f : 2u * CAP) - CAP;
-				pos += CAP;
-				if (--left == 0) { // the next group
-					uint32_t base;
-					if (open && rdy[ob] != 0u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); base = res[ob]; rdy[ob] = 0u; open = false; }
+				ost += CAP - 1u; // (the next chunk, one less left)
+				if ((ost & 7u) == 0u) { // the next group
+					uint32_t bb = ob, base;
+					asm volatile("" : "+v"(bb)); // (opaque: the addresses of this seldom-taken path are made here, not hoisted out of the round loop into registers the kernel does not have)
+					uint32_t op = ost & 8u;
+					if (op && rdy[bb] != 0u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); base = res[bb]; rdy[bb] = 0u; op = 0u; }
 					else { // not there yet (or never asked for: the first groups of G = 1): this lane reserves for itself and waits, behind its wave's stores
-						base = atomicAdd(my_cursor, RES);
+						base = atomicAdd(&OP.cursor[((size_t)home * NB + bb) * 32], RES);
 						__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) here, not in front of the register's next use
 					}
-					pos = claim(base, RES); left = G;
+					ost = claim(base, RES) | op | G;
 				}
 			}
-			if (left <= sig && !open) { rq[ob] = 1u; open = true; }
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			if (!BFCG_ABL(P, 512)) copy_list((uint32_t)__popcll(dm));
+			if ((ost & 7u) <= sig && !(ost & 8u)) { rq[ob] = 1u; ost |= 8u; }
+			if (tid == OWN0) nq[(round & 1u) ^ 1u] = 0; // (the next round's counter: nobody reads or bumps it before barrier A of that round)
+		}
+		if (ld_q && t_next != WC_NONE) { // (threads of the owners' first waves)
+			planes_q(t_next, planes + (cur ^ 1) * 4 * PW);
+			if (t_pf != WC_NONE) prefetch(t_pf);
 		}
 #ifdef BFCG_MEASURE
 		if (tid == 0) tm_ld += __builtin_readcyclecounter() - tm_t;
 		if (tid == OWN0) tm_ow += __builtin_readcyclecounter() - tm_t;
 #endif
-		__syncthreads(); // ---------------- B: the flushed buffers are free, the next tile's planes stand
+		__syncthreads(); // ---------------- B: the round's list of flushes stands, the next tile's planes too
+		if (!BFCG_ABL(P, 512)) take_pieces(nq[round & 1u]); // ---------------- P3
+		__syncthreads(); // ---------------- C: the flushed buffers are free
 #ifdef BFCG_MEASURE
 		{ const unsigned long long now = __builtin_readcyclecounter(); tm_p2 += now - tm_t; tm_t = now; ++tm_n; }
 #endif
@@ -308,6 +363,7 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	}
 
 	// ---- the end: what is left in the buffers leaves padded with dead records; what was reserved and not used is dead
+	store_pieces();
 #pragma unroll
 	for (int j = 0; j < S; ++j) if (pend[j] != WC_NONE) put(pend[j], w[j]);
 	__syncthreads();
@@ -320,17 +376,19 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	if (owner) {
 		const uint32_t f = fill[ob]; // <= CAP
 		for (uint32_t z = f; z < CAP; ++z) { uint32_t *p = buf + ((ob << CAPL) + z) * 3u; p[0] = 0xffffffffu; p[1] = 0xffffffffu; p[2] = 0xffffffffu; }
-		wl[ow][lane] = make_uint2(ob, ((slab + pos) >> 2) * 3u);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		copy_list(WAVE);
-		uint4 *d = out16 + (size_t)(((slab + pos + CAP) >> 2) * 3u);
-		for (uint32_t z = 0; z < (left - 1u) * PIECES; ++z) d[z] = dead; // the rest of the current group
-		if (open && rdy[ob] != 0u) dead_group(slab, res[ob]); // a group that was published and never taken
+		{ // the (padded) buffer itself: lane by lane, once per kernel
+			const uint4 *sp = buf16 + ob * PIECES;
+			uint4 *dp = out16 + (size_t)(((slab_of(ob) + (ost & ~15u)) >> 2) * 3u);
+			for (uint32_t z = 0; z < PIECES; ++z) dp[z] = sp[z];
+		}
+		uint4 *d = out16 + (size_t)(((slab_of(ob) + (ost & ~15u) + CAP) >> 2) * 3u);
+		for (uint32_t z = 0; z < ((ost & 7u) - 1u) * PIECES; ++z) d[z] = dead; // the rest of the current group
+		if ((ost & 8u) && rdy[ob] != 0u) dead_group(slab_of(ob), res[ob]); // a group that was published and never taken
 	} else if (rsv >= 0) { // groups whose answers never were published
 #pragma unroll
 		for (int u = 0; u < NRS; ++u) if (infl & (1u << u)) {
 			const uint32_t b = (uint32_t)lane + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
-			dead_group((b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u), rv[u]);
+			dead_group(slab_of(b), rv[u]);
 		}
 	}
 #ifdef BFCG_MEASURE
@@ -348,6 +406,9 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 		}
 	}
 }
+
+#undef draw_a
+#undef ob
 
 template <typename W, int CAPL, int KC>
 void launch_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)
@@ -381,8 +442,15 @@ bool scatter1_wc_ok(const KParams &P, const OnePass &OP, unsigned n_wgs, uint32_
 	if (P.F1 != 8 && P.F1 != 9) return false;
 	if ((OP.cap & 3u) || (OP.own_delta & 3u)) return false;
 	const uint32_t capl = 13 - P.F1, cap_rec = 1u << capl;
-	uint32_t G = OP.chunk >> capl; if (G < 1) G = 1; if (G > 4) G = 4;
-	if (mode != 2 && (uint64_t)(n_wgs / 8 + 1) * (G * cap_rec + cap_rec) * 8 > OP.cap) return false;
+	// Chunks per reservation: four -- an owner asks for its next group when it begins one, the answer is published four rounds later, and a
+	// bucket fills a chunk in two and a half (with two, measured: nearly every group found its successor missing and its owner reserved for
+	// itself, 3 000 - 4 000 cycles of a round behind the wave's fresh stores).  Fewer where the slabs are small: a workgroup leaves up to a
+	// group and a half and a padded buffer per bucket unused (dead records), and all of an XCD's workgroups share a slab.
+	uint32_t G = 4;
+	const char *ce = getenv("BFCG_S1_CHUNK"); // (tests force chunk sizes on small draws)
+	if (ce && atoi(ce) > 0) { G = (uint32_t)atoi(ce) >> capl; if (G < 1) G = 1; if (G > 4) G = 4; }
+	else while (G > 1 && (uint64_t)(n_wgs / 8 + 1) * (G * cap_rec * 3 / 2 + cap_rec) * 16 > OP.cap) G >>= 1;
+	if (mode != 2 && (uint64_t)(n_wgs / 8 + 1) * (G * cap_rec * 3 / 2 + cap_rec) * 16 > OP.cap) return false;
 	*G_out = G;
 	return true;
 }
