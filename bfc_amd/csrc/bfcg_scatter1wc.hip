@@ -46,8 +46,6 @@
 
 using namespace bfcg;
 
-namespace {
-
 constexpr int WC_TILE = 4096, WC_BT = 1024, WC_S = WC_TILE / WC_BT, WC_RECS = 8192; // positions per round, threads, positions per thread, records in the buffers
 constexpr uint32_t WC_NONE = 0xffffffffu;
 
@@ -320,10 +318,8 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 			const bool due = f >= CAP;
 			const unsigned long long dm = __ballot(due);
 			uint32_t qb = 0;
-			if (dm) { // one LDS atomic per wave for its places in the round's list
-				if (lane == (int)__builtin_ctzll(dm)) qb = atomicAdd(&nq[round & 1u], (uint32_t)__popcll(dm));
-				qb = __shfl(qb, (int)__builtin_ctzll(dm));
-			}
+			if (lane == 0) qb = atomicAdd(&nq[round & 1u], (uint32_t)__popcll(dm)); // one LDS atomic per wave for its places in the round's list
+			qb = __builtin_amdgcn_readfirstlane(qb);
 			if (due) {
 				const uint32_t my = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
 				wl[my] = make_uint2(ob, ((slab_of(ob) + (ost & ~15u)) >> 2) * 3u);
@@ -409,6 +405,8 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 
 #undef draw_a
 #undef ob
+
+namespace {
 
 template <typename W, int CAPL, int KC>
 void launch_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)

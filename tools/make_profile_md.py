@@ -30,7 +30,7 @@ def pmc_rows(path):
 
 def short(name):
     import re
-    m = re.match(r"_Z\d+(k_[a-z0-9_]+?)(I|P|N|v)", name)
+    m = re.match(r"_Z(?:N12_GLOBAL__N_1)?\d+(k_[a-z0-9_]+?)(I|P|N|v|E)", name)
     return m.group(1) if m else name.replace(".kd", "")
 
 

@@ -14,7 +14,7 @@ ROUND = os.environ.get("ROUND", "4")
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_profile_md import kernel_rows, pmc_rows, short  # noqa: E402
 
-STAGE = {"k_seg_setup": "scatter1", "k_hist1": "hist1", "k_colsum": "hist1", "k_scan_top": "hist1", "k_apply": "hist1", "k_scatter1": "scatter1",
+STAGE = {"k_seg_setup": "scatter1", "k_hist1": "hist1", "k_colsum": "hist1", "k_scan_top": "hist1", "k_apply": "hist1", "k_scatter1": "scatter1", "k_scatter1_wc": "scatter1",
          "k_hist2": "level2", "k_scan2": "level2", "k_scatter2": "level2", "k_bloom": "bloom", "k_bloom3": "bloom",
          "k_commit": "commit", "k_commit_stream": "commit", "k_commit_seg": "commit"}
 
