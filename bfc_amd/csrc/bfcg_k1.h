@@ -141,8 +141,9 @@ __device__ __forceinline__ void pack3_fast(RecW<3> &r, const Pack3 g, const U2 y
 }
 
 namespace bfcg {
-// bfcg_scatter1wc.hip: level 1 through write-combining buffers in LDS (k_scatter1_wc) -- whether this one-pass stage A can take it (and with how
-// many chunks per reservation), and its launch on `grid` persistent workgroups of 1024 threads
-bool scatter1_wc_ok(const KParams &P, const OnePass &OP, unsigned n_wgs, uint32_t *G_out);
-void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st);
+// bfcg_scatter1wc.hip: level 1 through write-combining buffers in LDS (k_scatter1_wc) -- whether this one-pass stage A can take it and how
+// (threads per workgroup, chunks per reservation, persistent workgroups), and its launch
+struct WcPlan { int bt; uint32_t G; unsigned grid; };
+bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan *pl);
+void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, const WcPlan &pl, hipStream_t st);
 }

@@ -2249,17 +2249,6 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 	if (ev) hipEventRecord(ev[2], st);
 }
 
-// k_scatter1_wc's grid: one persistent workgroup of 1024 threads per CU (96 KiB of buffers), a multiple of 8 (XCDs), no more than there are tiles
-static unsigned wc_grid_for(int64_t tiles1)
-{
-	static int n_cu = 0;
-	if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-	unsigned g = (unsigned)n_cu & ~7u; if (g < 8) g = 8;
-	const char *e = getenv("BFCG_S1_WC_WGS"); if (e && atoi(e) >= 8) g = (unsigned)atoi(e) & ~7u; // (tests: fewer workgroups on small draws)
-	const unsigned gt = (unsigned)(((tiles1 + 7) / 8) * 8);
-	return gt < g ? gt : g;
-}
-
 // one-pass stage A (K1 once): cursors cleared, K1 + level-1 scatter into the slabs, the slabs described as segments for level 2
 template <typename W, int RW>
 static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
@@ -2292,9 +2281,8 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 		OP.chunk = forced > 0 ? (uint32_t)forced : ch;
 	}
 	if constexpr (RW == 3) {
-		uint32_t wc_g = 0;
-		const unsigned wc_grid = wc_grid_for(tiles1);
-		if (B.cnt_live && scatter1_fast(P) && scatter1_wc_ok(P, OP, wc_grid, &wc_g)) run_scatter1_wc(P, seq, qual, n_pos, out1, OP, wc_g, wc_grid, st); // (round 5: write-combining buffers in LDS)
+		WcPlan wc;
+		if (B.cnt_live && scatter1_fast(P) && scatter1_wc_plan(P, OP, n_pos, &wc)) run_scatter1_wc(P, seq, qual, n_pos, out1, OP, wc, st); // (round 5: write-combining buffers in LDS)
 		else if (scatter1_fast(P)) {
 			if (sizeof(W) == 8 && P.k == 33) hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
 			else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);

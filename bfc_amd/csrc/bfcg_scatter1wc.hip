@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include "kmer_dev.h"
 #include "bfcg_internal.h"
 #include "bfcg_dev.h"
@@ -46,19 +47,22 @@
 
 using namespace bfcg;
 
-constexpr int WC_TILE = 4096, WC_BT = 1024, WC_S = WC_TILE / WC_BT, WC_RECS = 8192; // positions per round, threads, positions per thread, records in the buffers
 constexpr uint32_t WC_NONE = 0xffffffffu;
 
-template <typename W, int CAPL, int KC>
-__global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
-                                                       uint32_t *__restrict__ out, OnePass OP, uint32_t G)
+// W: the k-mer word (one 32-bit word up to k = 32, else halves); CAPL, NBL: log2 records per buffer, log2 buckets; BT: threads (512: two workgroups
+// per CU, 1024: one); KC: k at compile time or 0.  A round is a tile of 4 BT positions.
+template <typename W, int CAPL, int NBL, int BT, int KC>
+__global__ __launch_bounds__(BT, BT == 512 ? 2 : 1) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
+                                                                       uint32_t *__restrict__ out, OnePass OP, uint32_t G)
 {
-	constexpr int TILE = WC_TILE, BT = WC_BT, S = WC_S;
-	constexpr uint32_t CAP = 1u << CAPL, NB = WC_RECS >> CAPL, PIECES = CAP * 3 / 4; // records per buffer, buckets, 16-byte pieces of a chunk
+	constexpr int S = 4, TILE = BT * S;
+	constexpr uint32_t CAP = 1u << CAPL, NB = 1u << NBL, PIECES = CAP * 3 / 4; // records per buffer, buckets, 16-byte pieces of a chunk
 	constexpr int PW = (TILE + 64) / 32 + 2, NC16 = (TILE + 64) / 16, NCH = NC16 + 1;
-	constexpr int OWN0 = 512;                        // first owner thread: lane i of waves 8.. owns bucket i
-	constexpr int NOW = (NB + WAVE - 1) / WAVE;      // owner (= copying) waves
-	static_assert(NCH <= 5 * WAVE && OWN0 + NCH <= BT && OWN0 + NB <= BT && NB % WAVE == 0, "roles by wave");
+	// Roles.  Thread OWN0 + i owns bucket i; threads 0 .. NCH - 1 build the base planes, QL0 .. QL0 + NCH - 1 the quality plane; waves RSV0 .. RSV0 +
+	// NRW - 1 reserve.  With 1024 threads and 512 buckets the loaders, the reservers and the owners are different waves (the owners' first
+	// ones also build the quality plane); with 512 threads every thread owns a bucket and has its other roles beside that.
+	constexpr int OWN0 = BT - (int)NB, QL0 = BT / 2, RSV0 = BT == 512 ? 7 : 5, NRW = BT == 512 ? 1 : 3;
+	static_assert(OWN0 >= 0 && NCH <= QL0 && QL0 + NCH <= BT && (NCH + WAVE - 1) / WAVE <= RSV0 && NB % (2 * WAVE) == 0 && CAP >= 8, "roles by wave");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_wc[];
 	uint32_t *buf = reinterpret_cast<uint32_t *>(smem_wc); // NB buffers of CAP records of 3 dwords
 	__shared__ uint32_t fill[NB];
@@ -109,12 +113,12 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	const int mis = (int)((uintptr_t)seq & 15);
 	const uint8_t *const sb = seq - mis, *const qb = qual ? qual - mis : nullptr;
 	const int64_t v_end = n_pos + mis, v_last = (v_end - 1) & ~(int64_t)15;
-	// A 16-byte block of the tile is the work of TWO lanes: thread c < NCH turns its bases into three plane pieces, thread OWN0 + c its qualities
+	// A 16-byte block of the tile is the work of TWO lanes: thread c < NCH turns its bases into three plane pieces, thread QL0 + c its qualities
 	// into the fourth (one lane for both was a chain of ~300 instructions in five waves: 2 300 cycles of every round's P2).
-	const bool ld_b = tid < NCH, ld_q = qual != nullptr && tid >= OWN0 && tid < OWN0 + NCH;
+	const bool ld_b = tid < NCH, ld_q = qual != nullptr && tid >= QL0 && tid < QL0 + NCH;
 	uint4 pf = make_uint4(0, 0, 0, 0);
 	auto prefetch = [&](uint32_t t) { // (threads with ld_b or ld_q)
-		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)(ld_b ? tid : tid - OWN0) * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
+		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)(ld_b ? tid : tid - QL0) * 16, at = v < 0 ? 0 : v > v_last ? v_last : v;
 		pf = *reinterpret_cast<const uint4 *>((ld_b ? sb : qb) + at);
 	};
 	auto ragged = [&](int64_t v, uint32_t &k0, uint32_t &k1, uint32_t &k2, uint32_t &k3) -> bool { // a block at the ragged ends of the batch: byte masks of what belongs to it
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 		if (c < 4) pl[c * PW + PW - 1] = 0;
 	};
 	auto planes_q = [&](uint32_t t, uint32_t *pl) { // threads with ld_q: quality >= q (count.c:85's signed compare)
-		const int c = tid - OWN0;
+		const int c = tid - QL0;
 		const int64_t v = (int64_t)t * TILE - 64 + (int64_t)c * 16;
 		uint4 q4 = pf;
 		uint32_t k0, k1, k2, k3;
@@ -162,21 +166,22 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	};
 
 	// ---- the buckets' owners: lane i of waves 8.. owns bucket i -- its slab's base, the chunk it hands out next, chunks left in the group, the next group
-	const bool owner = tid >= OWN0 && tid < OWN0 + (int)NB;
+	const bool owner = tid >= OWN0;
 	// (recomputed where they are used -- the kernel runs at the register limit of its 1024 threads: ob = the bucket an owner thread owns, its slab's base)
 #define ob ((uint32_t)(tid - OWN0))
 	auto slab_of = [&](uint32_t b) -> uint32_t { return (b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u); };
-	// An owner's state in one register (the kernel runs at the register limit of its 1024 threads): the chunk it hands out next (a multiple of
-	// CAP >= 16) | a request for the next group is on its way (rq, a reserver's register, or res / rdy) << 3 | chunks left in the group (G <= 4)
+	// An owner's state in one register (the kernel runs at the register limit of its 1024 threads): the chunk it hands out next (counted in chunks) << 4
+	// | a request for the next group is on its way (rq, a reserver's register, or res / rdy) << 3 | chunks left in the group (G <= 4)
 	uint32_t ost = G;
+	auto ost_pos = [&]() -> uint32_t { return (ost >> 4) << CAPL; }; // (the position counts chunks there: a buffer may be 8 records)
 	const uint32_t sig = G > 1u ? G - 1u : 1u; // ask for the next group when this many chunks of the current one are left (as soon as it is begun)
 	auto claim = [&](uint32_t base, uint32_t n) -> uint32_t { // a reservation's answer: a full slab poisons the batch (it is replayed), write where it does no harm
 		if (base + n > OP.cap) { OP.flags[0] = 1; return 0u; }
 		return base;
 	};
-	if (owner) ost |= claim(atomicAdd(&OP.cursor[((size_t)home * NB + ob) * 32], RES), RES);
+	if (owner) ost |= (claim(atomicAdd(&OP.cursor[((size_t)home * NB + ob) * 32], RES), RES) >> CAPL) << 4;
 	// ---- the reservers: waves RSV0 .. RSV0 + NRW - 1, wave r active in rounds = r (mod NRW); lane l serves buckets l, l + 64, ...
-	constexpr int RSV0 = 5, NRW = 3, NRS = NB / WAVE / 2; // (a lane serves NRS PAIRS of buckets l + 128 s, l + 128 s + 64 and takes up one request per pair and turn)
+	constexpr int NRS = NB / WAVE / 2; static_assert(NRS <= 4, "a reserver lane's answers are registers"); // (a lane serves NRS PAIRS of buckets l + 128 s, l + 128 s + 64 and takes up one request per pair and turn)
 	const int rsv = tid >= RSV0 * WAVE && tid < (RSV0 + NRW) * WAVE ? tid / WAVE - RSV0 : -1;
 	uint32_t rv[NRS], infl = 0; // answers on their way: bit s of infl = rv[s] is one, bit 8 + s = it is the pair's second bucket's
 #pragma unroll
@@ -188,8 +193,8 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 	// The flushed chunks leave in 16-byte pieces, up to NPC per thread and round: read from the buffers into registers between barriers B and C
 	// (nothing but LDS reads there), stored at the top of the next P1 -- where a wave that the memory pipeline holds up at the issue of its
 	// stores (2 400 cycles per round when the owner waves stored inside P2, everyone else waiting at the barrier) leaves its SIMD to the
-	// three other waves' hashing.  More chunks than NPC x 1024 pieces in one round (256 of 512 buckets due at once): the rest is stored from P3.
-	constexpr int NPC = 3;
+	// three other waves' hashing.  More chunks than NPC x BT pieces in one round (half the buckets due at once): the rest is stored from P3.
+	constexpr int NPC = 3; // (a round flushes a fifth of its 4 BT positions' k-mers' worth of chunks on average: 2.4 pieces per thread)
 	uint4 pv[NPC]; uint32_t pa[NPC];
 #pragma unroll
 	for (int i = 0; i < NPC; ++i) { pv[i] = make_uint4(0, 0, 0, 0); pa[i] = WC_NONE; }
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 				planes_b(t_next, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
 				if (t_pf != WC_NONE) prefetch(t_pf);
 			}
-		} else if (rsv >= 0) {
+		}
+		if (rsv >= 0) {
 			if ((int)(round % NRW) == rsv) {
 				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), once and for what is NRW rounds old (said here: the compiler's own waits would sit between the new requests below)
 #pragma unroll
@@ -313,7 +319,8 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 					}
 				}
 			}
-		} else if (owner) {
+		}
+		if (owner) {
 			const uint32_t f = fill[ob];
 			const bool due = f >= CAP;
 			const unsigned long long dm = __ballot(due);
@@ -322,9 +329,9 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 			qb = __builtin_amdgcn_readfirstlane(qb);
 			if (due) {
 				const uint32_t my = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-				wl[my] = make_uint2(ob, ((slab_of(ob) + (ost & ~15u)) >> 2) * 3u);
+				wl[my] = make_uint2(ob, ((slab_of(ob) + ost_pos()) >> 2) * 3u);
 				fill[ob] = (f < 2u * CAP ? f : 2u * CAP) - CAP;
-				ost += CAP - 1u; // (the next chunk, one less left)
+				ost += 16u - 1u; // (the next chunk, one less left)
 				if ((ost & 7u) == 0u) { // the next group
 					uint32_t bb = ob, base;
 					asm volatile("" : "+v"(bb)); // (opaque: the addresses of this seldom-taken path are made here, not hoisted out of the round loop into registers the kernel does not have)
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 						base = atomicAdd(&OP.cursor[((size_t)home * NB + bb) * 32], RES);
 						__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) here, not in front of the register's next use
 					}
-					ost = claim(base, RES) | op | G;
+					ost = (claim(base, RES) >> CAPL) << 4 | op | G;
 				}
 			}
 			if ((ost & 7u) <= sig && !(ost & 8u)) { rq[ob] = 1u; ost |= 8u; }
@@ -374,13 +381,14 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 		for (uint32_t z = f; z < CAP; ++z) { uint32_t *p = buf + ((ob << CAPL) + z) * 3u; p[0] = 0xffffffffu; p[1] = 0xffffffffu; p[2] = 0xffffffffu; }
 		{ // the (padded) buffer itself: lane by lane, once per kernel
 			const uint4 *sp = buf16 + ob * PIECES;
-			uint4 *dp = out16 + (size_t)(((slab_of(ob) + (ost & ~15u)) >> 2) * 3u);
+			uint4 *dp = out16 + (size_t)(((slab_of(ob) + ost_pos()) >> 2) * 3u);
 			for (uint32_t z = 0; z < PIECES; ++z) dp[z] = sp[z];
 		}
-		uint4 *d = out16 + (size_t)(((slab_of(ob) + (ost & ~15u) + CAP) >> 2) * 3u);
+		uint4 *d = out16 + (size_t)(((slab_of(ob) + ost_pos() + CAP) >> 2) * 3u);
 		for (uint32_t z = 0; z < ((ost & 7u) - 1u) * PIECES; ++z) d[z] = dead; // the rest of the current group
 		if ((ost & 8u) && rdy[ob] != 0u) dead_group(slab_of(ob), res[ob]); // a group that was published and never taken
-	} else if (rsv >= 0) { // groups whose answers never were published
+	}
+	if (rsv >= 0) { // groups whose answers never were published
 #pragma unroll
 		for (int u = 0; u < NRS; ++u) if (infl & (1u << u)) {
 			const uint32_t b = (uint32_t)lane + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
@@ -408,63 +416,79 @@ __global__ __launch_bounds__(WC_BT) void k_scatter1_wc(KParams P, const uint8_t 
 
 namespace {
 
-template <typename W, int CAPL, int KC>
+template <typename W, int CAPL, int NBL, int BT, int KC>
 void launch_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)
 {
-	hipLaunchKernelGGL((k_scatter1_wc<W, CAPL, KC>), dim3(grid), dim3(WC_BT), (size_t)WC_RECS * 12, st, P, seq, qual, n_pos, out, OP, G);
+	hipLaunchKernelGGL((k_scatter1_wc<W, CAPL, NBL, BT, KC>), dim3(grid), dim3(BT), (size_t)12 << (CAPL + NBL), st, P, seq, qual, n_pos, out, OP, G);
 }
+template <typename W, int CAPL, int NBL, int BT, int KC>
+hipError_t attr_wc() { return hipFuncSetAttribute((const void *)k_scatter1_wc<W, CAPL, NBL, BT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << (CAPL + NBL)); }
 
 } // namespace
 
 namespace bfcg {
 
+// The variants: <word, log2 records per buffer, log2 buckets, threads, k at compile time>.  512 threads: 2^12 records of buffers (48 KiB), two
+// workgroups per CU -- one's flush (P2, P3: chains of dependent instructions and LDS round trips in a few waves) runs under the other's hashing;
+// 1024 threads: 2^13 records (96 KiB), one workgroup per CU (BFCG_S1_WC_BT=1024).
+#define WC_VARIANTS(X) \
+	X(uint64_t, 3, 9, 512, 33) X(uint64_t, 3, 9, 512, 0) X(uint64_t, 4, 8, 512, 0) X(uint32_t, 3, 9, 512, 0) X(uint32_t, 4, 8, 512, 0) \
+	X(uint64_t, 4, 9, 1024, 33) X(uint64_t, 4, 9, 1024, 0) X(uint64_t, 5, 8, 1024, 0) X(uint32_t, 4, 9, 1024, 0) X(uint32_t, 5, 8, 1024, 0)
+
 hipError_t set_scatter1wc_lds_attr(void)
 {
-	hipError_t e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint64_t, 4, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint64_t, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint64_t, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint32_t, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_scatter1_wc<uint32_t, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_RECS * 12);
+	hipError_t e = hipSuccess;
+#define X(W, C, N, B, K) if (e == hipSuccess) e = attr_wc<W, C, N, B, K>();
+	WC_VARIANTS(X)
+#undef X
 	return e;
 }
 
-// Whether a one-pass stage A of this geometry can run k_scatter1_wc: 12-byte records packed from halves with the level-1 bucket a bit field of
-// y0's low word (scatter1_fast, checked by the caller), 2^8 or 2^9 level-1 buckets (2^13 records of buffers in 96 KiB: 32 or 16 per bucket),
-// slabs that begin on 16-byte boundaries, and slabs large enough for what the workgroups leave unused (a group and a partial buffer per
-// workgroup and bucket at the end: dead records).  BFCG_S1_WC=0: never; =2: whenever the geometry allows (tests: tiny slabs overflow and are replayed).
-bool scatter1_wc_ok(const KParams &P, const OnePass &OP, unsigned n_wgs, uint32_t *G_out)
+// Whether a one-pass stage A of this geometry can run k_scatter1_wc, and how: 12-byte records packed from halves with the level-1 bucket a bit
+// field of y0's low word (scatter1_fast, checked by the caller), 2^8 or 2^9 level-1 buckets, slabs that begin on 16-byte boundaries, and slabs
+// large enough for what the workgroups leave unused (up to a group and a half and a padded buffer per workgroup and bucket at the end: dead
+// records).  BFCG_S1_WC=0: never; =2: whenever the geometry allows (tests: tiny slabs overflow and are replayed).
+bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan *pl)
 {
 	const char *e = getenv("BFCG_S1_WC");
 	const int mode = e ? atoi(e) : 1;
 	if (mode == 0) return false;
 	if (P.F1 != 8 && P.F1 != 9) return false;
 	if ((OP.cap & 3u) || (OP.own_delta & 3u)) return false;
-	const uint32_t capl = 13 - P.F1, cap_rec = 1u << capl;
-	// Chunks per reservation: four -- an owner asks for its next group when it begins one, the answer is published four rounds later, and a
+	e = getenv("BFCG_S1_WC_BT");
+	const int bt = e && atoi(e) == 1024 ? 1024 : 512;
+	const uint32_t capl = (bt == 512 ? 12 : 13) - P.F1, cap_rec = 1u << capl;
+	static int n_cu = 0;
+	if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+	unsigned g = (unsigned)(n_cu * (bt == 512 ? 2 : 1)) & ~7u; if (g < 8) g = 8; // persistent workgroups: as many as are resident at once, a multiple of 8 (XCDs)
+	e = getenv("BFCG_S1_WC_WGS"); if (e && atoi(e) >= 8) g = (unsigned)atoi(e) & ~7u; // (tests: fewer workgroups on small draws)
+	const int64_t tiles = (n_pos + 4 * bt - 1) / (4 * bt);
+	const unsigned gt = (unsigned)(((tiles + 7) / 8) * 8);
+	if (gt < g) g = gt;
+	// Chunks per reservation: four -- an owner asks for its next group when it begins one, the answer is published one to four rounds later, and a
 	// bucket fills a chunk in two and a half (with two, measured: nearly every group found its successor missing and its owner reserved for
-	// itself, 3 000 - 4 000 cycles of a round behind the wave's fresh stores).  Fewer where the slabs are small: a workgroup leaves up to a
-	// group and a half and a padded buffer per bucket unused (dead records), and all of an XCD's workgroups share a slab.
+	// itself, 3 000 - 4 000 cycles of a round behind the wave's fresh stores).  Fewer where the slabs are small: all of an XCD's workgroups share a slab.
 	uint32_t G = 4;
 	const char *ce = getenv("BFCG_S1_CHUNK"); // (tests force chunk sizes on small draws)
+	auto waste = [&](uint32_t gg) { return (uint64_t)(g / 8 + 1) * (gg * cap_rec * 3 / 2 + cap_rec) * 8; }; // (an eighth of a slab at most: a third of its head room)
 	if (ce && atoi(ce) > 0) { G = (uint32_t)atoi(ce) >> capl; if (G < 1) G = 1; if (G > 4) G = 4; }
-	else while (G > 1 && (uint64_t)(n_wgs / 8 + 1) * (G * cap_rec * 3 / 2 + cap_rec) * 16 > OP.cap) G >>= 1;
-	if (mode != 2 && (uint64_t)(n_wgs / 8 + 1) * (G * cap_rec * 3 / 2 + cap_rec) * 16 > OP.cap) return false;
-	*G_out = G;
+	else while (G > 1 && waste(G) > OP.cap) G >>= 1;
+	if (mode != 2 && waste(G) > OP.cap) return false;
+	pl->bt = bt; pl->G = G; pl->grid = g;
 	return true;
 }
 
 static unsigned long long g_wc_launches = 0; // (process-wide, for the tests: did a run take this kernel at all)
 
-void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)
+void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, const WcPlan &pl, hipStream_t st)
 {
 	__atomic_fetch_add(&g_wc_launches, 1ull, __ATOMIC_RELAXED);
-	if (P.k > 32) {
-		if (P.F1 == 9) { if (P.k == 33) launch_wc<uint64_t, 4, 33>(P, seq, qual, n_pos, out, OP, G, grid, st); else launch_wc<uint64_t, 4, 0>(P, seq, qual, n_pos, out, OP, G, grid, st); }
-		else launch_wc<uint64_t, 5, 0>(P, seq, qual, n_pos, out, OP, G, grid, st);
-	} else {
-		if (P.F1 == 9) launch_wc<uint32_t, 4, 0>(P, seq, qual, n_pos, out, OP, G, grid, st);
-		else launch_wc<uint32_t, 5, 0>(P, seq, qual, n_pos, out, OP, G, grid, st);
-	}
+	const int kc = P.k == 33 && P.F1 == 9 ? 33 : 0, w64 = P.k > 32;
+	const int capl = (pl.bt == 512 ? 12 : 13) - P.F1;
+#define X(W, C, N, B, K) if ((sizeof(W) == 8) == (w64 != 0) && C == capl && N == P.F1 && B == pl.bt && K == kc) { launch_wc<W, C, N, B, K>(P, seq, qual, n_pos, out, OP, pl.G, pl.grid, st); return; }
+	WC_VARIANTS(X)
+#undef X
+	fprintf(stderr, "[bfcg] k_scatter1_wc: no variant for k=%d F1=%d threads=%d\n", P.k, P.F1, pl.bt); abort(); // (scatter1_wc_plan admits only what is instantiated)
 }
 
 } // namespace bfcg

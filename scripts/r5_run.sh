@@ -96,8 +96,8 @@ PY
 fi
 if has wc; then  # k_scatter1_wc: its fuzz family, then c3 with the tile kernel (BFCG_S1_WC=0) against the write-combining one (default), one box
   timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x -k "write_combining" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_wc_fuzz.log; tail -15 gpurun_out/r5_wc_fuzz.log
-  for v in ${WC_AB:-0 1 0 1}; do
-    BFCG_S1_WC=$v timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary ${AB_ARGS:---no-secondary} > gpurun_out/r5_wc_$v.json 2> gpurun_out/r5_wc_$v.log; echo "BFCG_S1_WC=$v rc=$?"
+  for v in ${WC_AB:-BFCG_S1_WC=0 BFCG_S1_WC_BT=512 BFCG_S1_WC_BT=1024 BFCG_S1_WC_BT=512}; do
+    env $v timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary ${AB_ARGS:---no-secondary} > gpurun_out/r5_wc_$v.json 2> gpurun_out/r5_wc_$v.log; echo "$v rc=$?"
     summ gpurun_out/r5_wc_$v.json; tail -3 gpurun_out/r5_wc_$v.log | cut -c1-300
   done
 fi

@@ -196,7 +196,7 @@ def test_random_configuration_k33_on_tiny_slabs(gpu_lib, seed, monkeypatch):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch):
     """k_scatter1_wc (round 5, bfcg_scatter1wc.hip): level 1 of the one-pass partition through write-combining buffers in LDS -- a buffer of 16 or 32
-    records per bucket, full buffers leave as whole chunks into room reserved a group ahead, what finds its buffer full waits a round in
+    records per bucket (8 or 16 with two workgroups of 512 threads per CU), full buffers leave as whole chunks into room reserved a group ahead, what finds its buffer full waits a round in
     registers, what finds it full twice over takes a chunk of its own, dead records in everything reserved and not filled.  Forced (BFCG_S1_WC=2)
     onto draws whose slabs expect a handful of records, with 8 / 16 / 64 workgroups sharing them and 2^8 / 2^9 level-1 buckets: every path of the
     kernel runs -- spills on the low-complexity draws, slabs that overflow because of the padding (replayed through two passes), tiles stolen
@@ -206,6 +206,7 @@ def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch)
     monkeypatch.setenv("BFCG_S1_WC", "2")
     monkeypatch.setenv("BFCG_S1_WC_WGS", str([8, 16, 64][seed % 3]))
     monkeypatch.setenv("BFCG_F1", str(8 + (seed & 1)))
+    monkeypatch.setenv("BFCG_S1_WC_BT", "1024" if seed % 4 >= 2 else "512")  # (one workgroup of 1024 threads per CU, or two of 512 with buffers half the size)
     if seed % 4 == 3:
         monkeypatch.setenv("BFCG_S1_CHUNK", "64")  # (four chunks of 16 per reservation)
     prm, seq, qual, off, cuts, kw = _draw(52000 + seed, scale=12, b_range=(28, 34))
