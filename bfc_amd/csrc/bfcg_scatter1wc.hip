@@ -52,7 +52,7 @@ constexpr uint32_t WC_NONE = 0xffffffffu;
 // W: the k-mer word (one 32-bit word up to k = 32, else halves); CAPL, NBL: log2 records per buffer, log2 buckets; BT: threads (512: two workgroups
 // per CU, 1024: one); KC: k at compile time or 0.  A round is a tile of 4 BT positions.
 template <typename W, int CAPL, int NBL, int BT, int KC>
-__global__ __launch_bounds__(BT, BT == 512 ? 2 : 1) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
+__global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
                                                                        uint32_t *__restrict__ out, OnePass OP, uint32_t G)
 {
 	constexpr int S = 4, TILE = BT * S;
@@ -181,8 +181,12 @@ __global__ __launch_bounds__(BT, BT == 512 ? 2 : 1) void k_scatter1_wc(KParams P
 	};
 	if (owner) ost |= (claim(atomicAdd(&OP.cursor[((size_t)home * NB + ob) * 32], RES), RES) >> CAPL) << 4;
 	// ---- the reservers: waves RSV0 .. RSV0 + NRW - 1, wave r active in rounds = r (mod NRW); lane l serves buckets l, l + 64, ...
-	constexpr int NRS = NB / WAVE / 2; static_assert(NRS <= 4, "a reserver lane's answers are registers"); // (a lane serves NRS PAIRS of buckets l + 128 s, l + 128 s + 64 and takes up one request per pair and turn)
-	const int rsv = tid >= RSV0 * WAVE && tid < (RSV0 + NRW) * WAVE ? tid / WAVE - RSV0 : -1;
+	// (a lane serves NRS PAIRS of buckets l + 128 s, l + 128 s + 64 of its bank and takes up one request per pair and turn; 2^10 buckets are two
+	// banks of 2^9, the second one's reservers eight waves further on: a lane's answers are registers, and four is what the kernel has)
+	constexpr int NBANK = NB > 512 ? NB / 512 : 1, NRS = NB / NBANK / WAVE / 2;
+	static_assert(NRS <= 4 && (NBANK == 1 || RSV0 + 8 * (NBANK - 1) + NRW <= BT / WAVE), "reservers");
+	const int rsv_w = tid / WAVE - RSV0, rsv = rsv_w >= 0 && (rsv_w & 7) < NRW && (rsv_w >> 3) < NBANK ? (rsv_w & 7) : -1;
+	const uint32_t rsv_b0 = rsv >= 0 ? (uint32_t)(rsv_w >> 3) * 512u + (uint32_t)lane : 0u; // its bank's first bucket of this lane
 	uint32_t rv[NRS], infl = 0; // answers on their way: bit s of infl = rv[s] is one, bit 8 + s = it is the pair's second bucket's
 #pragma unroll
 	for (int u = 0; u < NRS; ++u) rv[u] = 0;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 2 : 1) void k_scatter1_wc(KParams P
 #pragma unroll
 				for (int u = 0; u < NRS; ++u) { // first every answer asked for at this wave's last turn, NRW rounds ago (one wait, for what is long there) ...
 					if (infl & (1u << u)) {
-						const uint32_t b = (uint32_t)lane + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
+						const uint32_t b = rsv_b0 + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
 						res[b] = rv[u];
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						rdy[b] = 1u;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 2 : 1) void k_scatter1_wc(KParams P
 				infl = 0;
 #pragma unroll
 				for (int u = 0; u < NRS; ++u) { // ... then the new requests (nothing below waits for them)
-					const uint32_t b0 = (uint32_t)lane + (uint32_t)u * 2u * WAVE, b1 = b0 + WAVE;
+					const uint32_t b0 = rsv_b0 + (uint32_t)u * 2u * WAVE, b1 = b0 + WAVE;
 					const bool n0 = rq[b0] != 0u, n1 = rq[b1] != 0u;
 					if (n0 | n1) {
 						const uint32_t b = n0 ? b0 : b1;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(BT, BT == 512 ? 2 : 1) void k_scatter1_wc(KParams P
 	if (rsv >= 0) { // groups whose answers never were published
 #pragma unroll
 		for (int u = 0; u < NRS; ++u) if (infl & (1u << u)) {
-			const uint32_t b = (uint32_t)lane + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
+			const uint32_t b = rsv_b0 + (uint32_t)u * 2u * WAVE + (infl & (0x100u << u) ? WAVE : 0u);
 			dead_group(slab_of(b), rv[u]);
 		}
 	}
@@ -430,10 +434,11 @@ namespace bfcg {
 
 // The variants: <word, log2 records per buffer, log2 buckets, threads, k at compile time>.  512 threads: 2^12 records of buffers (48 KiB), two
 // workgroups per CU -- one's flush (P2, P3: chains of dependent instructions and LDS round trips in a few waves) runs under the other's hashing;
-// 1024 threads: 2^13 records (96 KiB), one workgroup per CU (BFCG_S1_WC_BT=1024).
+// 1024 threads: 2^13 records (96 KiB), one workgroup per CU (BFCG_S1_WC_BT=1024, and what 2^10 buckets -- config c4's -b37 -- always take).
 #define WC_VARIANTS(X) \
 	X(uint64_t, 3, 9, 512, 33) X(uint64_t, 3, 9, 512, 0) X(uint64_t, 4, 8, 512, 0) X(uint32_t, 3, 9, 512, 0) X(uint32_t, 4, 8, 512, 0) \
-	X(uint64_t, 4, 9, 1024, 33) X(uint64_t, 4, 9, 1024, 0) X(uint64_t, 5, 8, 1024, 0) X(uint32_t, 4, 9, 1024, 0) X(uint32_t, 5, 8, 1024, 0)
+	X(uint64_t, 4, 9, 1024, 33) X(uint64_t, 4, 9, 1024, 0) X(uint64_t, 5, 8, 1024, 0) X(uint32_t, 4, 9, 1024, 0) X(uint32_t, 5, 8, 1024, 0) \
+	X(uint64_t, 3, 10, 1024, 33) X(uint64_t, 3, 10, 1024, 0) X(uint32_t, 3, 10, 1024, 0)
 
 hipError_t set_scatter1wc_lds_attr(void)
 {
@@ -445,7 +450,7 @@ hipError_t set_scatter1wc_lds_attr(void)
 }
 
 // Whether a one-pass stage A of this geometry can run k_scatter1_wc, and how: 12-byte records packed from halves with the level-1 bucket a bit
-// field of y0's low word (scatter1_fast, checked by the caller), 2^8 or 2^9 level-1 buckets, slabs that begin on 16-byte boundaries, and slabs
+// field of y0's low word (scatter1_fast, checked by the caller), 2^8 .. 2^10 level-1 buckets, slabs that begin on 16-byte boundaries, and slabs
 // large enough for what the workgroups leave unused (up to a group and a half and a padded buffer per workgroup and bucket at the end: dead
 // records).  BFCG_S1_WC=0: never; =2: whenever the geometry allows (tests: tiny slabs overflow and are replayed).
 bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan *pl)
@@ -453,10 +458,10 @@ bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan
 	const char *e = getenv("BFCG_S1_WC");
 	const int mode = e ? atoi(e) : 1;
 	if (mode == 0) return false;
-	if (P.F1 != 8 && P.F1 != 9) return false;
+	if (P.F1 < 8 || P.F1 > 10) return false;
 	if ((OP.cap & 3u) || (OP.own_delta & 3u)) return false;
 	e = getenv("BFCG_S1_WC_BT");
-	const int bt = e && atoi(e) == 1024 ? 1024 : 512;
+	const int bt = P.F1 == 10 || (e && atoi(e) == 1024) ? 1024 : 512;
 	const uint32_t capl = (bt == 512 ? 12 : 13) - P.F1, cap_rec = 1u << capl;
 	static int n_cu = 0;
 	if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
@@ -483,7 +488,7 @@ static unsigned long long g_wc_launches = 0; // (process-wide, for the tests: di
 void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, const WcPlan &pl, hipStream_t st)
 {
 	__atomic_fetch_add(&g_wc_launches, 1ull, __ATOMIC_RELAXED);
-	const int kc = P.k == 33 && P.F1 == 9 ? 33 : 0, w64 = P.k > 32;
+	const int kc = P.k == 33 && P.F1 >= 9 ? 33 : 0, w64 = P.k > 32;
 	const int capl = (pl.bt == 512 ? 12 : 13) - P.F1;
 #define X(W, C, N, B, K) if ((sizeof(W) == 8) == (w64 != 0) && C == capl && N == P.F1 && B == pl.bt && K == kc) { launch_wc<W, C, N, B, K>(P, seq, qual, n_pos, out, OP, pl.G, pl.grid, st); return; }
 	WC_VARIANTS(X)

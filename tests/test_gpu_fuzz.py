@@ -193,19 +193,19 @@ def test_random_configuration_k33_on_tiny_slabs(gpu_lib, seed, monkeypatch):
     _check(gpu_lib, prm, seq, qual, off, cuts, kw)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch):
     """k_scatter1_wc (round 5, bfcg_scatter1wc.hip): level 1 of the one-pass partition through write-combining buffers in LDS -- a buffer of 16 or 32
     records per bucket (8 or 16 with two workgroups of 512 threads per CU), full buffers leave as whole chunks into room reserved a group ahead, what finds its buffer full waits a round in
     registers, what finds it full twice over takes a chunk of its own, dead records in everything reserved and not filled.  Forced (BFCG_S1_WC=2)
-    onto draws whose slabs expect a handful of records, with 8 / 16 / 64 workgroups sharing them and 2^8 / 2^9 level-1 buckets: every path of the
+    onto draws whose slabs expect a handful of records, with 8 / 16 / 64 workgroups sharing them and 2^8 / 2^9 / 2^10 level-1 buckets: every path of the
     kernel runs -- spills on the low-complexity draws, slabs that overflow because of the padding (replayed through two passes), tiles stolen
     from other XCDs' counters, batches of less than one tile -- for k = 33 at compile time, k = 35 at run time and k <= 32 on one word.  Bit for
     bit the oracle's filter(s), statistics and table, like every other draw."""
     monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
     monkeypatch.setenv("BFCG_S1_WC", "2")
     monkeypatch.setenv("BFCG_S1_WC_WGS", str([8, 16, 64][seed % 3]))
-    monkeypatch.setenv("BFCG_F1", str(8 + (seed & 1)))
+    monkeypatch.setenv("BFCG_F1", str(8 + seed % 3))  # (2^10 buckets: config c4's geometry, 1024 threads with two banks of reservers)
     monkeypatch.setenv("BFCG_S1_WC_BT", "1024" if seed % 4 >= 2 else "512")  # (one workgroup of 1024 threads per CU, or two of 512 with buffers half the size)
     if seed % 4 == 3:
         monkeypatch.setenv("BFCG_S1_CHUNK", "64")  # (four chunks of 16 per reservation)
