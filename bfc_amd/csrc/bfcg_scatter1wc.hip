@@ -7,35 +7,38 @@
 // per position -> a 12-byte record (y0 minus its bucket bits | y1 | quality flag | file index) in the slab of its level-1 bucket; the order
 // inside a slab is irrelevant because every record carries its file index.
 //
-// Here a workgroup of 1024 threads (one per CU) lives for the whole batch and owns, per bucket, ONE buffer of CAP records in LDS (2^13 records
-// in all: 96 KiB).  A record takes the slot a returning LDS add on the bucket's fill hands out and is written straight into the buffer; a full
-// buffer leaves as one CHUNK of CAP x 12 contiguous bytes (192 at 512 buckets: whole 32-byte sectors, whole lines for two chunks in three)
-// into room that the bucket's owner lane reserved from the slab's cursor one GROUP of chunks ahead.  A round (one tile of 4096 positions, four per
-// thread) has TWO barriers:
+// Here a persistent workgroup owns, per bucket, ONE buffer of CAP records in LDS: 2^12 records (48 KiB) with 512 threads and two workgroups per
+// CU -- buffers of 8 records at 2^9 buckets, config c3 --, 2^13 (96 KiB) with 1024 threads and one (2^10 buckets, config c4's -b37; BFCG_S1_WC_BT=1024).
+// A record takes the slot a returning LDS add on the bucket's fill hands out and is written straight into the buffer; a full buffer leaves as one
+// CHUNK of CAP x 12 contiguous bytes (whole 32-byte sectors) into room reserved from the slab's cursor a GROUP of four chunks ahead.  A round (one
+// tile of four positions per thread) has THREE barriers:
 //
-//   P1  every thread: the puts that found their buffer full in the previous round (slot - CAP: the buffer was flushed meanwhile), then the
-//       k-mers of its four positions: hash, record, slot = fill[bucket]++; slot < CAP: put; slot < 2 CAP: keep it in registers for the next P1;
-//       beyond that (one bucket drew more than two buffers' worth in one round: 3 in 10 000 (bucket, round) pairs on hashed k-mers) the lane
-//       reserves a chunk of its own and stores the record with CAP - 1 dead records behind it
+//   P1  every thread: the 16-byte pieces it read in the last P3 are stored; the puts that found their buffer full in the previous round (slot -
+//       CAP: the buffer was flushed meanwhile); then the k-mers of its four positions: hash, record, slot = fill[bucket]++; slot < CAP: put; slot <
+//       2 CAP: keep it in registers for the next P1; beyond that (one bucket drew more than two buffers' worth in one round: 3 in 10 000 (bucket,
+//       round) pairs on hashed k-mers) the lane reserves a chunk of its own and stores the record with CAP - 1 dead records behind it
 //   --- barrier A
-//   P2  roles by wave, nothing in common between them:
-//       waves 0-4   the NEXT tile's three base planes from the bases requested a round ago (the quality plane: 261 lanes of waves 8-12, beside
-//                   their owner work); request those of the tile after it; thread 0 settles the tile draw it issued a round ago and issues the next
-//       waves 5-7   the RESERVERS, one of them per round in turn: a bucket whose owner asked for its next group (a word in LDS) gets it by a
-//                   returning atomic on the slab's cursor; the answer is published in LDS at the wave's next turn, three rounds later (these
-//                   waves issue returning atomics and nothing else: what they wait for is three rounds old)
-//       waves 8-15  lane i owns bucket i: fill >= CAP -> (bucket, destination) into the wave's own list (ballot + mbcnt, no atomics), fill -= CAP,
-//                   the chunk pointer moves on -- into the next group, taken from LDS, when the current one is used up; the next but one is
-//                   asked for as soon as a group is begun; then the wave copies its list's chunks, 16 bytes per lane (these waves store and
-//                   never wait for memory: a store is acknowledged ~5 us after its issue on this chip, more than a round -- the first cut, whose
-//                   owners reserved for themselves, spent 5 200 of a round's 14 800 cycles in that wait; profiles/round5_k_scatter1_wc.md)
+//   P2  roles by lane (with 1024 threads and 2^9 buckets they fall on different waves; with 512 threads, or 2^10 buckets, every thread owns a
+//       bucket and has its other roles beside that):
+//       OWNERS      thread OWN0 + i owns bucket i: fill >= CAP -> (bucket, destination) into the round's list (one LDS atomic per wave), fill -=
+//                   CAP, the chunk pointer moves on -- into the next group, taken from LDS, when the current one is used up; the next but one is
+//                   asked for as soon as a group is begun
+//       RESERVERS   waves RSV0.., one per round in turn: a bucket whose owner asked for its next group (a word in LDS) gets it by a returning
+//                   atomic on the slab's cursor; the answer is published in LDS at the wave's next turn (what it waits for then is a turn old).
+//                   An owner that reserved for itself waited for the answer BEHIND its wave's fresh stores -- loads, returning atomics and
+//                   stores share one in-order counter (vmcnt) on this chip --: 3 000 - 4 000 cycles of a round in the first cut
+//       LOADERS     threads 0 .. NCH - 1: the NEXT tile's three base planes from the bases requested a round ago, then the request for the tile
+//                   after it; threads QL0 .. QL0 + NCH - 1 the same for the quality plane; thread DRAW_T settles the tile draw of a round ago
 //   --- barrier B
+//   P3  every thread: up to three 16-byte pieces of the listed chunks from the buffers into registers (nothing but LDS reads)
+//   --- barrier C: the flushed buffers are free
 //
-// Loads, returning atomics and stores share one in-order counter on this chip (vmcnt): the roles are cut so that no wave waits for a load
-// or an atomic behind its own fresh stores.  An owner whose next group is not there when it needs it (a bucket that fills four buffers in
-// five rounds: 3 in 1 000 groups) reserves for itself and waits.  The slabs, their cursors, the dead records (all ones) in what was reserved and not filled, the overflow flag
-// and the statistics are exactly k_scatter1's (OnePass, bfcg_k1.h): k_seg_setup and level 2 read this kernel's output as they read that one's.
-// A tile belongs to an XCD for the DRAW (own counter first, then the others'), but every record of a workgroup goes to its home XCD's slabs.
+// The pieces are stored at the top of the next P1, where a wave that the memory pipeline holds up at the issue of its stores leaves its SIMD to
+// the other waves' hashing (stored from inside P2 by the owner waves, everyone else at the barrier: 2 400 of a round's 14 800 cycles).  The slabs,
+// their cursors, the dead records (all ones) in what was reserved and not filled, the overflow flag and the statistics are exactly k_scatter1's
+// (OnePass, bfcg_k1.h): k_seg_setup and level 2 read this kernel's output as they read that one's.  A tile belongs to an XCD for the DRAW (own
+// counter first, then the others'), but every record of a workgroup goes to its home XCD's slabs.  profiles/round5_k_scatter1_wc.md has the
+// phase clocks, the ablations and what the compiler did on the way.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 	// NRW - 1 reserve.  With 1024 threads and 512 buckets the loaders, the reservers and the owners are different waves (the owners' first
 	// ones also build the quality plane); with 512 threads every thread owns a bucket and has its other roles beside that.
 	constexpr int OWN0 = BT - (int)NB, QL0 = BT / 2, RSV0 = BT == 512 ? 7 : 5, NRW = BT == 512 ? 1 : 3;
+	constexpr int DRAW_T = BT == 512 ? 3 * WAVE : 4 * WAVE + 40; // the thread that draws the tiles: a lane of a wave without a loader's chain (512 threads: wave 3; 1024: a spare lane of wave 4)
 	static_assert(OWN0 >= 0 && NCH <= QL0 && QL0 + NCH <= BT && (NCH + WAVE - 1) / WAVE <= RSV0 && NB % (2 * WAVE) == 0 && CAP >= 8, "roles by wave");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_wc[];
 	uint32_t *buf = reinterpret_cast<uint32_t *>(smem_wc); // NB buffers of CAP records of 3 dwords
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 	// ---- tile draws (k_scatter1's: one counter per XCD behind the cursors; own XCD first)
 	uint32_t *const tile_ctr = OP.cursor + (size_t)8 * NB * 32;
 #define draw_a s_draw_a
-	if (tid == 0) s_draw_a = 0;
+	if (tid == DRAW_T) s_draw_a = 0;
 	auto draw_issue = [&]() -> uint32_t { return draw_a < 8u ? atomicAdd(&tile_ctr[((blockIdx.x + draw_a) & 7u) * 4u], 1u) : 0u; };
 	auto draw_settle = [&](uint32_t t) -> uint32_t {
 		while (draw_a < 8u) {
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 		return WC_NONE;
 	};
 	uint32_t draw = 0;
-	if (tid == 0) {
+	if (tid == DRAW_T) {
 		s_draw[0] = draw_settle(draw_issue()); s_draw[1] = draw_settle(draw_issue()); s_draw[2] = draw_settle(draw_issue());
 		draw = draw_issue();
 	}
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 		{ const unsigned long long now = __builtin_readcyclecounter(); tm_p1 += now - tm_t; tm_t = now; }
 #endif
 		// ---------------- P2
+		if (tid == DRAW_T) { s_draw[3] = draw_settle(draw); draw = draw_issue(); } // (the draw issued a round ago; the next one)
 		if (ld_b) {
-			if (tid == 0) { s_draw[3] = draw_settle(draw); draw = draw_issue(); } // (the draw issued a round ago; the next one)
 			if (t_next != WC_NONE) {
 				planes_b(t_next, planes + (cur ^ 1) * 4 * PW); // (its bases arrived while this tile was hashed)
 				if (t_pf != WC_NONE) prefetch(t_pf);
