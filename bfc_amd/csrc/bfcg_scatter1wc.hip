@@ -178,7 +178,6 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 	// | a request for the next group is on its way (rq, a reserver's register, or res / rdy) << 3 | chunks left in the group (G <= 4)
 	uint32_t ost = G;
 	auto ost_pos = [&]() -> uint32_t { return (ost >> 4) << CAPL; }; // (the position counts chunks there: a buffer may be 8 records)
-	const uint32_t slab16 = owner ? (slab_of(ob) >> 2) * 3u : 0u; // an owner's slab in 16-byte units (slabs begin on multiples of four records)
 	const uint32_t sig = G > 1u ? G - 1u : 1u; // ask for the next group when this many chunks of the current one are left (as soon as it is begun)
 	auto claim = [&](uint32_t base, uint32_t n) -> uint32_t { // a reservation's answer: a full slab poisons the batch (it is replayed), write where it does no harm
 		if (base + n > OP.cap) { OP.flags[0] = 1; return 0u; }
@@ -199,38 +198,37 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 
 	uint4 *const out16 = reinterpret_cast<uint4 *>(out);
 	const uint4 *const buf16 = reinterpret_cast<const uint4 *>(smem_wc);
-	// The flushed chunks leave in 16-byte pieces, THREE per thread and round: read from the buffers into registers between barriers B and C (nothing
-	// but LDS reads there), stored at the top of the next P1 -- where a wave that the memory pipeline holds up at the issue of its stores (2 400
-	// cycles per round when the owner waves stored inside P2, everyone else waiting at the barrier) leaves its SIMD to the three other waves'
-	// hashing.  A chunk is the work of LPC = PIECES / 3 neighbouring threads; thread q of them takes pieces q, q + LPC, q + 2 LPC: one list entry,
-	// one LDS address and one destination per thread, the rest immediate offsets, and the LPC threads' stores of one instruction are contiguous
-	// (a piece per thread and instruction with its own list look-up and address: 70 instead of 25 instructions in every wave and round, in a
-	// kernel whose two workgroups per CU keep the SIMDs' issue slots full).  More than BT / LPC chunks in one round (half the buckets due at
-	// once): the rest is stored from P3.
-	constexpr uint32_t LPC = PIECES / 3, LPCL = LPC == 2 ? 1 : LPC == 4 ? 2 : 3;
-	static_assert(LPC * 3 == PIECES && (1u << LPCL) == LPC, "three pieces per thread");
-	uint4 pv[3]; uint32_t pa = WC_NONE;
+	// The flushed chunks leave in 16-byte pieces, up to NPC per thread and round: read from the buffers into registers between barriers B and C
+	// (nothing but LDS reads there), stored at the top of the next P1 -- where a wave that the memory pipeline holds up at the issue of its
+	// stores (2 400 cycles per round when the owner waves stored inside P2, everyone else waiting at the barrier) leaves its SIMD to the
+	// three other waves' hashing.  More chunks than NPC x BT pieces in one round (half the buckets due at once): the rest is stored from P3.
+	constexpr int NPC = 3; // (a round flushes a fifth of its 4 BT positions' k-mers' worth of chunks on average: 2.4 pieces per thread)
+	uint4 pv[NPC]; uint32_t pa[NPC];
 #pragma unroll
-	for (int i = 0; i < 3; ++i) pv[i] = make_uint4(0, 0, 0, 0);
+	for (int i = 0; i < NPC; ++i) { pv[i] = make_uint4(0, 0, 0, 0); pa[i] = WC_NONE; }
 	auto take_pieces = [&](uint32_t n) { // P3
-		const uint32_t j = (uint32_t)tid >> LPCL, q = (uint32_t)tid & (LPC - 1u);
-		pa = WC_NONE;
-		if (j < n) {
-			const uint2 e = wl[j];
-			// (24-bit multiplies: the compiler's v_mad_u64_u32 for a 32-bit product + offset takes ANY register as the undefined high half of
-			// its addend -- here the one the tile draw's atomic returns to, and with it an s_waitcnt vmcnt(0) for this thread's fresh stores)
-			const uint4 *sp = reinterpret_cast<const uint4 *>(smem_wc + (__umul24(e.x, PIECES * 16u) + q * 16u));
-			pv[0] = sp[0]; pv[1] = sp[LPC]; pv[2] = sp[2 * LPC];
-			pa = e.y + q;
+		const uint32_t np = n * PIECES;
+#pragma unroll
+		for (int i = 0; i < NPC; ++i) {
+			const uint32_t x = (uint32_t)tid + (uint32_t)i * BT;
+			pa[i] = WC_NONE;
+			if (x < np) {
+				const uint32_t j = x / PIECES, p = x - j * PIECES;
+				const uint2 e = wl[j];
+				// (24-bit multiplies: the compiler's v_mad_u64_u32 for a 32-bit product + offset takes ANY register as the undefined high half of
+				// its addend -- here the one the tile draw's atomic returns to, and with it an s_waitcnt vmcnt(0) for this thread's fresh stores)
+				pv[i] = *reinterpret_cast<const uint4 *>(smem_wc + (__umul24(e.x, PIECES * 16u) + p * 16u)); pa[i] = e.y + p;
+			}
 		}
-		for (uint32_t x = (uint32_t)tid + (uint32_t)BT / LPC * PIECES; x < n * PIECES; x += BT) { // (rare)
-			const uint32_t jj = x / PIECES, p = x - jj * PIECES;
-			const uint2 e = wl[jj];
+		for (uint32_t x = (uint32_t)tid + (uint32_t)NPC * BT; x < np; x += BT) { // (rare)
+			const uint32_t j = x / PIECES, p = x - j * PIECES;
+			const uint2 e = wl[j];
 			out16[(size_t)e.y + p] = buf16[e.x * PIECES + p];
 		}
 	};
 	auto store_pieces = [&]() { // top of P1 (and once behind the last round)
-		if (pa != WC_NONE && !BFCG_ABL(P, 256)) { uint4 *dp = out16 + (size_t)pa; dp[0] = pv[0]; dp[LPC] = pv[1]; dp[2 * LPC] = pv[2]; }
+#pragma unroll
+		for (int i = 0; i < NPC; ++i) if (pa[i] != WC_NONE && !BFCG_ABL(P, 256)) out16[(size_t)pa[i]] = pv[i];
 	};
 
 	if (ld_b | ld_q) {
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 			qb = __builtin_amdgcn_readfirstlane(qb);
 			if (due) {
 				const uint32_t my = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-				wl[my] = make_uint2(ob, slab16 + (ost >> 4) * PIECES); // (the chunk's destination in 16-byte units: CAP records are PIECES of them)
+				wl[my] = make_uint2(ob, ((slab_of(ob) + ost_pos()) >> 2) * 3u);
 				fill[ob] = (f < 2u * CAP ? f : 2u * CAP) - CAP;
 				ost += 16u - 1u; // (the next chunk, one less left)
 				if ((ost & 7u) == 0u) { // the next group
