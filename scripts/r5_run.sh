@@ -104,3 +104,8 @@ fi
 if has wcph; then  # k_scatter1_wc's phase clocks (the -DBFCG_MEASURE library, built before the call): cycles per round, P1 / P2
   for e in ${WCPH_ENVS:-X=1}; do env $e TAG=$e timeout 300 python scripts/s1wc_phases.py 2>&1 | tail -2; done | tee gpurun_out/r5_wc_phases.txt
 fi
+if has runs; then  # N more driver-style runs of c3 alone (no secondaries, no boundary, no CPU leg): the spread across a box's minutes
+  for i in $(seq 1 ${RUNS:-4}); do
+    timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-boundary --no-secondary > gpurun_out/r5_run_$i.json 2> gpurun_out/r5_run_$i.log; echo "run $i rc=$?"; summ gpurun_out/r5_run_$i.json
+  done
+fi
