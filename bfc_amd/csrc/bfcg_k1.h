@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "kmer_dev.h"
 #include "bfcg_internal.h"
+#include "bfcg_dev.h"
 
 using namespace bfcg;
 
@@ -104,6 +105,78 @@ __device__ __forceinline__ bool kmer_at(const uint32_t *planes, int r, int k, W 
 	return true;
 }
 
+// ---- records
+
+// A k-mer record is RD dwords: y0, y1 (the two words of bfc_kmer_hash, kmer.h:79-88), the high-quality flag and the file-order index
+// (position in the batch, 32 bit).  After the level-1 scatter a record sits in the bucket its bloom block id selects, and for k >= bf_shift-9
+// that id is a bit field of y0 (kmer_dev.h: the low bf_shift-9 bits of the hash are y0's): bits [rec_lo, rec_lo + rec_n) of y0 ARE the
+// level-1 bucket.  They are not stored (RecGeom): config c3's records (k=33) take 12 instead of 16 bytes, c5's (k=51) 16 instead of 20.
+//   RD=3: u64 A = y0' | y1 << a | hi << (a+k)   (a = k - rec_n kept bits of y0; a + k + 1 <= 64), u32 index          -- 12 bytes
+//   RD=4: one 128-bit word  y0' | y1 << a | hi << (a+k) | index << (a+k+1)                       (a + k + 33 <= 128)  -- 16 bytes
+//   RD=5: u64 y0 | is_high<<63, u64 y1, u32 index (nothing dropped)                                                    -- 20 bytes (4-byte aligned)
+struct RecGeom { int k, a, lo, n; };
+__device__ __forceinline__ RecGeom rec_geom(const KParams &P) { RecGeom g; g.k = P.k; g.n = P.rec_n; g.a = P.k - P.rec_n; g.lo = P.rec_lo; return g; }
+__device__ __forceinline__ uint64_t y0_drop(const RecGeom g, uint64_t y0) { return g.n ? (y0 & ((1ULL << g.lo) - 1)) | ((y0 >> (g.lo + g.n)) << g.lo) : y0; }
+__device__ __forceinline__ uint64_t y0_join(const RecGeom g, uint64_t y0c, uint32_t imp)
+{ return g.n ? (y0c & ((1ULL << g.lo) - 1)) | ((uint64_t)imp << g.lo) | ((y0c >> g.lo) << (g.lo + g.n)) : y0c; }
+
+// A DEAD record (all ones) fills what a level-1 workgroup left unused of its last chunk of a slab (k_scatter1, OnePass): level 2 skips it.  For
+// 12- and 20-byte records the last dword is the file index, which is never 2^32 - 1 (a batch has fewer positions); a 16-byte record's last
+// dword mixes index, y1 and the quality flag, so there every dword is tested (a live record with y0' and y1 all ones AND the last index does not exist).
+template <int RD> __device__ __forceinline__ bool rec_dead(const RecW<RD> &w)
+{
+	if (RD == 4) return (w.d[0] & w.d[1] & w.d[2] & w.d[3]) == 0xffffffffu;
+	return w.d[RD - 1] == 0xffffffffu;
+}
+
+// pack: y0 is the FULL word (the bucket's bits are dropped here); unpack: imp = the record's (global) level-1 bucket
+template <int RD> struct Rec;
+template <> struct Rec<3> {
+	static __device__ __forceinline__ void pack(RecW<3> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	{
+		const uint64_t A = y0_drop(g, y0) | (y1 << g.a) | ((uint64_t)hi << (g.a + g.k));
+		r.d[0] = (uint32_t)A; r.d[1] = (uint32_t)(A >> 32); r.d[2] = idx;
+	}
+	static __device__ __forceinline__ void unpack(const RecW<3> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	{
+		const uint64_t A = r.d[0] | ((uint64_t)r.d[1] << 32);
+		y0 = y0_join(g, A & ((1ULL << g.a) - 1), imp);
+		y1 = (A >> g.a) & ((1ULL << g.k) - 1);
+		hi = (A >> (g.a + g.k)) & 1; idx = r.d[2];
+	}
+};
+template <> struct Rec<4> {
+	// On two 64-bit halves (round 5; the 128-bit arithmetic it replaces compiled into chains of selects around variable funnel shifts): records are
+	// 16 bytes iff 96 < a + k + 33 <= 128, i.e. 64 <= a + k <= 95 with 1 <= a <= 63 -- y1 straddles the halves, the quality flag (bit a + k) and
+	// the index (from bit a + k + 1) lie in the upper one.
+	static __device__ __forceinline__ void pack(RecW<4> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	{
+		const uint64_t lo = y0_drop(g, y0) | (y1 << g.a);
+		const uint64_t hi64 = (y1 >> (64 - g.a)) | ((uint64_t)hi << (g.a + g.k - 64)) | ((uint64_t)idx << (g.a + g.k - 63));
+		r.d[0] = (uint32_t)lo; r.d[1] = (uint32_t)(lo >> 32); r.d[2] = (uint32_t)hi64; r.d[3] = (uint32_t)(hi64 >> 32);
+	}
+	static __device__ __forceinline__ void unpack(const RecW<4> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	{
+		const uint64_t lo = r.d[0] | ((uint64_t)r.d[1] << 32), hi64 = r.d[2] | ((uint64_t)r.d[3] << 32);
+		y0 = y0_join(g, lo & ((1ULL << g.a) - 1), imp);
+		y1 = ((lo >> g.a) | (hi64 << (64 - g.a))) & ((1ULL << g.k) - 1);
+		hi = (hi64 >> (g.a + g.k - 64)) & 1;
+		idx = (uint32_t)(hi64 >> (g.a + g.k - 63));
+	}
+};
+template <> struct Rec<5> {
+	static __device__ __forceinline__ void pack(RecW<5> &r, const RecGeom, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
+	{
+		const uint64_t a = y0 | ((uint64_t)hi << 63);
+		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)y1; r.d[3] = (uint32_t)(y1 >> 32); r.d[4] = idx;
+	}
+	static __device__ __forceinline__ void unpack(const RecW<5> &r, const RecGeom, uint32_t, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
+	{
+		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32);
+		y0 = a & ~(1ULL << 63); hi = a >> 63; y1 = r.d[2] | ((uint64_t)r.d[3] << 32); idx = r.d[4];
+	}
+};
+
 // ONEPASS: no histogram pass at all (K1 runs ONCE per batch).  The output is not one contiguous run per bucket but 8 SLABS per bucket, one per
 // XCD (workgroups are dealt to the XCDs round-robin: blockIdx & 7), each of `cap` records: a tile reserves room for its bucket runs with one
 // returning atomicAdd per bucket on the slab's cursor -- 8 x 2^F1 cursors on cache lines of their own, so that the chains of same-address
@@ -143,7 +216,7 @@ __device__ __forceinline__ void pack3_fast(RecW<3> &r, const Pack3 g, const U2 y
 namespace bfcg {
 // bfcg_scatter1wc.hip: level 1 through write-combining buffers in LDS (k_scatter1_wc) -- whether this one-pass stage A can take it and how
 // (threads per workgroup, chunks per reservation, persistent workgroups), and its launch
-struct WcPlan { int bt; uint32_t G; unsigned grid; };
-bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan *pl);
+struct WcPlan { int rw, bt, spt; uint32_t G; unsigned grid; }; // record dwords, threads, positions per thread and round, chunks per reservation, workgroups
+bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int rw, int64_t n_pos, WcPlan *pl);
 void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, const WcPlan &pl, hipStream_t st);
 }

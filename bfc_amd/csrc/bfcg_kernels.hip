@@ -1,8 +1,10 @@
 // bfcg_kernels.hip -- hand-written gfx950 kernels for the k-mer counting path of bfc
 // (count.c + bbf.c + htab.c).  DESIGN.md section 2 has the pipeline; per batch of reads:
 //
-//   k_scatter1   bases -> k-mers ONCE (K1, kmer_dev.h: windows of four bit planes, no rolling state) -> 12/16/20-byte records,
-//                ordered by level-1 bucket in LDS and appended run by run to the bucket's slabs (one cursor atomic per run)
+//   k_scatter1_wc (bfcg_scatter1wc.hip, round 5: 12-byte records, and 16-byte ones at 2^10 buckets) / k_scatter1 (every other geometry)
+//                bases -> k-mers ONCE (K1, kmer_dev.h: windows of four bit planes, no rolling state) -> 12/16/20-byte records into the
+//                level-1 buckets' slabs: through write-combining buffers in LDS that leave as whole chunks, or (k_scatter1) ordered by
+//                bucket in LDS tile by tile and appended run by run (one cursor atomic per run)
 //   k_seg_setup  the slabs' fill -> the segment list level 2 reads
 //   k_scatter2   level-1 slabs -> one slab per bloom REGION (2^R blocks of 64 bytes), again one pass
 //   k_bloom      one workgroup per region: the region of the bitmap in LDS, exact sequential `seen` flags by a first-setter
@@ -106,75 +108,7 @@ __device__ __forceinline__ void build_planes(const uint8_t *__restrict__ seq, co
 // ------------------------------------------------------------------------------------------
 // records
 
-// A k-mer record is RD dwords: y0, y1 (the two words of bfc_kmer_hash, kmer.h:79-88), the high-quality flag and the file-order index
-// (position in the batch, 32 bit).  After the level-1 scatter a record sits in the bucket its bloom block id selects, and for k >= bf_shift-9
-// that id is a bit field of y0 (kmer_dev.h: the low bf_shift-9 bits of the hash are y0's): bits [rec_lo, rec_lo + rec_n) of y0 ARE the
-// level-1 bucket.  They are not stored (RecGeom): config c3's records (k=33) take 12 instead of 16 bytes, c5's (k=51) 16 instead of 20.
-//   RD=3: u64 A = y0' | y1 << a | hi << (a+k)   (a = k - rec_n kept bits of y0; a + k + 1 <= 64), u32 index          -- 12 bytes
-//   RD=4: one 128-bit word  y0' | y1 << a | hi << (a+k) | index << (a+k+1)                       (a + k + 33 <= 128)  -- 16 bytes
-//   RD=5: u64 y0 | is_high<<63, u64 y1, u32 index (nothing dropped)                                                    -- 20 bytes (4-byte aligned)
-struct RecGeom { int k, a, lo, n; };
-__device__ __forceinline__ RecGeom rec_geom(const KParams &P) { RecGeom g; g.k = P.k; g.n = P.rec_n; g.a = P.k - P.rec_n; g.lo = P.rec_lo; return g; }
-__device__ __forceinline__ uint64_t y0_drop(const RecGeom g, uint64_t y0) { return g.n ? (y0 & ((1ULL << g.lo) - 1)) | ((y0 >> (g.lo + g.n)) << g.lo) : y0; }
-__device__ __forceinline__ uint64_t y0_join(const RecGeom g, uint64_t y0c, uint32_t imp)
-{ return g.n ? (y0c & ((1ULL << g.lo) - 1)) | ((uint64_t)imp << g.lo) | ((y0c >> g.lo) << (g.lo + g.n)) : y0c; }
-
-// A DEAD record (all ones) fills what a level-1 workgroup left unused of its last chunk of a slab (k_scatter1, OnePass): level 2 skips it.  For
-// 12- and 20-byte records the last dword is the file index, which is never 2^32 - 1 (a batch has fewer positions); a 16-byte record's last
-// dword mixes index, y1 and the quality flag, so there every dword is tested (a live record with y0' and y1 all ones AND the last index does not exist).
-template <int RD> __device__ __forceinline__ bool rec_dead(const RecW<RD> &w)
-{
-	if (RD == 4) return (w.d[0] & w.d[1] & w.d[2] & w.d[3]) == 0xffffffffu;
-	return w.d[RD - 1] == 0xffffffffu;
-}
-
-// pack: y0 is the FULL word (the bucket's bits are dropped here); unpack: imp = the record's (global) level-1 bucket
-template <int RD> struct Rec;
-template <> struct Rec<3> {
-	static __device__ __forceinline__ void pack(RecW<3> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
-	{
-		const uint64_t A = y0_drop(g, y0) | (y1 << g.a) | ((uint64_t)hi << (g.a + g.k));
-		r.d[0] = (uint32_t)A; r.d[1] = (uint32_t)(A >> 32); r.d[2] = idx;
-	}
-	static __device__ __forceinline__ void unpack(const RecW<3> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
-	{
-		const uint64_t A = r.d[0] | ((uint64_t)r.d[1] << 32);
-		y0 = y0_join(g, A & ((1ULL << g.a) - 1), imp);
-		y1 = (A >> g.a) & ((1ULL << g.k) - 1);
-		hi = (A >> (g.a + g.k)) & 1; idx = r.d[2];
-	}
-};
-template <> struct Rec<4> {
-	// On two 64-bit halves (round 5; the 128-bit arithmetic it replaces compiled into chains of selects around variable funnel shifts): records are
-	// 16 bytes iff 96 < a + k + 33 <= 128, i.e. 64 <= a + k <= 95 with 1 <= a <= 63 -- y1 straddles the halves, the quality flag (bit a + k) and
-	// the index (from bit a + k + 1) lie in the upper one.
-	static __device__ __forceinline__ void pack(RecW<4> &r, const RecGeom g, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
-	{
-		const uint64_t lo = y0_drop(g, y0) | (y1 << g.a);
-		const uint64_t hi64 = (y1 >> (64 - g.a)) | ((uint64_t)hi << (g.a + g.k - 64)) | ((uint64_t)idx << (g.a + g.k - 63));
-		r.d[0] = (uint32_t)lo; r.d[1] = (uint32_t)(lo >> 32); r.d[2] = (uint32_t)hi64; r.d[3] = (uint32_t)(hi64 >> 32);
-	}
-	static __device__ __forceinline__ void unpack(const RecW<4> &r, const RecGeom g, uint32_t imp, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
-	{
-		const uint64_t lo = r.d[0] | ((uint64_t)r.d[1] << 32), hi64 = r.d[2] | ((uint64_t)r.d[3] << 32);
-		y0 = y0_join(g, lo & ((1ULL << g.a) - 1), imp);
-		y1 = ((lo >> g.a) | (hi64 << (64 - g.a))) & ((1ULL << g.k) - 1);
-		hi = (hi64 >> (g.a + g.k - 64)) & 1;
-		idx = (uint32_t)(hi64 >> (g.a + g.k - 63));
-	}
-};
-template <> struct Rec<5> {
-	static __device__ __forceinline__ void pack(RecW<5> &r, const RecGeom, uint64_t y0, uint64_t y1, uint32_t idx, bool hi)
-	{
-		const uint64_t a = y0 | ((uint64_t)hi << 63);
-		r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)y1; r.d[3] = (uint32_t)(y1 >> 32); r.d[4] = idx;
-	}
-	static __device__ __forceinline__ void unpack(const RecW<5> &r, const RecGeom, uint32_t, uint64_t &y0, uint64_t &y1, uint32_t &idx, bool &hi)
-	{
-		const uint64_t a = r.d[0] | ((uint64_t)r.d[1] << 32);
-		y0 = a & ~(1ULL << 63); hi = a >> 63; y1 = r.d[2] | ((uint64_t)r.d[3] << 32); idx = r.d[4];
-	}
-};
+// (the records -- RecGeom, Rec<3 / 4 / 5>, rec_dead -- are in bfcg_k1.h: bfcg_scatter1wc.hip packs them too)
 
 template <typename W> __device__ __forceinline__ uint32_t fine_id(const KParams &P, uint64_t y0, uint64_t y1)
 {
@@ -2282,12 +2216,16 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	}
 	if constexpr (RW == 3) {
 		WcPlan wc;
-		if (B.cnt_live && scatter1_fast(P) && scatter1_wc_plan(P, OP, n_pos, &wc)) run_scatter1_wc(P, seq, qual, n_pos, out1, OP, wc, st); // (round 5: write-combining buffers in LDS)
+		if (B.cnt_live && scatter1_fast(P) && scatter1_wc_plan(P, OP, 3, n_pos, &wc)) run_scatter1_wc(P, seq, qual, n_pos, out1, OP, wc, st); // (round 5: write-combining buffers in LDS)
 		else if (scatter1_fast(P)) {
 			if (sizeof(W) == 8 && P.k == 33) hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, sizeof(W) == 8 ? 33 : 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
 			else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true, 0, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
 		} else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
-	} else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
+	} else {
+		WcPlan wc;
+		if (RW == 4 && B.cnt_live && scatter1_wc_plan(P, OP, 4, n_pos, &wc)) run_scatter1_wc(P, seq, qual, n_pos, out1, OP, wc, st); // (16-byte records at 2^10 buckets: config c5)
+		else hipLaunchKernelGGL((k_scatter1<W, RW, T1, BTS1, true>), dim3(g1), dim3(BTS1), lds1, st, P, seq, qual, n_pos, (const uint32_t *)nullptr, out1, OP);
+	}
 	dbg_sync(st, "k_scatter1 (one pass)");
 	uint32_t *sg = B.op_seg;
 	hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, st, P, B.op_cursor, B.op_cap, B.op_flags, T2, sg, sg + 8 * nb1, sg + 16 * nb1, sg + 24 * nb1 + 1);

@@ -4,14 +4,15 @@
 // scan the bucket counters, reserve a place per (tile, bucket) run, stage the tile in bucket order, copy it out run by run: five barriers per
 // tile, ~61 of the kernel's 175 lane-instructions per k-mer, and runs of ~6 records = 77 bytes that leave as partial lines (WRITE_SIZE 1.54 x the
 // records; profiles/round5_c3.md).  Semantics are the same: count.c:72-89 (rolling k-mers, quality mask) and kmer.h:79-88 (the canonical hash)
-// per position -> a 12-byte record (y0 minus its bucket bits | y1 | quality flag | file index) in the slab of its level-1 bucket; the order
-// inside a slab is irrelevant because every record carries its file index.
+// per position -> a 12-byte record (y0 minus its bucket bits | y1 | quality flag | file index; 16 bytes for 37 <= k <= 52 at 2^10 buckets: config
+// c5's k = 51) in the slab of its level-1 bucket; the order inside a slab is irrelevant because every record carries its file index.
 //
 // Here a persistent workgroup owns, per bucket, ONE buffer of CAP records in LDS: 2^12 records (48 KiB) with 512 threads and two workgroups per
-// CU -- buffers of 8 records at 2^9 buckets, config c3 --, 2^13 (96 KiB) with 1024 threads and one (2^10 buckets, config c4's -b37; BFCG_S1_WC_BT=1024).
+// CU -- buffers of 8 records at 2^9 buckets, config c3 --, 2^13 (96 KiB; 128 KiB of 16-byte records) with 1024 threads and one (2^10 buckets,
+// configs c4's and c5's -b37; BFCG_S1_WC_BT=1024).
 // A record takes the slot a returning LDS add on the bucket's fill hands out and is written straight into the buffer; a full buffer leaves as one
-// CHUNK of CAP x 12 contiguous bytes (whole 32-byte sectors) into room reserved from the slab's cursor a GROUP of four chunks ahead.  A round (one
-// tile of four positions per thread) has THREE barriers:
+// CHUNK of CAP x 12 (16) contiguous bytes (whole 32-byte sectors) into room reserved from the slab's cursor a GROUP of four chunks ahead.  A round
+// (one tile of four positions per thread; three with 16-byte records) has THREE barriers:
 //
 //   P1  every thread: the 16-byte pieces it read in the last P3 are stored; the puts that found their buffer full in the previous round (slot -
 //       CAP: the buffer was flushed meanwhile); then the k-mers of its four positions: hash, record, slot = fill[bucket]++; slot < CAP: put; slot <
@@ -52,14 +53,16 @@ using namespace bfcg;
 
 constexpr uint32_t WC_NONE = 0xffffffffu;
 
-// W: the k-mer word (one 32-bit word up to k = 32, else halves); CAPL, NBL: log2 records per buffer, log2 buckets; BT: threads (512: two workgroups
-// per CU, 1024: one); KC: k at compile time or 0.  A round is a tile of 4 BT positions.
-template <typename W, int CAPL, int NBL, int BT, int KC>
+// W: the k-mer word (one 32-bit word up to k = 32, else halves); RW: dwords per record (3, or 4: k up to 52 at 2^10 buckets -- config c5); CAPL, NBL:
+// log2 records per buffer, log2 buckets; BT: threads (512: two workgroups per CU, 1024: one); S: positions per thread and round (a round is a
+// tile of S BT positions); KC: k at compile time or 0.
+template <typename W, int RW, int CAPL, int NBL, int BT, int S, int KC>
 __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, int64_t n_pos,
                                                                        uint32_t *__restrict__ out, OnePass OP, uint32_t G)
 {
-	constexpr int S = 4, TILE = BT * S;
-	constexpr uint32_t CAP = 1u << CAPL, NB = 1u << NBL, PIECES = CAP * 3 / 4; // records per buffer, buckets, 16-byte pieces of a chunk
+	constexpr int TILE = BT * S;
+	constexpr uint32_t CAP = 1u << CAPL, NB = 1u << NBL, PIECES = CAP * RW / 4; // records per buffer, buckets, 16-byte pieces of a chunk
+	static_assert(RW == 3 || RW == 4, "12- or 16-byte records");
 	constexpr int PW = (TILE + 64) / 32 + 2, NC16 = (TILE + 64) / 16, NCH = NC16 + 1;
 	// Roles.  Thread OWN0 + i owns bucket i; threads 0 .. NCH - 1 build the base planes, QL0 .. QL0 + NCH - 1 the quality plane; waves RSV0 .. RSV0 +
 	// NRW - 1 reserve.  With 1024 threads and 512 buckets the loaders, the reservers and the owners are different waves (the owners' first
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 	const bool owner = tid >= OWN0;
 	// (recomputed where they are used -- the kernel runs at the register limit of its 1024 threads: ob = the bucket an owner thread owns, its slab's base)
 #define ob ((uint32_t)(tid - OWN0))
+	auto to16 = [](uint32_t r) -> uint32_t { return RW == 3 ? (r >> 2) * 3u : r; }; // a record index (a multiple of four where records are 12 bytes) in 16-byte units
 	auto slab_of = [&](uint32_t b) -> uint32_t { return (b * 8u + home) * OP.cap + (b - OP.own_lo < OP.own_n ? OP.own_delta : 0u); };
 	// An owner's state in one register (the kernel runs at the register limit of its 1024 threads): the chunk it hands out next (counted in chunks) << 4
 	// | a request for the next group is on its way (rq, a reserver's register, or res / rdy) << 3 | chunks left in the group (G <= 4)
@@ -238,13 +242,17 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 	}
 	__syncthreads();
 
-	RecW<3> w[S];
+	RecW<RW> w[S];
 	uint32_t pend[S]; // a record that found its buffer full: where it goes once the buffer has been flushed (record index in buf), else WC_NONE
 #pragma unroll
 	for (int j = 0; j < S; ++j) pend[j] = WC_NONE;
 	uint32_t n_k = 0, n_h = 0;
 	int cur = 0;
-	auto put = [&](uint32_t o, const RecW<3> &r) { uint32_t *p = reinterpret_cast<uint32_t *>(smem_wc + __umul24(o, 12u)); p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; };
+	auto put = [&](uint32_t o, const RecW<RW> &r) {
+		if constexpr (RW == 4) *reinterpret_cast<uint4 *>(smem_wc + __umul24(o, 16u)) = make_uint4(r.d[0], r.d[1], r.d[2], r.d[3]);
+		else { uint32_t *p = reinterpret_cast<uint32_t *>(smem_wc + __umul24(o, 12u)); p[0] = r.d[0]; p[1] = r.d[1]; p[2] = r.d[2]; }
+	};
+	const RecGeom RG = rec_geom(P);
 
 #ifdef BFCG_MEASURE // phase clocks (scripts/s1wc_phases.py): thread 0 and the first owner lane, summed per workgroup into the statistics' spare words
 	unsigned long long tm_p1 = 0, tm_p2 = 0, tm_ld = 0, tm_ow = 0, tm_w8 = 0, tm_n = 0, tm_t = __builtin_readcyclecounter();
@@ -271,7 +279,8 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 			sl[j] = WC_NONE; bo[j] = 0;
 			if (have) {
 				const uint32_t b = (y0.lo >> b1_shift) & (NB - 1u);
-				pack3_fast(w[j], PK, y0, y1, P.idx_rank | (t_cur * (uint32_t)TILE + (uint32_t)r), hi);
+				if constexpr (RW == 3) pack3_fast(w[j], PK, y0, y1, P.idx_rank | (t_cur * (uint32_t)TILE + (uint32_t)r), hi);
+				else Rec<RW>::pack(w[j], RG, u2_join(y0), u2_join(y1), P.idx_rank | (t_cur * (uint32_t)TILE + (uint32_t)r), hi);
 				sl[j] = atomicAdd(&fill[b], 1u); bo[j] = b << CAPL;
 				++n_k; n_h += hi;
 			}
@@ -283,9 +292,10 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 			else if (sl[j] != WC_NONE) { // more than two buffers' worth for one bucket in one round: a chunk of its own, the record and CAP - 1 dead ones
 				const uint32_t b = bo[j] >> CAPL;
 				const uint32_t base = claim(atomicAdd(&OP.cursor[((size_t)home * NB + b) * 32], CAP), CAP);
-				uint32_t *d = out + (size_t)(slab_of(b) + base) * 3u;
-				d[0] = w[j].d[0]; d[1] = w[j].d[1]; d[2] = w[j].d[2];
-				for (uint32_t z = 3; z < CAP * 3u; ++z) d[z] = 0xffffffffu;
+				uint32_t *d = out + (size_t)(slab_of(b) + base) * RW;
+#pragma unroll
+				for (int z = 0; z < RW; ++z) d[z] = w[j].d[z];
+				for (uint32_t z = RW; z < CAP * RW; ++z) d[z] = 0xffffffffu;
 			}
 		}
 #ifdef BFCG_MEASURE
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 			qb = __builtin_amdgcn_readfirstlane(qb);
 			if (due) {
 				const uint32_t my = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-				wl[my] = make_uint2(ob, ((slab_of(ob) + ost_pos()) >> 2) * 3u);
+				wl[my] = make_uint2(ob, to16(slab_of(ob) + ost_pos()));
 				fill[ob] = (f < 2u * CAP ? f : 2u * CAP) - CAP;
 				ost += 16u - 1u; // (the next chunk, one less left)
 				if ((ost & 7u) == 0u) { // the next group
@@ -381,18 +391,18 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 	const uint4 dead = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
 	auto dead_group = [&](uint32_t b_slab, uint32_t base) { // a group that was reserved and never begun
 		if (base + RES > OP.cap) { OP.flags[0] = 1; return; } // (k_seg_setup reads the slab up to min(cursor, capacity): a piece of this group would lie inside it, unwritten)
-		uint4 *d = out16 + (size_t)(((b_slab + base) >> 2) * 3u);
+		uint4 *d = out16 + (size_t)to16(b_slab + base);
 		for (uint32_t z = 0; z < G * PIECES; ++z) d[z] = dead;
 	};
 	if (owner) {
 		const uint32_t f = fill[ob]; // <= CAP
-		for (uint32_t z = f; z < CAP; ++z) { uint32_t *p = buf + ((ob << CAPL) + z) * 3u; p[0] = 0xffffffffu; p[1] = 0xffffffffu; p[2] = 0xffffffffu; }
+		for (uint32_t z = f * RW; z < CAP * RW; ++z) buf[(ob << CAPL) * RW + z] = 0xffffffffu;
 		{ // the (padded) buffer itself: lane by lane, once per kernel
 			const uint4 *sp = buf16 + ob * PIECES;
-			uint4 *dp = out16 + (size_t)(((slab_of(ob) + ost_pos()) >> 2) * 3u);
+			uint4 *dp = out16 + (size_t)to16(slab_of(ob) + ost_pos());
 			for (uint32_t z = 0; z < PIECES; ++z) dp[z] = sp[z];
 		}
-		uint4 *d = out16 + (size_t)(((slab_of(ob) + ost_pos() + CAP) >> 2) * 3u);
+		uint4 *d = out16 + (size_t)to16(slab_of(ob) + ost_pos() + CAP);
 		for (uint32_t z = 0; z < ((ost & 7u) - 1u) * PIECES; ++z) d[z] = dead; // the rest of the current group
 		if ((ost & 8u) && rdy[ob] != 0u) dead_group(slab_of(ob), res[ob]); // a group that was published and never taken
 	}
@@ -424,13 +434,13 @@ __global__ __launch_bounds__(BT, 4) void k_scatter1_wc(KParams P, const uint8_t 
 
 namespace {
 
-template <typename W, int CAPL, int NBL, int BT, int KC>
+template <typename W, int RW, int CAPL, int NBL, int BT, int S, int KC>
 void launch_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, uint32_t G, unsigned grid, hipStream_t st)
 {
-	hipLaunchKernelGGL((k_scatter1_wc<W, CAPL, NBL, BT, KC>), dim3(grid), dim3(BT), (size_t)12 << (CAPL + NBL), st, P, seq, qual, n_pos, out, OP, G);
+	hipLaunchKernelGGL((k_scatter1_wc<W, RW, CAPL, NBL, BT, S, KC>), dim3(grid), dim3(BT), (size_t)(RW * 4) << (CAPL + NBL), st, P, seq, qual, n_pos, out, OP, G);
 }
-template <typename W, int CAPL, int NBL, int BT, int KC>
-hipError_t attr_wc() { return hipFuncSetAttribute((const void *)k_scatter1_wc<W, CAPL, NBL, BT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << (CAPL + NBL)); }
+template <typename W, int RW, int CAPL, int NBL, int BT, int S, int KC>
+hipError_t attr_wc() { return hipFuncSetAttribute((const void *)k_scatter1_wc<W, RW, CAPL, NBL, BT, S, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (RW * 4) << (CAPL + NBL)); }
 
 } // namespace
 
@@ -440,14 +450,15 @@ namespace bfcg {
 // workgroups per CU -- one's flush (P2, P3: chains of dependent instructions and LDS round trips in a few waves) runs under the other's hashing;
 // 1024 threads: 2^13 records (96 KiB), one workgroup per CU (BFCG_S1_WC_BT=1024, and what 2^10 buckets -- config c4's -b37 -- always take).
 #define WC_VARIANTS(X) \
-	X(uint64_t, 3, 9, 512, 33) X(uint64_t, 3, 9, 512, 0) X(uint64_t, 4, 8, 512, 0) X(uint32_t, 3, 9, 512, 0) X(uint32_t, 4, 8, 512, 0) \
-	X(uint64_t, 4, 9, 1024, 33) X(uint64_t, 4, 9, 1024, 0) X(uint64_t, 5, 8, 1024, 0) X(uint32_t, 4, 9, 1024, 0) X(uint32_t, 5, 8, 1024, 0) \
-	X(uint64_t, 3, 10, 1024, 33) X(uint64_t, 3, 10, 1024, 0) X(uint32_t, 3, 10, 1024, 0)
+	X(uint64_t, 3, 3, 9, 512, 4, 33) X(uint64_t, 3, 3, 9, 512, 4, 0) X(uint64_t, 3, 4, 8, 512, 4, 0) X(uint32_t, 3, 3, 9, 512, 4, 0) X(uint32_t, 3, 4, 8, 512, 4, 0) \
+	X(uint64_t, 3, 4, 9, 1024, 4, 33) X(uint64_t, 3, 4, 9, 1024, 4, 0) X(uint64_t, 3, 5, 8, 1024, 4, 0) X(uint32_t, 3, 4, 9, 1024, 4, 0) X(uint32_t, 3, 5, 8, 1024, 4, 0) \
+	X(uint64_t, 3, 3, 10, 1024, 4, 33) X(uint64_t, 3, 3, 10, 1024, 4, 0) X(uint32_t, 3, 3, 10, 1024, 4, 0) \
+	X(uint64_t, 4, 3, 10, 1024, 3, 0) /* 16-byte records (config c5: k = 51, -b37): 2^10 buffers of 8 x 16 bytes = 128 KiB, three positions per thread and round */
 
 hipError_t set_scatter1wc_lds_attr(void)
 {
 	hipError_t e = hipSuccess;
-#define X(W, C, N, B, K) if (e == hipSuccess) e = attr_wc<W, C, N, B, K>();
+#define X(W, R, C, N, B, S, K) if (e == hipSuccess) e = attr_wc<W, R, C, N, B, S, K>();
 	WC_VARIANTS(X)
 #undef X
 	return e;
@@ -457,21 +468,24 @@ hipError_t set_scatter1wc_lds_attr(void)
 // field of y0's low word (scatter1_fast, checked by the caller), 2^8 .. 2^10 level-1 buckets, slabs that begin on 16-byte boundaries, and slabs
 // large enough for what the workgroups leave unused (up to a group and a half and a padded buffer per workgroup and bucket at the end: dead
 // records).  BFCG_S1_WC=0: never; =2: whenever the geometry allows (tests: tiny slabs overflow and are replayed).
-bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan *pl)
+bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int rw, int64_t n_pos, WcPlan *pl)
 {
 	const char *e = getenv("BFCG_S1_WC");
 	const int mode = e ? atoi(e) : 1;
 	if (mode == 0) return false;
 	if (P.F1 < 8 || P.F1 > 10) return false;
 	if ((OP.cap & 3u) || (OP.own_delta & 3u)) return false;
+	// 16-byte records: the one geometry that is instantiated (config c5's: k > 32, 2^10 buckets); the bucket must be a bit field of y0's low word
+	if (rw == 4 && !(P.F1 == 10 && P.k > 32 && P.k >= P.bf_shift - 9 && P.R + P.F2 + P.F1 <= 32)) return false;
+	if (rw != 3 && rw != 4) return false;
 	e = getenv("BFCG_S1_WC_BT");
-	const int bt = P.F1 == 10 || (e && atoi(e) == 1024) ? 1024 : 512;
+	const int bt = P.F1 == 10 || (e && atoi(e) == 1024) ? 1024 : 512, spt = rw == 4 ? 3 : 4;
 	const uint32_t capl = (bt == 512 ? 12 : 13) - P.F1, cap_rec = 1u << capl;
 	static int n_cu = 0;
 	if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
 	unsigned g = (unsigned)(n_cu * (bt == 512 ? 2 : 1)) & ~7u; if (g < 8) g = 8; // persistent workgroups: as many as are resident at once, a multiple of 8 (XCDs)
 	e = getenv("BFCG_S1_WC_WGS"); if (e && atoi(e) >= 8) g = (unsigned)atoi(e) & ~7u; // (tests: fewer workgroups on small draws)
-	const int64_t tiles = (n_pos + 4 * bt - 1) / (4 * bt);
+	const int64_t tiles = (n_pos + spt * bt - 1) / (spt * bt);
 	const unsigned gt = (unsigned)(((tiles + 7) / 8) * 8);
 	if (gt < g) g = gt;
 	// Chunks per reservation: four -- an owner asks for its next group when it begins one, the answer is published one to four rounds later, and a
@@ -483,7 +497,7 @@ bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int64_t n_pos, WcPlan
 	if (ce && atoi(ce) > 0) { G = (uint32_t)atoi(ce) >> capl; if (G < 1) G = 1; if (G > 4) G = 4; }
 	else while (G > 1 && waste(G) > OP.cap) G >>= 1;
 	if (mode != 2 && waste(G) > OP.cap) return false;
-	pl->bt = bt; pl->G = G; pl->grid = g;
+	pl->rw = rw; pl->bt = bt; pl->spt = spt; pl->G = G; pl->grid = g;
 	return true;
 }
 
@@ -492,12 +506,12 @@ static unsigned long long g_wc_launches = 0; // (process-wide, for the tests: di
 void run_scatter1_wc(const KParams &P, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out, const OnePass &OP, const WcPlan &pl, hipStream_t st)
 {
 	__atomic_fetch_add(&g_wc_launches, 1ull, __ATOMIC_RELAXED);
-	const int kc = P.k == 33 && P.F1 >= 9 ? 33 : 0, w64 = P.k > 32;
+	const int kc = pl.rw == 3 && P.k == 33 && P.F1 >= 9 ? 33 : 0, w64 = P.k > 32;
 	const int capl = (pl.bt == 512 ? 12 : 13) - P.F1;
-#define X(W, C, N, B, K) if ((sizeof(W) == 8) == (w64 != 0) && C == capl && N == P.F1 && B == pl.bt && K == kc) { launch_wc<W, C, N, B, K>(P, seq, qual, n_pos, out, OP, pl.G, pl.grid, st); return; }
+#define X(W, R, C, N, B, S, K) if ((sizeof(W) == 8) == (w64 != 0) && R == pl.rw && C == capl && N == P.F1 && B == pl.bt && S == pl.spt && K == kc) { launch_wc<W, R, C, N, B, S, K>(P, seq, qual, n_pos, out, OP, pl.G, pl.grid, st); return; }
 	WC_VARIANTS(X)
 #undef X
-	fprintf(stderr, "[bfcg] k_scatter1_wc: no variant for k=%d F1=%d threads=%d\n", P.k, P.F1, pl.bt); abort(); // (scatter1_wc_plan admits only what is instantiated)
+	fprintf(stderr, "[bfcg] k_scatter1_wc: no variant for k=%d F1=%d threads=%d record dwords=%d\n", P.k, P.F1, pl.bt, pl.rw); abort(); // (scatter1_wc_plan admits only what is instantiated)
 }
 
 } // namespace bfcg

@@ -109,3 +109,9 @@ if has runs; then  # N more driver-style runs of c3 alone (no secondaries, no bo
     timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-boundary --no-secondary > gpurun_out/r5_run_$i.json 2> gpurun_out/r5_run_$i.log; echo "run $i rc=$?"; summ gpurun_out/r5_run_$i.json
   done
 fi
+if has wc16; then  # k_scatter1_wc on 16-byte records: its fuzz family + the c5 shapes of the baseline tests, then c5 at 8x coverage with the tile kernel and with it
+  timeout 1200 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_baseline_shapes.py tests/test_gpu_parity.py -q -m gpu -x -k "write_combining or c5 or filter_mode" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > gpurun_out/r5_wc16.log; tail -6 gpurun_out/r5_wc16.log
+  for v in 0 1; do
+    BFCG_S1_WC=$v timeout 900 python scripts/c4_run.py --batch-reads 16777216 --filter-mode 1 --k 51 --cov ${C5_COV:-8} > gpurun_out/r5_c5_wc$v.log 2>&1; echo "BFCG_S1_WC=$v"; tail -1 gpurun_out/r5_c5_wc$v.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('gpu_s','gpu_stage_ms','n_kmers','n_seen','partition')})"
+  done
+fi

@@ -216,6 +216,22 @@ def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch)
     _check(gpu_lib, prm, seq, qual, off, cuts, kw)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_write_combining_level1_16_byte_records(gpu_lib, seed, monkeypatch):
+    """k_scatter1_wc on 16-byte records (config c5's geometry: k = 51, 2^10 level-1 buckets; 1024 threads, buffers of 8 x 16 bytes, three
+    positions per thread and round): k = 39 / 47 / 51 / 52 forced onto small draws with 8 / 16 / 64 workgroups, table and filter mode, FASTA and
+    FASTQ -- bit for bit the oracle's filter(s), statistics and table."""
+    monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
+    monkeypatch.setenv("BFCG_S1_WC", "2")
+    monkeypatch.setenv("BFCG_S1_WC_WGS", str([8, 16, 64][seed % 3]))
+    monkeypatch.setenv("BFCG_F1", "10")
+    prm, seq, qual, off, cuts, kw = _draw(53000 + seed, scale=12, b_range=(29, 34))
+    prm = dict(prm, k=[39, 47, 51, 52][seed % 4])
+    prm["l_pre"] = min(prm["l_pre"], 2 * prm["k"] - 2)
+    kw.pop("region_shift", None)
+    _check(gpu_lib, prm, seq, qual, off, cuts, kw)
+
+
 def test_write_combining_level1_was_exercised(gpu_lib, monkeypatch):
     """the family above is only worth its name if the kernel runs: one fixed draw, the process-wide launch counter before and after"""
     monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
@@ -230,6 +246,13 @@ def test_write_combining_level1_was_exercised(gpu_lib, monkeypatch):
     g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
     after = g.s1wc_launches(); g.close()
     assert after > before, (before, after)
+    monkeypatch.setenv("BFCG_F1", "10")  # and on 16-byte records (k = 51, 2^10 buckets)
+    prm, seq, qual, off, cuts, kw = _draw(53001, scale=12, b_range=(31, 32))
+    kw.pop("region_shift", None)
+    _check(gpu_lib, dict(prm, k=51, fm=1, l_pre=20), seq, qual, off, cuts, kw)
+    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
+    after2 = g.s1wc_launches(); g.close()
+    assert after2 > after, (after, after2)
 
 
 @pytest.mark.parametrize("seed", range(6))
