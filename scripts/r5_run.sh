@@ -115,3 +115,9 @@ if has wc16; then  # k_scatter1_wc on 16-byte records: its fuzz family + the c5 
     BFCG_S1_WC=$v timeout 900 python scripts/c4_run.py --batch-reads 16777216 --filter-mode 1 --k 51 --cov ${C5_COV:-8} > gpurun_out/r5_c5_wc$v.log 2>&1; echo "BFCG_S1_WC=$v"; tail -1 gpurun_out/r5_c5_wc$v.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('gpu_s','gpu_stage_ms','n_kmers','n_seen','partition')})"
   done
 fi
+if has prof2; then  # traces + PMC passes of the secondary workloads the bench line carries (so that their `traffic` is of this build): c2 and c4e
+  for w in ${PROF2_W:-c2 c4e}; do
+    PMC=1 STEPS=${PROF2_STEPS:-2} BENCH_ARGS="--workload $w" bash scripts/prof_round2.sh $w > gpurun_out/prof_$w.out 2>&1; tail -2 gpurun_out/prof_$w.out | cut -c1-200
+    ROUND=5 python tools/make_round_md.py gpurun_out/prof_$w $w > gpurun_out/round5_$w.md; cp profiles/round5_${w}_pmc.json gpurun_out/ 2>/dev/null
+  done
+fi
