@@ -233,26 +233,33 @@ def test_random_configuration_write_combining_level1_16_byte_records(gpu_lib, se
 
 
 def test_write_combining_level1_was_exercised(gpu_lib, monkeypatch):
-    """the family above is only worth its name if the kernel runs: one fixed draw, the process-wide launch counter before and after"""
+    """the families above are only worth their name if the kernel runs: one input that does not depend on the fuzz seed base, the process-wide
+    launch counter before and after -- 12-byte records (k = 33, 2^9 buckets), then 16-byte ones (k = 51, 2^10 buckets, filter mode)"""
     monkeypatch.setenv("BFCG_ONEPASS_MIN_TILES", "1")
     monkeypatch.setenv("BFCG_S1_WC", "2")
     monkeypatch.setenv("BFCG_S1_WC_WGS", "16")
+    rng = np.random.default_rng(52001)
+    n, L, G = 4000, 120, 60000
+    genome = rng.integers(0, 4, G + L)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    seq = np.concatenate([acgt[genome[p:p + L]] for p in rng.integers(0, G, n)]).astype(np.uint8)
+    qual = rng.integers(33, 75, len(seq)).astype(np.uint8)
+
+    def launches():
+        g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
+        v = g.s1wc_launches(); g.close()
+        return v
+
+    before = launches()
     monkeypatch.setenv("BFCG_F1", "9")
-    prm, seq, qual, off, cuts, kw = _draw(52001, scale=12, b_range=(30, 31))
-    kw.pop("region_shift", None)
-    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
-    before = g.s1wc_launches(); g.close()
-    _check(gpu_lib, dict(prm, k=33, fm=0, l_pre=20), seq, qual, off, cuts, kw)
-    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
-    after = g.s1wc_launches(); g.close()
-    assert after > before, (before, after)
-    monkeypatch.setenv("BFCG_F1", "10")  # and on 16-byte records (k = 51, 2^10 buckets)
-    prm, seq, qual, off, cuts, kw = _draw(53001, scale=12, b_range=(31, 32))
-    kw.pop("region_shift", None)
-    _check(gpu_lib, dict(prm, k=51, fm=1, l_pre=20), seq, qual, off, cuts, kw)
-    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
-    after2 = g.s1wc_launches(); g.close()
-    assert after2 > after, (after, after2)
+    _check(gpu_lib, dict(k=33, b=30, nh=4, l_pre=20, q=20, fm=0), seq, qual, off, [0, n // 3, n], {})
+    mid = launches()
+    assert mid > before, (before, mid)
+    monkeypatch.setenv("BFCG_F1", "10")
+    _check(gpu_lib, dict(k=51, b=31, nh=4, l_pre=20, q=20, fm=1), seq, qual, off, [0, n], {})
+    after = launches()
+    assert after > mid, (mid, after)
 
 
 @pytest.mark.parametrize("seed", range(6))
