@@ -76,6 +76,14 @@ def test_g42_reference_goldens(gpu_lib, g42, k, b, n_batches):
     g.close()
 
 
+def _wc_launches(gpu_lib):
+    """launches of k_scatter1_wc by this process so far (a process-wide counter behind any context)"""
+    g = gpu_lib.GpuCounter(33, 30, max_batch_pos=64)
+    v = g.s1wc_launches()
+    g.close()
+    return v
+
+
 @pytest.mark.parametrize("batch_reads,layout", [(786432, 0), (1572864, 0), (786432, 1)])
 def test_c2_full_read_set(gpu_lib, batch_reads, layout):
     """Config c2 as bench.py runs it (k=31, -b33, 3.07 M reads at 100x, 4 or 2 batches): equals the reference on the same reads."""
@@ -93,7 +101,9 @@ def test_c3_full_read_set(gpu_lib):
     k-mers hardly repeat so the context switches to STREAM mode, the table grows to 300 M keys): equals the reference."""
     e = BASE["c3"]
     rs = gen.ReadSet(**e["gen"])
+    wc0 = _wc_launches(gpu_lib)
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584)
+    assert g.s1wc_launches() > wc0, "c3's level 1 is expected to run k_scatter1_wc (round 5: write-combining buffers in LDS), not the tile kernel"
     ti = g.table_info()
     assert ti["segments"] and ti["seg_growths"] >= 1, ti  # 48 identity bits; the segments grow with the 300 M keys
     st = _check_against(g, e)
@@ -136,7 +146,9 @@ def test_c4_eighth_full_geometry(gpu_lib):
     (tests/golden/baseline.json[c4e]; the L1 digest of 470 M slots is left to the smaller shapes)."""
     e = BASE["c4e"]
     rs = gen.ReadSet(**e["gen"])
+    wc0 = _wc_launches(gpu_lib)
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 16_777_216)
+    assert g.s1wc_launches() > wc0, "c4's 2^10 level-1 buckets are expected to take k_scatter1_wc"
     _check_against(g, e, l1=False)
     assert g.partition_info() == dict(one_pass=True, level2_one_pass=True, replayed_batches=0)
     g.close()
@@ -158,8 +170,11 @@ def test_c5_eighth_full_geometry(gpu_lib):
     submit them: k-mer / high / seen totals and BOTH filters' popcount + FNV-1a equal the reference's (tests/golden/baseline.json[c5e])."""
     e = BASE["c5e"]
     rs = gen.ReadSet(**e["gen"])
+    wc0 = _wc_launches(gpu_lib)
     g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 16_777_216, filter_mode=1)
     assert g.mg_info()["rec_bytes"] == 16
+    assert g.s1wc_launches() > wc0, "c5's 16-byte records at 2^10 buckets are expected to take k_scatter1_wc"
+
     _check_against(g, e)
     assert g.stats()["slow_buckets"] == 0
     g.close()
