@@ -121,3 +121,14 @@ if has prof2; then  # traces + PMC passes of the secondary workloads the bench l
     ROUND=5 python tools/make_round_md.py gpurun_out/prof_$w $w > gpurun_out/round5_$w.md; cp profiles/round5_${w}_pmc.json gpurun_out/ 2>/dev/null
   done
 fi
+if has e2e512; then  # the boundary with the parser's AVX-512 pack (default) against the eight-positions-per-step one (BFC_INGEST_NO_AVX512=1): the whole c3 file through bfc-dropin, three runs each
+  python - <<PY
+import sys; sys.path.insert(0,'.')
+from bfc_amd import gen
+rs = gen.ReadSet(seed=3, G=248_000_000, cov=30)
+rs.fastq_parallel('/dev/shm/c3e.fq', 0, rs.n_reads, threads=32)
+PY
+  export BFC_GPU_TIMING=1
+  for v in 0 1 0 1 0 1; do echo "== BFC_INGEST_NO_AVX512=$v"; ( if [ $v = 1 ]; then export BFC_INGEST_NO_AVX512=1; fi; oracle/_ref/bfc-dropin -E -s 250m -k 33 -t64 /dev/shm/c3e.fq ) 2>&1 | grep -E "Real time|waited for the parser" | cut -c1-200; done > gpurun_out/r5_e2e_avx512.txt 2>&1
+  rm -f /dev/shm/c3e.fq; cat gpurun_out/r5_e2e_avx512.txt
+fi
