@@ -309,7 +309,9 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	{
 		const uint64_t tile = (uint64_t)bfcg_tile_of_rw(c->rw / 4), tile1 = (uint64_t)bfcg_tile1_of_rw(c->rw / 4);
 		const uint64_t tiles1 = (prm->max_batch_pos + tile1 - 1) / tile1, chunks1 = (tiles1 + BFCG_SCAN_CH - 1) / BFCG_SCAN_CH;
-		const uint64_t rows2 = c->recv_cap / tile + (uint64_t)nb1 * 8 + 1; // one ragged row per segment at most (one-pass level 1: 8 segments per bucket)
+		// one ragged row per segment at most (one-pass level 1: 8 segments per bucket); a one-pass level 1 hands over its slabs' FILL, dead records
+		// included -- up to the slabs' capacity, 9/8 of the batch (+ rounding) --, and the two-pass level 2 keeps a histogram row for every tile of that
+		const uint64_t rows2 = (c->recv_cap + c->recv_cap / 8) / tile + (uint64_t)nb1 * 16 + 8;
 		for (int b = 0; b < 2; ++b) {
 			HIPCKN(hipMalloc(&c->rows1[b], sizeof(uint32_t) * tiles1 * nb1));
 			HIPCKN(hipMalloc(&c->chunk1[b], sizeof(uint32_t) * chunks1 * nb1));
@@ -365,7 +367,7 @@ extern "C" bfcg_ctx_t *bfcg_create(const bfcg_params_t *prm)
 	c->recs2_n = c->recv_cap;
 	if (c->onepass_ok || c->mg_op2_ok || c->mg_slab_ok) { // level 2 in one pass: a slab per region, 9/8 of the mean of a full batch's positions + 64 records (k-mers are ~0.8 of the positions)
 		const char *e = getenv("BFCG_ONEPASS2");
-		const uint64_t cap2 = (B.max_kmers + B.max_kmers / 8) / (uint64_t)nfine + 64, n2 = cap2 * (uint64_t)nfine + bfcg_tile_of_rw(c->rw / 4);
+		const uint64_t cap2 = (B.max_kmers + B.max_kmers / 8) / (uint64_t)nfine + 64, n2 = cap2 * (uint64_t)nfine + 8192; // (a tile of slack: 8192 = the largest level-2 tile, KParams.l2_big)
 		if (!(e && atoi(e) == 0) && n2 < 0xffffffffULL) {
 			c->cap2 = (uint32_t)cap2; c->recs2_n = n2 > c->recv_cap ? n2 : c->recv_cap;
 			HIPCKN(hipMalloc(&c->cnt2, sizeof(uint32_t) * (size_t)nfine));
@@ -1338,6 +1340,11 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	if (op) {
 		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags + 4 * b; Bt.op_cap = c->op_cap;
 		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2;
+		{ // level 2 on tiles of 8192 records where a tile of 4096 would leave as runs of four (2^10 regions per bucket); BFCG_L2_BIG=0: never, =1: from 2^9 on
+			const char *e = getenv("BFCG_L2_BIG");
+			const int want = e ? atoi(e) : 2;
+			Pt.l2_big = c->rw == 12 && c->cap2 && want > 0 && Pt.F2 >= (want == 1 ? 9 : 10);
+		}
 		run_stage_a_onepass(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
 	} else run_stage_a(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
 	HIPCK(hipEventRecord(c->evA[b], sA));
@@ -1347,7 +1354,12 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	if (handover_begin(c, Bt, b, op && Bt.cap2, c->call_no) != 0) return -1;
 	if (op) {
 		uint32_t *sg = c->op_seg[b];
-		run_stage_b(Pt, Bt, Bt.recs1, sg, sg + 8 * nb1, 8 * nb1, 8, sg + 16 * nb1, sg + 24 * nb1 + 1, n_pos, c->st, c->evt[b]);
+		// the bound on level 2's rows is the slabs' CAPACITY, not the batch's positions: a segment is a slab's fill, and that holds the dead records of
+		// everything level 1 reserved and did not use -- per (workgroup, bucket) a group and a half and a padded buffer with k_scatter1_wc, whatever
+		// the batch's size.  With n_pos here, a batch of a few million positions in a context sized for 2^28 had more rows than workgroups, and the
+		// k-mers of the rows beyond the grid were lost without a word (tests/test_gpu_parity.py::test_small_batch_in_a_large_context).
+		// Surplus workgroups leave at once.
+		run_stage_b(Pt, Bt, Bt.recs1, sg, sg + 8 * nb1, 8 * nb1, 8, sg + 16 * nb1, sg + 24 * nb1 + 1, (uint64_t)8 * nb1 * c->op_cap, c->st, c->evt[b]);
 	} else
 	run_stage_b(Pt, Bt, Bt.recs1, Bt.start1, Bt.start1 + 1, nb1, 1, Bt.row_base, Bt.start1, n_pos, c->st, c->evt[b]);
 	if (handover_end(c, Bt, b) != 0) return -1;

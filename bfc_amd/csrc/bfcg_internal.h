@@ -55,6 +55,8 @@ struct KParams {
 	int b3;                     // the default path's bloom insert runs k_bloom3: a list entry in LDS is 10 bytes (bloom_lds_bytes), and batches without `dedupe` take that kernel
 	int b3_warm;                // this batch goes into a warm filter: fs_cap / list_cap are the SHORT list's (four workgroups of k_bloom3 per CU instead of three)
 	int b3fm;                   // filter mode (`bfc -1`) on 16-byte records whose bloom address is a bit field of their words: k_bloom3fm (list_cap: its 10-byte entries)
+	int l2_big;                 // level 2 of this batch works on tiles of 8192 records with 1024 threads (round 6: 2^10 regions per bucket -- config c4's -b37 --, 12-byte
+	                            // records, one-pass partition of a single GPU): a (tile, region) run is 8 records = 96 bytes as at c3's 2^9, not 4 = 48
 	int b3_cold;                // this batch goes into a filter that is still filling up: k_bloom3<.., COLD> -- the list ordered by (block, file index), one lane walks a
 	                            // block's k-mers as bfc_bf_insert would; list_cap is the cold list's (12-byte entries, no first-setter table beside them)
 };

@@ -2145,6 +2145,12 @@ template <int RW> struct S1 { static constexpr int BT = 512, TILE = RW == 3 ? 40
 static_assert(S1<3>::TILE == 4096 && S1<4>::TILE == 3072 && S1<5>::TILE == 3072, "bfcg_tile1_of_rw (bfcg_internal.h) sizes the host's buffers");
 #define TILE2 BFCG_TILE2
 #define BT2 512
+// Round 6: level 2 at 2^10 regions per bucket (config c4's -b37).  A tile of 4096 records spread over 1024 regions leaves as runs of FOUR records --
+// 48 bytes, a sector and a half -- and the kernel that streams at 4.8-5.0 TB/s at c3's 2^9 regions (runs of eight = 96 bytes = three whole sectors) moved
+// c4e's records at 3.5 (profiles/round5_c4e.md: WRITE_SIZE 1.09 x the records, so the bytes were right and the rate was not).  Tiles of 8192 records
+// with 1024 threads restore the run length: 96 KiB of stage + 8 KiB of counters, one workgroup per CU.
+#define TILE2_BIG 8192
+#define BT2_BIG 1024
 
 // BFCG_DEBUG_SYNC=1: wait behind every stage's launches and say which one the device failed in (a memory fault names no kernel)
 static void dbg_sync(hipStream_t st, const char *what)
@@ -2228,7 +2234,7 @@ static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const ui
 	}
 	dbg_sync(st, "k_scatter1 (one pass)");
 	uint32_t *sg = B.op_seg;
-	hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, st, P, B.op_cursor, B.op_cap, B.op_flags, T2, sg, sg + 8 * nb1, sg + 16 * nb1, sg + 24 * nb1 + 1);
+	hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, st, P, B.op_cursor, B.op_cap, B.op_flags, (RW == 3 && P.l2_big) ? TILE2_BIG : T2, sg, sg + 8 * nb1, sg + 16 * nb1, sg + 24 * nb1 + 1);
 	dbg_sync(st, "k_seg_setup");
 	if (ev) hipEventRecord(ev[2], st);
 }
@@ -2297,7 +2303,18 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		constexpr int T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
 		// rows of level 2 <= records/T2 + one ragged row per segment; surplus blocks exit at once
 		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
-		if (B.cap2) { // one pass: region slabs and cursors
+		bool big_done = false;
+		if constexpr (RW == 3) {
+			if (B.cap2 && P.l2_big && scatter2_fast(P)) { // (the segments' rows were counted in tiles of TILE2_BIG by this batch's k_seg_setup)
+				const unsigned g2b = (unsigned)(((n_rec_bound / TILE2_BIG + n_seg + 1 + 7) / 8) * 8);
+				hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
+				hipLaunchKernelGGL((k_scatter2<W, RW, TILE2_BIG, BT2_BIG, true, true>), dim3(g2b), dim3(BT2_BIG), (size_t)TILE2_BIG * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+				                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
+				big_done = true;
+			}
+		}
+		if (big_done) ;
+		else if (B.cap2) { // one pass: region slabs and cursors
 			hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
 			if ((RW == 3 || RW == 4) && scatter2_fast(P)) // (round 5: 16-byte records too -- their first word holds the same low bits of y0)
 				hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true, RW == 3 || RW == 4>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
@@ -2437,6 +2454,7 @@ template <typename W, int RW> static hipError_t set_attr_t(int lds)
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	if (RW == 3 || RW == 4) { e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, T2, BT2, true, RW == 3 || RW == 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T2 * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e; }
+	if constexpr (RW == 3) { e = hipFuncSetAttribute((const void *)k_scatter2<W, RW, TILE2_BIG, BT2_BIG, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE2_BIG * (RW * 4) + 8 * BFCG_MAXB); if (e != hipSuccess) return e; }
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 1024, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_bloom<W, RW, 512, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e;

@@ -83,7 +83,7 @@ struct bfcg_group {
 	uint32_t slab_cap; uint64_t blk; // records per slab; per block of nb_loc x 8 slabs (what one rank sends to one destination)
 	size_t row_words;           // a rank's row of sizes: up to 8 x nb1 words, then its failure word, then its overflow word
 	uint64_t kmer_limit;        // k-mers of a global batch one rank's regions take at full speed
-	int lazy_ok, lazy;          // the sizes reach the host AFTER exchange and stage B are enqueued: possible at all (slab mode, every rank in this process); for the current batch
+	int lazy_ok, lazy;          // the sizes reach the host AFTER exchange and stage B are enqueued: possible at all (slab mode, every context able to take its stage B from rows on the device -- in-process AND multi-process groups); for the current batch
 	uint64_t n_lazy;            // global batches taken that way
 	std::vector<rank_t> r;
 	uint32_t *all_counts;       // [n_ranks][nb1 + 1], host (pinned): every rank's bucket sizes of the current batch and its failure word
@@ -179,6 +179,9 @@ static int process_in_groups_slabs(bfcg_group_t *g, rank_t &R, const uint8_t *re
 // The lazy protocol's first group of sources: [0, s1) with s1 the most sources whose BOUND fits what this rank's regions take at full speed -- a source
 // sends an owner at most its share's positions / N (k-mers <= positions; the hash spreads them evenly: + 5 %).  `pos[s]`: the shares' positions
 // where this process knows them (all ranks local), else every share is taken at the contexts' capacity.
+// A RANK-LOCAL decision: s1 only says in how many launches THIS owner applies what it received -- every source's records are applied
+// either way, in file order by their indices -- so the processes of a multi-process group need not agree on it (the warm factor is per context
+// and may differ between them); what they must decide alike is whether the batch is lazy at all: lazy_possible, which reads nothing rank-local.
 static int lazy_first_group(bfcg_group_t *g, rank_t &R)
 {
 	const int N = g->n_ranks;

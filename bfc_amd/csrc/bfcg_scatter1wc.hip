@@ -455,13 +455,21 @@ namespace bfcg {
 	X(uint64_t, 3, 3, 10, 1024, 4, 33) X(uint64_t, 3, 3, 10, 1024, 4, 0) X(uint32_t, 3, 3, 10, 1024, 4, 0) \
 	X(uint64_t, 4, 3, 10, 1024, 3, 0) /* 16-byte records (config c5: k = 51, -b37): 2^10 buffers of 8 x 16 bytes = 128 KiB, three positions per thread and round */
 
+// A device or driver that refuses the kernels' dynamic LDS (up to 128 KiB + ~27 KiB static) loses k_scatter1_wc, not the library: scatter1_wc_plan
+// then says no and level 1 runs the tile kernel (this used to fail every bfcg_create, whatever the geometry).
+static int g_wc_refused = 0;
 hipError_t set_scatter1wc_lds_attr(void)
 {
 	hipError_t e = hipSuccess;
 #define X(W, R, C, N, B, S, K) if (e == hipSuccess) e = attr_wc<W, R, C, N, B, S, K>();
 	WC_VARIANTS(X)
 #undef X
-	return e;
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		if (!__atomic_exchange_n(&g_wc_refused, 1, __ATOMIC_RELAXED))
+			fprintf(stderr, "[W::bfcg] k_scatter1_wc unavailable on this device (%s for its LDS buffers): level 1 takes the tile kernel\n", hipGetErrorString(e));
+	}
+	return hipSuccess;
 }
 
 // Whether a one-pass stage A of this geometry can run k_scatter1_wc, and how: 12-byte records packed from halves with the level-1 bucket a bit
@@ -472,7 +480,7 @@ bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int rw, int64_t n_pos
 {
 	const char *e = getenv("BFCG_S1_WC");
 	const int mode = e ? atoi(e) : 1;
-	if (mode == 0) return false;
+	if (mode == 0 || __atomic_load_n(&g_wc_refused, __ATOMIC_RELAXED)) return false;
 	if (P.F1 < 8 || P.F1 > 10) return false;
 	if ((OP.cap & 3u) || (OP.own_delta & 3u)) return false;
 	// 16-byte records: the one geometry that is instantiated (config c5's: k > 32, 2^10 buckets); the bucket must be a bit field of y0's low word
@@ -497,6 +505,19 @@ bool scatter1_wc_plan(const KParams &P, const OnePass &OP, int rw, int64_t n_pos
 	if (ce && atoi(ce) > 0) { G = (uint32_t)atoi(ce) >> capl; if (G < 1) G = 1; if (G > 4) G = 4; }
 	else while (G > 1 && waste(G) > OP.cap) G >>= 1;
 	if (mode != 2 && waste(G) > OP.cap) return false;
+	// ... and against the BATCH (round 6): what a workgroup leaves unused does not shrink with the batch, so a batch of a few million
+	// positions in a context sized for 2^28 filled its slabs with two or three dead records per live one for level 2 to read and skip.  A slab's
+	// dead records stay below a quarter of the positions it expects: smaller groups first, then fewer workgroups (each then fills several chunks
+	// per bucket); a batch too small even for eight workgroups of single chunks takes the tile kernel.
+	if (mode != 2 && !(ce && atoi(ce) > 0)) {
+		const uint64_t live = (uint64_t)n_pos / ((uint64_t)8 << P.F1);
+		auto dead = [&](uint32_t gg, unsigned wg) { return (uint64_t)(wg / 8 + 1) * (gg * cap_rec * 3 / 2 + cap_rec); };
+		while (dead(G, g) * 4 > live) {
+			if (G > 1) G >>= 1;
+			else if (g > 8) g = (g / 2 + 7) & ~7u;
+			else return false;
+		}
+	}
 	pl->rw = rw; pl->bt = bt; pl->spt = spt; pl->G = G; pl->grid = g;
 	return true;
 }

@@ -131,6 +131,14 @@ uint64_t bfcgen_fnv1a64(const uint8_t *p, uint64_t n)
 	return h;
 }
 
+/* the same, continued from h (a stream hashed piece by piece; start with 0xcbf29ce484222325) */
+uint64_t bfcgen_fnv1a64_from(uint64_t h, const uint8_t *p, uint64_t n)
+{
+	uint64_t i;
+	for (i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ULL;
+	return h;
+}
+
 #ifdef BFCGEN_MAIN
 int main(int argc, char **argv)
 {

@@ -37,6 +37,8 @@ def _L():
         L.bfcgen_popcount.argtypes = [C.c_void_p, C.c_uint64]
         L.bfcgen_fnv1a64.restype = C.c_uint64
         L.bfcgen_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
+        L.bfcgen_fnv1a64_from.restype = C.c_uint64
+        L.bfcgen_fnv1a64_from.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 

@@ -178,7 +178,7 @@ void bfcg_group_destroy(bfcg_group_t *g);
 int bfcg_group_info(bfcg_group_t *g, int out[6]);     /* n_ranks, n_local, transport in use (1 RCCL, 2 peer copies), bytes per record, 2^F1, first rank */
 bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i);  /* local rank i's context (statistics, exports of its slice); owned by the group */
 int bfcg_group_slab_mode(bfcg_group_t *g);           /* 1: stage A runs in one pass into slabs; 0: two passes (never possible, switched off, or a slab overflowed in this run) */
-uint64_t bfcg_group_lazy_batches(bfcg_group_t *g);   /* global batches since creation whose exchange and stage B were enqueued before the host saw any size (slab mode, all ranks in this process) */
+uint64_t bfcg_group_lazy_batches(bfcg_group_t *g);   /* global batches since creation whose exchange and stage B were enqueued before the host saw any size (slab mode; in-process and multi-process groups alike -- the processes agree on it through the set-up's all-gather, bit 1 of its first word) */
 int bfcg_group_reset(bfcg_group_t *g);
 /* one global batch: local rank i contributes the stream d_seq[i] / d_qual[i] (on ITS device) of n_pos[i] positions (0 = nothing) */
 int bfcg_group_count_batch_dev(bfcg_group_t *g, const uint8_t *const *d_seq, const uint8_t *const *d_qual, const uint64_t *n_pos);

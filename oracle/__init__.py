@@ -126,6 +126,8 @@ def ref_ec():
         R.bfc_ch_destroy.argtypes = [C.c_void_p]
         R.ref_kcov.restype = None
         R.ref_kcov.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p]
+        R.ref_trim_batch.restype = None
+        R.ref_trim_batch.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         _ref_ec = R
     return _ref_ec
 
@@ -160,12 +162,25 @@ def ref():
         R.bfc_ch_count.argtypes = [C.c_void_p]
         R.bfc_ch_hist.argtypes = [C.c_void_p, u64p, u64p]
         R.ref_ingest_digest.argtypes = [C.c_char_p, C.c_int, u64p]
+        R.ref_count_batch_blocks.restype = C.c_uint64
+        R.ref_count_batch_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_int]
         R.bfc_ch_dump.argtypes = [C.c_void_p, C.c_char_p]
         R.bfc_ch_restore.restype = C.c_void_p
         R.bfc_ch_restore.argtypes = [C.c_char_p]
         R.bfc_ch_destroy.argtypes = [C.c_void_p]
         _ref = R
     return _ref
+
+
+def ref_trim(bf_ptr, k, seq, off, min_frac=0.9, n_threads=1):
+    """The reference's own trim pass (worker_ec -> max_streak + keep rule, correct.c:478-497,557-567, reached through ref_shim_ec.c) on a
+    bfc_bf_t* of either reference library.  Returns (start int32[n], end int32[n]); start -1 = read dropped."""
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    n = len(off) - 1
+    st = np.empty(n, dtype=np.int32); en = np.empty(n, dtype=np.int32)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    ref_ec().ref_trim_batch(bf_ptr, k, C.c_float(min_frac), seq.ctypes.data, _ptr(off, u64p), n, int(n_threads), st.ctypes.data, en.ctypes.data)
+    return st, en
 
 
 # ----------------------------------------------------------------------------- convenience
@@ -210,6 +225,14 @@ class Counter:
             n = self.L.ref_count_batch(self.st, self.k, self.q, self.n_hashes, seq.ctypes.data,
                                        qual.ctypes.data if qual is not None else None, _ptr(off, u64p), n_reads, _ptr(tr, u64p))
         return tr if trace else n
+
+    def count_blocks(self, seq, qual, off, n_parts):
+        """impl='ref' only: the same answers as count() from n_parts threads, each owning the bloom blocks of one residue class
+        (ref_shim.c: ref_count_batch_blocks -- every block still sees its k-mers in file order).  The table's layout is not `bfc -t1`'s."""
+        assert self.impl == "ref"
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        return self.L.ref_count_batch_blocks(self.st, self.k, self.q, self.n_hashes, seq.ctypes.data,
+                                             qual.ctypes.data if qual is not None else None, _ptr(off, u64p), len(off) - 1, int(n_parts))
 
     def stats(self):
         out = np.zeros(4, dtype=np.uint64)

@@ -103,3 +103,65 @@ int ref_ingest_digest(const char *fn, int chunk_size, uint64_t out[7])
 	bseq_close(fp);
 	return 0;
 }
+
+/* The same harness spread over threads WITHOUT changing its answers (round 6: the goldens of the eighth-of-human read sets took 2-2.5 h
+ * of one core each).  What a k-mer does depends only on the earlier k-mers of ITS OWN 64-byte bloom block (bbf.c:27-31: every bit it
+ * tests and sets lies in block `hash & (2^(n_shift-9) - 1)`), the second filter's block is the same one (same hash, count.c:67-68), and
+ * table counts commute (saturating adds of htab.c:74-79 under the sub-table's lock).  So part p of n_parts walks ALL reads in file order,
+ * hashes every k-mer, and calls the reference's bfc_bf_insert / bfc_ch_insert for the k-mers whose block id is p modulo n_parts only:
+ * each block sees exactly its k-mers in file order, i.e. what `bfc -t1` does to it.  Filters, totals and the layout-free table
+ * digest (L1) are therefore those of the sequential run -- tests/golden/make_baseline_goldens.py re-derives the committed sequential
+ * c5e entry (bf / bf_high checksums, totals) through this function before it adds anything to it.  The table's LAYOUT (the -d dump
+ * bytes) is insertion-order dependent and not reproduced by this variant. */
+void kt_for(int n_threads, void (*func)(void*, long, int), void *data, long n);
+typedef struct {
+	ref_state_t *st; int k, q, n_hashes, n_parts; const uint8_t *seq, *qual; const uint64_t *off; uint64_t n_reads, base;
+	uint64_t (*acc)[4];
+} ref_mt_t;
+static void ref_mt_worker(void *data, long part, int tid)
+{
+	ref_mt_t *m = (ref_mt_t*)data;
+	ref_state_t *st = m->st;
+	const int k = m->k;
+	const uint64_t mask = (1ULL << k) - 1, bmask = (1ULL << (st->bf->n_shift - 9)) - 1;
+	uint64_t r, g = m->base, nk = 0, nh = 0, ns = 0, hx = 0;
+	for (r = 0; r < m->n_reads; ++r) {
+		const char *seq = (const char*)m->seq + m->off[r], *qual = m->qual ? (const char*)m->qual + m->off[r] : 0;
+		int i, l = 0, len = (int)(m->off[r+1] - m->off[r]);
+		bfc_kmer_t x = bfc_kmer_null;
+		uint64_t qmer = 0;
+		for (i = 0; i < len; ++i) {
+			int c = seq_nt6_table[(uint8_t)seq[i]] - 1;
+			if (c < 4) {
+				bfc_kmer_append(k, x.x, c);
+				qmer = (qmer << 1 | (qual == 0 || qual[i] - 33 >= m->q)) & mask;
+				if (++l >= k) {
+					uint64_t y[2], hash = bfc_kmer_hash(k, x.x, y);
+					++g;
+					if ((long)((hash & bmask) % (uint64_t)m->n_parts) == part) {
+						int is_high = (qmer == mask), seen = (bfc_bf_insert(st->bf, hash) == m->n_hashes);
+						++nk; nh += is_high; ns += seen; hx ^= hash * (g | 1);
+						if (seen) {
+							if (st->ch) bfc_ch_insert(st->ch, y, is_high, 1);
+							else if (st->bf_high) bfc_bf_insert(st->bf_high, hash);
+						}
+					}
+				}
+			} else l = 0, qmer = 0, x = bfc_kmer_null;
+		}
+	}
+	m->acc[part][0] = nk; m->acc[part][1] = nh; m->acc[part][2] = ns; m->acc[part][3] = hx;
+}
+uint64_t ref_count_batch_blocks(ref_state_t *st, int k, int q, int n_hashes, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint64_t n_reads, int n_parts)
+{
+	ref_mt_t m;
+	uint64_t n = 0;
+	int p;
+	m.st = st; m.k = k; m.q = q; m.n_hashes = n_hashes; m.n_parts = n_parts; m.seq = seq; m.qual = qual; m.off = off; m.n_reads = n_reads; m.base = st->n_kmers;
+	m.acc = (uint64_t(*)[4])calloc((size_t)n_parts, sizeof(*m.acc));
+	kt_for(n_parts, ref_mt_worker, &m, n_parts);
+	for (p = 0; p < n_parts; ++p) { n += m.acc[p][0]; st->n_high += m.acc[p][1]; st->n_seen += m.acc[p][2]; st->hash_xor ^= m.acc[p][3]; }
+	st->n_kmers += n;
+	free(m.acc);
+	return n;
+}

@@ -46,7 +46,17 @@ CASES = {
     # an EIGHTH of c5 (round 5): the same 77.5 M reads at c5's parameters, `-s 3g -k51 -1` => -b37, two 16 GiB filters (count.c:67-68), 16-byte records;
     # 7.7 G k-mers.  ~2 h of one core and ~40 GB here.  bench.py's secondary `c5e` and tests/test_gpu_baseline_shapes.py hold the GPU path to it
     "c5e": dict(gen=dict(seed=4, G=387_500_000, cov=30.0), k=51, b=37, fm=1),
+    # round 6 -- the two below are made by the block-partitioned harness (oracle/ref_shim.c: ref_count_batch_blocks, MT threads; the same answers as
+    # the sequential one: tests/test_oracle.py::test_block_partitioned_harness_equals_the_sequential_one, and `same_as` re-derives a committed
+    # sequential entry at full size before anything is added to it)
+    # config c5's QUERY pass: c5e's count again (must reproduce the committed c5e entry), then the reference's own trim pass (worker_ec ->
+    # max_streak + keep rule, correct.c:478-497,557-567, via oracle/ref_shim_ec.c) over the same 77.5 M reads against the reference's bf_high
+    "c5e_trim": dict(gen=dict(seed=4, G=387_500_000, cov=30.0), k=51, b=37, fm=1, mt=True, same_as="c5e", trim=True),
+    # the reference's one published command line, `bfc -s 3g -k55` (tex/README.md:26): c4e's reads at k=55, -b37, TABLE mode -- 2^24 sub-tables
+    # (htab.c:19-34), the lossy key of k >= 38 (htab.c:45-58), 20-byte records on the GPU
+    "c4e_k55": dict(gen=dict(seed=4, G=387_500_000, cov=30.0), k=55, b=37, fm=0, mt=True),
 }
+MT = int(os.environ.get("GOLDEN_THREADS", "6"))
 
 
 def run(name):
@@ -57,16 +67,41 @@ def run(name):
     CH = 2_000_000
     for r0 in range(0, rs.n_reads, CH):
         seq, qual, off = rs.reads(r0, min(rs.n_reads, r0 + CH))
-        c.count(seq, qual, off)
+        if cs.get("mt"):
+            c.count_blocks(seq, qual, off, MT)
+        else:
+            c.count(seq, qual, off)
         print("[%s] %d / %d reads  %.0fs" % (name, min(rs.n_reads, r0 + CH), rs.n_reads, time.time() - t0), file=sys.stderr, flush=True)
     st = c.stats()
     pop, fnv = c.bloom_checksums()
     e = dict(name=name, gen=cs["gen"], k=cs["k"], b=cs["b"], filter_mode=cs["fm"], n_reads=rs.n_reads,
              n_kmers=st["n_kmers"], n_high=st["n_high"], n_seen=st["n_seen"], hash_xor="%016x" % st["hash_xor"],
              bf_popcount=pop, bf_fnv1a64="%016x" % fnv)
+    if cs.get("mt"):
+        e["harness"] = "ref_count_batch_blocks, %d threads" % MT
     if cs["fm"]:
         pop2, fnv2 = c.bloom_checksums(high=True)
         e.update(bf_high_popcount=pop2, bf_high_fnv1a64="%016x" % fnv2)
+    if cs.get("same_as"):  # the block-partitioned harness at full size against the committed SEQUENTIAL entry of the same configuration
+        old = {x["name"]: x for x in json.load(open(OUT))}[cs["same_as"]]
+        for f in ("n_reads", "n_kmers", "n_high", "n_seen", "hash_xor", "bf_popcount", "bf_fnv1a64", "bf_high_popcount", "bf_high_fnv1a64"):
+            assert e[f] == old[f], (f, e[f], old[f])
+        e["reproduces"] = cs["same_as"]
+        print("[%s] reproduces the sequential entry %s  %.0fs" % (name, cs["same_as"], time.time() - t0), file=sys.stderr, flush=True)
+    if cs.get("trim"):
+        # (start, end) per read as the reference's worker_ec leaves them, -1 / -1 for a dropped read; FNV-1a/64 over the int32 pairs in read order
+        kept = bases = 0
+        h = 0xcbf29ce484222325
+        G = gen._L()
+        for r0 in range(0, rs.n_reads, CH):
+            seq, qual, off = rs.reads(r0, min(rs.n_reads, r0 + CH))
+            st_, en_ = oracle.ref_trim(c._bf(True), cs["k"], seq, off, 0.9, MT)
+            m = st_ >= 0
+            kept += int(m.sum()); bases += int((en_[m] - st_[m]).sum())
+            pairs = np.ascontiguousarray(np.stack([st_, en_], axis=1), dtype="<i4")
+            h = int(G.bfcgen_fnv1a64_from(h, pairs.ctypes.data, pairs.nbytes))
+            print("[%s] trim %d / %d reads  %.0fs" % (name, min(rs.n_reads, r0 + CH), rs.n_reads, time.time() - t0), file=sys.stderr, flush=True)
+        e.update(min_frac=0.9, trim_reads_kept=kept, trim_bases_kept=bases, trim_windows_fnv1a64="%016x" % h, trim_queries=e["n_kmers"])
     else:
         mode, cnt, high = c.table_hist()
         e.update(distinct=c.table_count(), hist_mode=int(mode), cnt=[int(v) for v in cnt], high=[int(v) for v in high])

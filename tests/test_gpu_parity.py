@@ -406,3 +406,42 @@ def test_filter_mode_block_walk_heavy_regions(gpu_lib, monkeypatch):
         assert np.array_equal(g.bloom_bytes(0), oc.bloom_bytes()) and np.array_equal(g.bloom_bytes(1), oc.bloom_bytes(True))
         assert g.stats()["n_seen"] == oc.stats()["n_seen"]
         g.close(); oc.close()
+
+
+@pytest.mark.parametrize("wc", ["default", "forced"])
+@pytest.mark.parametrize("n_reads", [30_000, 58_000])
+def test_small_batch_in_a_large_context(gpu_lib, g42, monkeypatch, wc, n_reads):
+    """a batch of a few million positions (just above the one-pass partition's minimum, nb1 * 8 * 1024) in a context sized for
+    2^28, on the FULL persistent grid of k_scatter1_wc.  What the 512 workgroups reserve and do not fill is dead records in the slabs -- more of them
+    than live ones here --, level 2's rows follow the slabs' fill, and a grid sized by the batch's positions left the last rows' k-mers uncounted.
+    `forced` (BFCG_S1_WC=2) keeps the full grid and groups of four chunks whatever the batch's size (the plan's own scaling by the batch is off):
+    the case as it was found; `default`: the plan shrinks groups and grid for such a batch.  Counts, bitmap and table equal the oracle's, and the
+    two-pass partition's (count.c:72-89, bbf.c:25-45, htab.c:60-82)."""
+    rs, (seq, qual, off) = g42
+    k, b = 33, 35
+    seq, qual, off = seq[:n_reads * rs.L], qual[:n_reads * rs.L], off[:n_reads + 1]
+    if wc == "forced":
+        monkeypatch.setenv("BFCG_S1_WC", "2")
+    s, q = gpu_lib.to_stream(seq, off), gpu_lib.to_stream(qual, off)
+    g = gpu_lib.GpuCounter(k, b, max_batch_pos=1 << 28)
+    w0 = g.s1wc_launches()
+    g.count_host(s, q)
+    st = g.stats()
+    assert g.partition_info()["one_pass"] and g.partition_info()["replayed_batches"] == 0
+    assert g.s1wc_launches() > w0, "the batch did not take k_scatter1_wc"
+    oc = oracle.Counter(k, b)
+    oc.count(seq, qual, off)
+    ost = oc.stats()
+    assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (ost["n_kmers"], ost["n_high"], ost["n_seen"])
+    bits = g.bloom_bytes()
+    assert gen.bitmap_checksums(bits) == oc.bloom_checksums()
+    del bits
+    sizes, slots = g.export_table().export_sorted()
+    assert oracle.l1_digest(sizes, slots) == oracle.l1_digest(*oc.export())
+    g.close(); oc.close()
+    monkeypatch.setenv("BFCG_ONEPASS", "0")
+    g2 = gpu_lib.GpuCounter(k, b, max_batch_pos=1 << 28)
+    g2.count_host(s, q)
+    st2 = g2.stats()
+    assert (st2["n_kmers"], st2["n_seen"], st2["n_keys"]) == (st["n_kmers"], st["n_seen"], st["n_keys"])
+    g2.close()

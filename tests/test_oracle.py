@@ -251,3 +251,56 @@ def test_config_c1_oracle_equals_reference_golden(tmp_path):
     c.dump(dump)
     assert oracle.md5_file(dump) == e["ref_dump_md5"]
     c.close()
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built")
+@pytest.mark.parametrize("k,b,fm", [(31, 24, 0), (51, 26, 1), (55, 24, 0)])
+def test_block_partitioned_harness_equals_the_sequential_one(g1, k, b, fm):
+    """ref_count_batch_blocks (oracle/ref_shim.c: n threads, thread p owns the bloom blocks of residue class p and walks all reads in file
+    order) gives what the sequential harness (= `bfc -t1`) gives: totals, both filters byte for byte, the table as sorted slot lists.  The
+    eighth-of-human goldens of round 6 (c5e_trim, c4e_k55) are made with it."""
+    rs, (seq, qual, off) = g1
+    a = oracle.Counter(k, b, filter_mode=fm, impl="ref")
+    a.count(seq, qual, off)
+    for parts in (3, 8):
+        m = oracle.Counter(k, b, filter_mode=fm, impl="ref")
+        h = rs.n_reads // 3  # two calls: the running k-mer index of hash_xor carries over
+        m.count_blocks(seq[:int(off[h])], qual[:int(off[h])], off[:h + 1], parts)
+        m.count_blocks(seq[int(off[h]):], qual[int(off[h]):], off[h:] - off[h], parts)
+        assert m.stats() == a.stats()
+        assert np.array_equal(m.bloom_view(), a.bloom_view())
+        if fm:
+            assert np.array_equal(m.bloom_view(True), a.bloom_view(True))
+        else:
+            (sa, la), (sm, lm) = a.export(), m.export()
+            assert oracle.l1_digest(sa, la) == oracle.l1_digest(sm, lm)
+        m.close()
+    a.close()
+
+
+@pytest.mark.skipif(not (oracle.have_ref() and oracle.have_ref_ec()), reason="oracle/_ref not built")
+def test_reference_trim_pass_through_worker_ec(g1):
+    """oracle.ref_trim = the reference's worker_ec (max_streak + keep rule, correct.c:478-497,557-567) driven by its own kt_for: the windows
+    equal the restatement's, their count and bases the reference binary's (`bfc -1 -k51 -b26 -t1`), on one thread and on four; a read of
+    300 bases takes the path that asks max_streak for the start."""
+    rs, (seq, qual, off) = g1
+    L = oracle.lib()
+    r = oracle.Counter(51, 26, filter_mode=1, impl="ref")
+    r.count(seq, qual, off)
+    o = oracle.Counter(51, 26, filter_mode=1)
+    o.count(seq, qual, off)
+    obf = L.orc_state_bf_high(o.st)
+    long_seq = np.concatenate([seq[:150], seq[:150]])
+    seq2 = np.concatenate([seq, long_seq]); off2 = np.concatenate([off, [off[-1] + 300]]).astype(np.uint64)
+    exp_s, exp_e = [], []
+    for i in range(len(off2) - 1):
+        s = seq2[int(off2[i]):int(off2[i + 1])]
+        mx = L.orc_max_streak(51, obf, s.ctypes.data, len(s))
+        a, b = C.c_int(), C.c_int()
+        kept = L.orc_trim_decide(mx, 51, len(s), 0.9, C.byref(a), C.byref(b))
+        exp_s.append(a.value if kept else -1); exp_e.append(b.value if kept else -1)
+    for nt in (1, 4):
+        st, en = oracle.ref_trim(r._bf(True), 51, seq2, off2, 0.9, nt)
+        assert st.tolist() == exp_s and en.tolist() == exp_e
+    assert (int((st[:-1] >= 0).sum()), int((en[:-1] - st[:-1])[st[:-1] >= 0].sum())) == (1763, 259433)
+    r.close(); o.close()
