@@ -12,8 +12,10 @@
 
 /* ------------------------------------------------------------------ line reader over zlib */
 
+struct psrc_s;
 typedef struct {
 	gzFile fp;
+	struct psrc_s *mem; uint64_t mem_pos; /* pipe input (psrc_t below): the bytes come from the pipe reader's ring, from stream offset mem_pos on, not from gzread */
 	uint8_t *buf; int begin, end, eof;
 	uint64_t total;  /* bytes delivered by gzread so far */
 	int first_piece; /* size of the next gzread if it is not RD_PIECE */
@@ -26,10 +28,18 @@ typedef struct {
 #define RD_BUF (1 << 20)
 #define RD_PIECE 16384
 
+static inline int psrc_take(struct psrc_s *ps, uint64_t pos, uint8_t *dst, int want);
 static inline int rd_fill(reader_t *r)
 {
 	if (r->eof) return 0;
 	r->begin = 0; r->end = 0;
+	if (r->mem) { /* what gzread's loop below delivers for plain text: RD_BUF bytes, fewer only at the end of the input */
+		r->end = psrc_take(r->mem, r->mem_pos, r->buf, RD_BUF - RD_BUF % RD_PIECE);
+		r->mem_pos += (uint64_t)r->end;
+		if (r->end < RD_BUF - RD_BUF % RD_PIECE) r->eof = 1;
+		r->total += (uint64_t)r->end;
+		return r->end;
+	}
 	/* gzread in kseq's own pieces (kseq.h:72-74,104-106: 16384 bytes a call, a short or failed read ends the input): what zlib hands out
 	 * before it reports a damaged gzip stream depends on the sizes it is asked for */
 	while (r->end + RD_PIECE <= RD_BUF) {
@@ -329,8 +339,124 @@ static void *fq_pack(void *arg)
 	return 0;
 }
 
+/* ------------------------------------------------------------------ pipe input (round 6): stdin, a FIFO, `<(seqtk mergepe ...)` -- what the reference's
+ * published command line feeds it (tex/README.md:26; bseq.c:33-50 opens whatever it is given with gzdopen / gzopen).  A pipe cannot be mapped, but the
+ * chained walks above need memory, not a mapping: a reader thread drains the pipe into a RING whose cap bytes are mapped twice back to back (one
+ * memfd, two mappings), so any window of up to cap bytes is contiguous in the address space wherever it starts, nothing is ever moved, and the
+ * reader's read() lands directly behind the last byte.  The parser's threads walk the window while the reader fills the ring behind it.  The
+ * serial parser takes its bytes from the same ring (reader_t.mem) when the input is not strict 4-line FASTQ: a pipe cannot be re-read. */
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <errno.h>
+typedef struct psrc_s {
+	int fd, own_fd; uint8_t *ring; uint64_t cap;
+	uint64_t head, tail;   /* stream offsets: [head, tail) is in the ring, byte o at ring[o % cap] (and again cap further on) */
+	int eof, quit, on;
+	pthread_t th; pthread_mutex_t mu; pthread_cond_t cv_data, cv_space;
+} psrc_t;
+
+static void *psrc_reader(void *arg)
+{
+	psrc_t *p = (psrc_t*)arg;
+	for (;;) {
+		uint64_t t, space;
+		ssize_t n;
+		pthread_mutex_lock(&p->mu);
+		while (p->tail - p->head == p->cap && !p->quit) pthread_cond_wait(&p->cv_space, &p->mu);
+		if (p->quit) { pthread_mutex_unlock(&p->mu); return 0; }
+		t = p->tail; space = p->cap - (p->tail - p->head);
+		pthread_mutex_unlock(&p->mu);
+		if (space > ((uint64_t)8 << 20)) space = (uint64_t)8 << 20;
+		do n = read(p->fd, p->ring + t % p->cap, (size_t)space); while (n < 0 && errno == EINTR);
+		pthread_mutex_lock(&p->mu);
+		if (n <= 0) { p->eof = 1; pthread_cond_broadcast(&p->cv_data); pthread_mutex_unlock(&p->mu); return 0; } /* (a read error ends the input, as gzread's does) */
+		p->tail += (uint64_t)n;
+		pthread_cond_broadcast(&p->cv_data);
+		pthread_mutex_unlock(&p->mu);
+	}
+}
+static inline psrc_t *psrc_open(int fd, int own_fd, uint64_t cap)
+{
+	psrc_t *p = (psrc_t*)calloc(1, sizeof(psrc_t));
+	int mfd;
+	void *base;
+	cap = (cap + ((2u << 20) - 1)) & ~(uint64_t)((2u << 20) - 1);
+	mfd = (int)syscall(SYS_memfd_create, "bfc_pipe_ring", 0u);
+	if (mfd < 0 || ftruncate(mfd, (off_t)cap) != 0) { if (mfd >= 0) close(mfd); free(p); return 0; }
+	base = mmap(0, (size_t)(2 * cap), PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (base == MAP_FAILED) { close(mfd); free(p); return 0; }
+	if (mmap(base, (size_t)cap, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, mfd, 0) == MAP_FAILED ||
+	    mmap((uint8_t*)base + cap, (size_t)cap, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, mfd, 0) == MAP_FAILED) { munmap(base, (size_t)(2 * cap)); close(mfd); free(p); return 0; }
+	close(mfd);
+	p->fd = fd; p->own_fd = own_fd; p->ring = (uint8_t*)base; p->cap = cap;
+#ifdef F_SETPIPE_SZ
+	(void)fcntl(fd, F_SETPIPE_SZ, 1 << 20); /* fewer, larger reads (the default pipe holds 64 KiB); refused above /proc/sys/fs/pipe-max-size: then as it was */
+#endif
+	pthread_mutex_init(&p->mu, 0); pthread_cond_init(&p->cv_data, 0); pthread_cond_init(&p->cv_space, 0);
+	if (pthread_create(&p->th, 0, psrc_reader, p) != 0) { munmap(base, (size_t)(2 * cap)); free(p); return 0; }
+	p->on = 1;
+	return p;
+}
+static inline void psrc_close(psrc_t *p)
+{
+	if (!p) return;
+	if (p->on) {
+		pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_space); pthread_mutex_unlock(&p->mu);
+		if (!p->eof) pthread_cancel(p->th); /* (blocked in read() on a pipe nobody writes to any more) */
+		pthread_join(p->th, 0);
+	}
+	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_data); pthread_cond_destroy(&p->cv_space);
+	munmap(p->ring, (size_t)(2 * p->cap));
+	if (p->own_fd) close(p->fd);
+	free(p);
+}
+/* pgz_ensure's contract on the ring: bytes [pos, pos + want) made available (fewer at the end of the input), everything before pos given back to the
+ * reader.  0 and a pointer q with q[off] = byte `off` of the stream for pos <= off < *avail_end; -1: the window does not fit the ring. */
+static inline int psrc_ensure(psrc_t *p, uint64_t pos, uint64_t want, const uint8_t **q, uint64_t *avail_end, int *eof)
+{
+	if (want > p->cap) return -1;
+	pthread_mutex_lock(&p->mu);
+	if (pos < p->head) { pthread_mutex_unlock(&p->mu); return -1; }
+	while (!p->eof && p->tail < pos) { p->head = p->tail; pthread_cond_signal(&p->cv_space); pthread_cond_wait(&p->cv_data, &p->mu); } /* (never: callers consume in order) */
+	if (pos > p->head) { p->head = pos < p->tail ? pos : p->tail; pthread_cond_signal(&p->cv_space); }
+	while (!p->eof && p->tail < pos + want) pthread_cond_wait(&p->cv_data, &p->mu);
+	*avail_end = p->tail; *eof = p->eof;
+	pthread_mutex_unlock(&p->mu);
+	*q = p->ring + pos % p->cap - pos;
+	return 0;
+}
+static inline int psrc_take(struct psrc_s *p, uint64_t pos, uint8_t *dst, int want)
+{
+	const uint8_t *q; uint64_t avail; int eof, n;
+	if (psrc_ensure(p, pos, (uint64_t)want, &q, &avail, &eof) != 0) return 0;
+	n = avail - pos < (uint64_t)want ? (int)(avail - pos) : want;
+	if (n > 0) memcpy(dst, q + pos, (size_t)n);
+	return n;
+}
+/* the first two bytes of a pipe WITHOUT consuming them (tee(2) duplicates what is there into a scratch pipe): -1 = not a pipe / cannot tell,
+ * else how many were seen (0: the input is empty) */
+static inline int pipe_peek2(int fd, uint8_t out[2])
+{
+	int sc[2], n = -1, tries;
+	if (pipe(sc) != 0) return -1;
+	for (tries = 0; tries < 200000; ++tries) {
+		ssize_t r = tee(fd, sc[1], 2, 0); /* blocks until the writer has sent something or closed */
+		if (r < 0) { if (errno == EINTR) continue; n = -1; break; }
+		if (r > 0) { uint8_t tmp[2]; ssize_t g = read(sc[0], tmp, (size_t)r); if (g > 0) memcpy(out, tmp, (size_t)g); n = (int)g; }
+		else n = 0;
+		if (r == 0 || r >= 2) break;
+		usleep(50); /* one byte so far */
+	}
+	close(sc[0]); close(sc[1]);
+	return n;
+}
+
 typedef struct {
 	const uint8_t *map; uint64_t size, pos; /* pos: next record boundary */
+	psrc_t *pipe;          /* pipe input: `map` is re-based on the ring for every window, `size` unknown until the pipe's end */
 	pgz_t *gz;             /* gzip input: `map` is the text the parallel inflate (bfc_pgz.h) holds from `pos` on, `size` unknown until its end */
 	const uint8_t *zmap; uint64_t zsize; /* the mapped .gz file */
 	int n_threads, active;
@@ -389,6 +515,13 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 		if (f->gz) { /* inflate until the window is there (or the input ends) */
 			uint64_t avail; int eof;
 			if (pgz_ensure(f->gz, f->pos, win, &f->map, &avail, &eof) != 0) return 0; /* damaged gzip: gzread decides what the reference would see */
+			if (eof) f->size = avail;
+			wend = f->pos + win < avail ? f->pos + win : avail; at_eof = eof && wend == avail;
+			if (f->pos == 0 && wend > 0 && f->map[0] != '@') return 0;
+		}
+		if (f->pipe) { /* wait until the reader has the window in the ring (or the pipe's end) */
+			uint64_t avail; int eof;
+			if (psrc_ensure(f->pipe, f->pos, win, &f->map, &avail, &eof) != 0) return 0; /* a window larger than the ring: the serial parser goes on from here */
 			if (eof) f->size = avail;
 			wend = f->pos + win < avail ? f->pos + win : avail; at_eof = eof && wend == avail;
 			if (f->pos == 0 && wend > 0 && f->map[0] != '@') return 0;
@@ -481,7 +614,7 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 			} else f->pos = cur;
 		}
 		if (bases > 0) f->bytes_per_base = (double)(f->pos - pos0) / (double)bases;
-		if (!f->gz) fq_consumed(f, f->pos);
+		if (!f->gz && !f->pipe) fq_consumed(f, f->pos);
 		return 1;
 	}
 }
@@ -529,6 +662,38 @@ static inline int ingest_open(ingest_t *in, const char *fn, uint64_t chunk_size,
 	memset(in, 0, sizeof(*in));
 	in->ps.chunk_size = chunk_size;
 	in->workers = workers < 1 ? 1 : workers;
+	if (n_threads > 0 && !getenv("BFC_INGEST_NO_PIPE")) { /* a pipe (stdin, a FIFO, /dev/fd/N of a process substitution) with plain text in it: the ring */
+		struct stat st;
+		const int is_stdin = !(fn && strcmp(fn, "-"));
+		int fd = -1;
+		if (is_stdin) { if (fstat(fileno(stdin), &st) == 0 && S_ISFIFO(st.st_mode)) fd = fileno(stdin); }
+		else if (stat(fn, &st) == 0 && S_ISFIFO(st.st_mode)) fd = open(fn, O_RDONLY); /* (waits for the pipe's writer, as gzopen would) */
+		if (fd >= 0) {
+			uint8_t two[2] = {0, 0};
+			const int n = pipe_peek2(fd, two);
+			if (n >= 1 && !(n >= 2 && two[0] == 0x1f && two[1] == 0x8b)) { /* not gzip (zlib would copy it through: gzread's transparent mode) */
+				/* the ring holds the largest window a batch may need: the fast path starts with 3 bytes per base and doubles once at most before it gives up */
+				uint64_t cap = getenv("BFC_INGEST_RING") ? strtoull(getenv("BFC_INGEST_RING"), 0, 10) : chunk_size * 6 + ((uint64_t)64 << 20);
+				psrc_t *p = psrc_open(fd, !is_stdin, cap);
+				if (p) {
+					in->fast.pipe = p; in->fast.map = 0; in->fast.size = ~(uint64_t)0; in->fast.pos = 0; in->fast.active = 1;
+					in->fast.n_threads = n_threads > FQ_MAX_THREADS ? FQ_MAX_THREADS : n_threads;
+					in->fast.min_slice = getenv("BFC_INGEST_MIN_SLICE") ? strtoull(getenv("BFC_INGEST_MIN_SLICE"), 0, 10) : 65536;
+					if (in->fast.min_slice < 16) in->fast.min_slice = 16;
+					in->fast.job = (fq_job_t*)calloc((size_t)in->fast.n_threads, sizeof(fq_job_t));
+					in->fast.pool = bfc_pool_create(in->fast.n_threads);
+					in->ps.rd.buf = (uint8_t*)malloc(RD_BUF);
+					in->ps.rd.mem = p; in->ps.rd.mem_pos = 0; /* (the serial parser, should it take over, reads the ring too: rd_fill) */
+					return 0;
+				}
+			}
+			/* gzip data, an empty pipe, or no ring: gzread on THIS descriptor (nothing was consumed; opening a FIFO a second time would wait for a second writer) */
+			in->ps.rd.fp = gzdopen(fd, "r");
+			if (in->ps.rd.fp == 0) return -1;
+			in->ps.rd.buf = (uint8_t*)malloc(RD_BUF);
+			return 0;
+		}
+	}
 	in->ps.rd.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
 	if (in->ps.rd.fp == 0) return -1;
 	in->ps.rd.buf = (uint8_t*)malloc(RD_BUF);
@@ -578,8 +743,11 @@ static inline void ingest_fill(ingest_t *in, batch_t *b)
 		else {
 			in->fast.active = 0; /* not strict 4-line FASTQ from here on: the serial parser takes over at the last record boundary */
 			if (in->fast.gz) { pgz_close(in->fast.gz); in->fast.gz = 0; in->fast.map = 0; } /* (for gzip input zlib inflates up to there again) */
+			if (in->fast.pipe) { in->ps.rd.mem_pos = in->fast.pos; in->ps.rd.total = in->fast.pos; } /* a pipe is not read again: the ring still holds everything from the boundary on */
+			else {
 			gzseek(in->ps.rd.fp, (z_off_t)in->fast.pos, SEEK_SET);
 			in->ps.rd.total = in->fast.pos; in->ps.rd.first_piece = RD_PIECE - (int)(in->fast.pos % RD_PIECE);
+			}
 		}
 	}
 	if (!done) {
@@ -601,9 +769,11 @@ static inline void ingest_close(ingest_t *in)
 		pthread_mutex_destroy(&in->fast.um_mu); pthread_cond_destroy(&in->fast.um_cv);
 	}
 	if (in->fast.zmap) munmap((void*)in->fast.zmap, (size_t)in->fast.zsize);
+	else if (in->fast.pipe) ;
 	else if (in->fast.map && in->fast.size > in->fast.um_done) munmap((void*)(in->fast.map + in->fast.um_done), (size_t)(in->fast.size - in->fast.um_done));
 	if (in->fast.job) { for (i = 0; i < in->fast.n_threads; ++i) free(in->fast.job[i].rec); free(in->fast.job); }
-	gzclose(in->ps.rd.fp);
+	if (in->fast.pipe) psrc_close(in->fast.pipe);
+	if (in->ps.rd.fp) gzclose(in->ps.rd.fp);
 	free(in->ps.rd.buf); free(in->ps.rd.line); free(in->ps.seq); free(in->ps.qual); free(in->ps.hdr); free(in->ps.cmt);
 }
 

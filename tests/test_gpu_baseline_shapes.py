@@ -164,7 +164,7 @@ def test_c5_parameters(gpu_lib):
 
 
 @pytest.mark.skipif("c5e" not in BASE, reason="tests/golden/baseline.json has no c5e entry (make_baseline_goldens.py c5e: ~1.2 h of one core)")
-def test_c5_eighth_full_geometry(gpu_lib):
+def test_c5_eighth_full_geometry_count_and_trim(gpu_lib):
     """An EIGHTH of config c5 itself: the 77.5 M reads of c4e at c5's parameters -- `-s 3g -k51 -1`: k=51, -b37, two 16 GiB filters,
     2^20 regions, 10+10 scatter levels, 16-byte records, k_bloom3fm -- in calls of 16 M reads as scripts/c4_run.py and bench.py's secondary `c5e`
     submit them: k-mer / high / seen totals and BOTH filters' popcount + FNV-1a equal the reference's (tests/golden/baseline.json[c5e])."""
@@ -177,7 +177,34 @@ def test_c5_eighth_full_geometry(gpu_lib):
 
     _check_against(g, e)
     assert g.stats()["slow_buckets"] == 0
+    # ---- config c5's QUERY pass on c5's own workload and geometry: the second filter stays in HBM as bfc_count leaves it for
+    # bfc_correct, the trim context adopts it, and the windows of all 77.5 M reads -- k_query4 (one bfc_bf_get per k-mer, bbf.c:47-63) + k_streak
+    # (max_streak + keep rule, correct.c:478-497,557-567) -- are those the reference's own worker_ec gave against the reference's bf_high
+    # (tests/golden/baseline.json[c5e_trim], tests/golden/make_baseline_goldens.py)
+    t = BASE.get("c5e_trim")
+    if t is None:
+        g.close()
+        pytest.skip("tests/golden/baseline.json has no c5e_trim entry (make_baseline_goldens.py c5e_trim)")
+    assert t["reproduces"] == "c5e" and (t["bf_high_popcount"], t["bf_high_fnv1a64"]) == (e["bf_high_popcount"], e["bf_high_fnv1a64"])
+    bf = g.export_bloom(1, resident=True)
     g.close()
+    br, stride = 8_388_608, rs.L + 1
+    tr = gpu_lib.GpuTrimmer(e["k"], bf, max_pos=br * stride, max_reads=br)
+    assert tr.adopted, "the trim context is expected to adopt the filter the count pass left in HBM"
+    kept = bases = 0
+    h = 0xcbf29ce484222325
+    G = gen._L()
+    for r0 in range(0, rs.n_reads, br):
+        r1 = min(rs.n_reads, r0 + br)
+        seq, _, _ = rs.reads(r0, r1)
+        st_, en_ = tr.trim(gen.to_stream(seq, rs.L, 10), np.arange(r1 - r0 + 1, dtype=np.uint64) * np.uint64(stride), t["min_frac"])
+        m = st_ >= 0
+        kept += int(m.sum()); bases += int((en_[m] - st_[m]).sum())
+        pairs = np.ascontiguousarray(np.stack([st_, en_], axis=1), dtype="<i4")
+        h = int(G.bfcgen_fnv1a64_from(h, pairs.ctypes.data, pairs.nbytes))
+    tr.close(); bf.close()
+    assert (kept, bases) == (t["trim_reads_kept"], t["trim_bases_kept"])
+    assert "%016x" % h == t["trim_windows_fnv1a64"], "the (start, end) windows differ from the reference's"
 
 
 @pytest.mark.parametrize("fm", [0, 1])

@@ -254,3 +254,112 @@ def test_bit_planes_straight_from_the_file(gpu_lib, tmp_path, case):
                 assert tiny[:6] == want[:6] and tiny[6] == want[0], (case, chunk, q)
             if q != 20:
                 continue
+
+
+# ------------------------------------------------------------------ pipe input (round 6): a FIFO drained into a ring, the same chained walks
+
+
+def _digest_fifo(gpu_lib, tmp_path, data, chunk, threads, piece=None, cap=1 << 24):
+    """the digest of `data` arriving through a named pipe, written in pieces of `piece` bytes (None: at once) by a thread of this process"""
+    import threading
+    fifo = str(tmp_path / "in.fifo")
+    if os.path.exists(fifo):
+        os.unlink(fifo)
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb", buffering=0) as f:
+            try:
+                if piece is None:
+                    f.write(data)
+                else:
+                    for i in range(0, len(data), piece):
+                        f.write(data[i:i + piece])
+            except BrokenPipeError:
+                pass
+    th = threading.Thread(target=feed)
+    th.start()
+    try:
+        return _digest(gpu_lib, fifo, chunk, threads, cap=cap)
+    finally:
+        th.join()
+        os.unlink(fifo)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_pipe_input_parses_like_the_file(gpu_lib, tmp_path, case):
+    """VERDICT r5 missing 6: a pipe (the published command feeds `<(seqtk mergepe ...)`, tex/README.md:26; bseq.c:33-50) takes the multi-threaded FASTQ
+    path too -- a reader thread drains it into a ring mapped twice, the chained walks run on windows of the ring -- and where the text is not strict
+    4-line FASTQ the serial parser goes on FROM THE RING (a pipe cannot be read again).  Same batches as the file's, by every parser."""
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    fn = str(tmp_path / (case + ".fq"))
+    size = _make(case, fn, rng)
+    data = open(fn, "rb").read()
+    for chunk in (20000, 1 << 30) if size < (1 << 22) else (500000,):
+        want = _digest(gpu_lib, fn, chunk, 0)
+        for threads, piece in ((1, None), (4, 4099), (8, 65536)):
+            got = _digest_fifo(gpu_lib, tmp_path, data, chunk, threads, piece)
+            assert got[:6] == want[:6], (case, chunk, threads)
+            if case in ("plain", "crlf", "no_final_newline", "trailing_blank_lines", "long_reads", "tiny_reads") and want[0] and chunk < (1 << 30):
+                assert got[6] == want[0], "every batch of a strict FASTQ on a pipe comes from the fast path"
+            if case in ("multiline", "fasta"):
+                assert got[6] == 0
+        if case == "strict_then_multiline" and chunk == 20000:
+            assert 0 < got[6] < want[0], "fast path until the wrapped record, serial parser from the ring behind it"
+
+
+def test_pipe_ring_wraps_and_gzip_on_a_pipe(gpu_lib, tmp_path, monkeypatch):
+    """12 MB of strict FASTQ through a ring of 4 MiB (the windows wrap around its end three times; the reader waits for the parser), then through a
+    ring too small for one window (the serial parser takes everything, from the ring), then gzip data on a pipe (left to gzread: nothing consumed
+    by the look at its first two bytes), and BFC_INGEST_NO_PIPE=1 (the old way)."""
+    rng = np.random.default_rng(78)
+    data = _fastq(rng, 60000, 60, 120)
+    fn = str(tmp_path / "big.fq"); open(fn, "wb").write(data)
+    want = _digest(gpu_lib, fn, 500000, 0)
+    monkeypatch.setenv("BFC_INGEST_RING", str(4 << 20))
+    for threads in (1, 8):
+        got = _digest_fifo(gpu_lib, tmp_path, data, 500000, threads, 1 << 20)
+        assert got[:6] == want[:6] and got[6] == want[0], threads
+    monkeypatch.setenv("BFC_INGEST_RING", str(1 << 20))  # (rounded up to 2 MiB: a first window of 3 x 500 000 + 256 Ki bytes still fits; 1.5 M bases do not)
+    big = _digest(gpu_lib, fn, 1500000, 0)
+    got = _digest_fifo(gpu_lib, tmp_path, data, 1500000, 4, 1 << 20)
+    assert got[:6] == big[:6] and got[6] == 0
+    monkeypatch.delenv("BFC_INGEST_RING")
+    gz = gzip.compress(data[:3_000_000], 1)
+    small = str(tmp_path / "small.fq"); open(small, "wb").write(data[:3_000_000])
+    want_gz = _digest(gpu_lib, small, 500000, 0)
+    got = _digest_fifo(gpu_lib, tmp_path, gz, 500000, 4, 70001)
+    assert got[:6] == want_gz[:6] and got[6] == 0
+    monkeypatch.setenv("BFC_INGEST_NO_PIPE", "1")
+    got = _digest_fifo(gpu_lib, tmp_path, data, 500000, 4, 1 << 20)
+    assert got[:6] == want[:6] and got[6] == 0
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libbfcref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(40))
+def test_damaged_inputs_on_a_pipe_parse_like_the_reference(gpu_lib, tmp_path, seed):
+    """The damaged texts of the test above, through a pipe: the reference's bseq_read on the FILE says what the batches are."""
+    rng = np.random.default_rng(7000 + seed)
+    kind = seed % 3
+    if kind == 0:
+        data = _fastq(rng, int(rng.integers(1, 400)), 1, 120, crlf=rng.random() < 0.2)
+    elif kind == 1:
+        data = b"".join(b">f%d x\n" % r + rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(0, 200))).tobytes() + b"\n" for r in range(int(rng.integers(1, 300))))
+    else:
+        data = _fastq(rng, 150, 10, 80) + b">fa\nACGTTGCA\nAC\n" + _fastq(rng, 150, 10, 80)
+    fn = str(tmp_path / "d.fq")
+    for rep in range(4):
+        text = _mutate(rng, data)
+        open(fn, "wb").write(text)
+        for chunk in (300, 5000, 1 << 30):
+            want = _ref_digest(fn, chunk)[:6]
+            for threads, min_slice in ((3, None), (5, "64")):
+                if min_slice:
+                    os.environ["BFC_INGEST_MIN_SLICE"] = min_slice
+                try:
+                    got = _digest_fifo(gpu_lib, tmp_path, text, chunk, threads, int(rng.integers(1, 5000)))[:6]
+                finally:
+                    os.environ.pop("BFC_INGEST_MIN_SLICE", None)
+                if got != want:
+                    open("/tmp/ingest_pipe_fail.fq", "wb").write(text)
+                assert got == want, (seed, rep, chunk, threads, min_slice)
