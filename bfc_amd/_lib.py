@@ -81,6 +81,7 @@ SYMBOLS = {
     "bfcg_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "bfcg_group_slab_mode": (C.c_int, [C.c_void_p]),
     "bfcg_group_lazy_batches": (C.c_uint64, [C.c_void_p]),
+    "bfcg_group_exchange_bytes": (C.c_int, [C.c_void_p, u64p]),
     "bfcg_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
     "bfcg_group_reset": (C.c_int, [C.c_void_p]),
     "bfcg_group_count_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),

@@ -417,8 +417,14 @@ class GpuGroup:
     def info(self):
         out = (C.c_int * 6)()
         self.L.bfcg_group_info(self.g, out)
-        return dict(n_ranks=out[0], n_local=out[1], transport={1: "rccl", 2: "peer"}.get(out[2], out[2]), rec_bytes=out[3], nb1=out[4], first_rank=out[5],
+        return dict(n_ranks=out[0], n_local=out[1], transport={1: "rccl", 2: "peer", 3: "push"}.get(out[2], out[2]), rec_bytes=out[3], nb1=out[4], first_rank=out[5],
                     slab_mode=bool(self.L.bfcg_group_slab_mode(self.g)), lazy_batches=int(self.L.bfcg_group_lazy_batches(self.g)))
+
+    def exchange_bytes(self):
+        """Bytes the local ranks put on the links since creation / reset, and the bytes of the live records among them (bfcg_group_exchange_bytes)."""
+        out = (C.c_uint64 * 4)()
+        self._ck(self.L.bfcg_group_exchange_bytes(self.g, out))
+        return dict(links=int(out[0]), exact=int(out[1]), batches=int(out[2]), transport={1: "rccl", 2: "peer", 3: "push"}.get(int(out[3]), int(out[3])))
 
     def ctx(self, i):
         """Local rank i's counting context as a GpuCounter view (owned by the group)."""

@@ -652,20 +652,26 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		__syncthreads();
 		if (!ONEPASS2) {
 			for (int i = threadIdx.x; i < nb2; i += BT) gdelta[i] = rowp[i] - cnt[i]; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
-		} else {
-			const uint32_t f0 = (uint32_t)(b1 / segs_per_bucket) << P.F2;
-			for (int i = threadIdx.x; i < nb2; i += BT) {
-				const uint32_t ex = cnt[i], c = (i + 1 < nb2 ? cnt[i + 1] : tot) - ex;
-				uint32_t base = 0;
-				if (c) {
-					base = atomicAdd(&O2.cnt2[f0 + i], c);
-					if (base + c > O2.cap2) { O2.flags[2] = 1; base = 0; } // (the run then lands on records nobody will read: the buffer ends with a tile of slack)
-				}
-				gdelta[i] = (f0 + (uint32_t)i) * O2.cap2 + base - ex;
+		}
+	}
+	// One pass: a (tile, region) run reserves its place with a RETURNING atomic on the region's cursor -- executed at the memory side, a round trip of
+	// microseconds --, and nothing needs the answer before the copy-out: the atomics are issued here, the tile is put in region order in LDS
+	// meanwhile, and the answers are turned into gdelta behind that (round 6; they were awaited before the staging began).
+	constexpr int NQ = (BFCG_MAXB + BT - 1) / BT;
+	uint32_t q_base[NQ], q_ex[NQ], q_c[NQ];
+	if (ONEPASS2) {
+		const uint32_t f0 = (uint32_t)(b1 / segs_per_bucket) << P.F2;
+#pragma unroll
+		for (int u = 0; u < NQ; ++u) {
+			const int i = threadIdx.x + u * BT;
+			q_base[u] = 0; q_ex[u] = 0; q_c[u] = 0;
+			if (i < nb2) {
+				q_ex[u] = cnt[i]; q_c[u] = (i + 1 < nb2 ? cnt[i + 1] : n_live) - q_ex[u];
+				if (q_c[u]) q_base[u] = atomicAdd(&O2.cnt2[f0 + i], q_c[u]);
 			}
 		}
 	}
-	__syncthreads();
+	if (!ONEPASS2) __syncthreads();
 #pragma unroll
 	for (int j = 0; j < S; ++j) {
 		if (br[j] != 0xffffffffu) {
@@ -673,6 +679,18 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 #pragma unroll
 			for (int t = 0; t < RW; ++t) stage[(size_t)pos * RW + t] = w[j].d[t];
 			if (KEEP_BK) sbk[pos] = (unsigned short)b;
+		}
+	}
+	if (ONEPASS2) {
+		const uint32_t f0 = (uint32_t)(b1 / segs_per_bucket) << P.F2;
+#pragma unroll
+		for (int u = 0; u < NQ; ++u) {
+			const int i = threadIdx.x + u * BT;
+			if (i < nb2) {
+				uint32_t base = q_base[u];
+				if (q_c[u] && base + q_c[u] > O2.cap2) { O2.flags[2] = 1; base = 0; } // (the run then lands on records nobody will read: the buffer ends with a tile of slack)
+				gdelta[i] = (f0 + (uint32_t)i) * O2.cap2 + base - q_ex[u];
+			}
 		}
 	}
 	__syncthreads();

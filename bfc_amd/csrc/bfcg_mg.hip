@@ -44,7 +44,46 @@ extern "C" void *bfcg_bloom_slice(bfcg_ctx_t *c, int which, uint64_t *bytes);
 
 namespace {
 
-enum { XP_RCCL = 1, XP_PEER = 2 };
+enum { XP_RCCL = 1, XP_PEER = 2, XP_PUSH = 3 };
+
+// PUSH transport (round 6; ranks of one process whose devices reach each other's memory): ONE kernel per rank and global batch writes the FILLED
+// part of every slab of this rank's stage A straight into its owner's receive buffer -- peer-mapped memory, stores over xGMI, the mechanism RCCL's own
+// send / receive kernels use -- and the rank's row of fills beside it.  The fills are read on the device (the rows k_pack_rows made), so the bytes on
+// the links are the records, exactly, and the host still knows no size when it enqueues this (the lazy protocol of round 5 sent whole slabs with
+// their unfilled ends for that reason: +40 % bytes).  A work item = one slab of one destination; persistent workgroups stride over them.
+#define PUSH_MAX_RANKS 16
+struct PushDst { uint8_t *recv[PUSH_MAX_RANKS]; uint32_t *rows[PUSH_MAX_RANKS]; };
+__global__ __launch_bounds__(256) void k_push_slabs(const uint8_t *__restrict__ send, const uint32_t *__restrict__ rows_out, PushDst D, int N, int me, uint32_t per /* slabs per destination */,
+                                                   uint32_t cap, uint32_t rb, uint32_t row_w, unsigned long long *__restrict__ moved)
+{
+	const uint32_t n_items = (uint32_t)(N - 1) * per;
+	unsigned long long mine = 0;
+	for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+		const int to = (me + 1 + (int)(item / per)) % N;
+		const uint32_t i = item % per;
+		const uint32_t *row = rows_out + (size_t)to * row_w;
+		uint32_t fill = row[per] ? 0u : row[i]; // (row[per] != 0: a slab of this stage A overflowed, or the stage failed -- nothing of it may be used; the row says so to the owner)
+		if (fill > cap) fill = cap;
+		const uint64_t blk = (uint64_t)per * cap;
+		const uint8_t *src = send + ((uint64_t)to * blk + (uint64_t)i * cap) * rb;
+		uint8_t *dst = D.recv[to] + ((uint64_t)me * blk + (uint64_t)i * cap) * rb;
+		const uint64_t nbytes = (uint64_t)fill * rb; // (a multiple of 4: records are 12, 16 or 20 bytes)
+		if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+			const uint64_t n16 = nbytes >> 4;
+			for (uint64_t j = threadIdx.x; j < n16; j += blockDim.x) reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(src)[j];
+			for (uint64_t j = (n16 << 2) + threadIdx.x; j < (nbytes >> 2); j += blockDim.x) reinterpret_cast<uint32_t *>(dst)[j] = reinterpret_cast<const uint32_t *>(src)[j];
+		} else
+			for (uint64_t j = threadIdx.x; j < (nbytes >> 2); j += blockDim.x) reinterpret_cast<uint32_t *>(dst)[j] = reinterpret_cast<const uint32_t *>(src)[j];
+		if (threadIdx.x == 0) mine += nbytes;
+	}
+	if (blockIdx.x < (unsigned)(N - 1)) { // the rows: workgroup b carries the one for the b-th peer
+		const int to = (me + 1 + (int)blockIdx.x) % N;
+		for (uint32_t j = threadIdx.x; j < row_w; j += blockDim.x) D.rows[to][(size_t)me * row_w + j] = rows_out[(size_t)to * row_w + j];
+		if (threadIdx.x == 0) mine += (unsigned long long)row_w * 4u;
+	}
+	if (threadIdx.x == 0 && mine) atomicAdd(moved, mine);
+	__threadfence_system(); // the stores are another device's memory: visible there before this kernel is seen as complete
+}
 const uint64_t MSG_BYTES = 256ull << 20; // this image's RCCL truncates single messages above 1 GiB (measured): stay far below
 
 struct rank_t {
@@ -60,6 +99,7 @@ struct rank_t {
 	uint32_t *d_counts;        // multi-process: all ranks' rows, device side of the all-gather
 	uint32_t *d_rows_out[2], *d_rows_in[2]; // slab mode, all ranks in this process: the fills of stage A's slabs as one row per destination (device), and every
 	                           // source's row for this rank -- they travel beside the blocks, the owner's stage B reads them on the device (rank_batch: `lazy`)
+	unsigned long long *d_moved; // PUSH: bytes k_push_slabs has written to peers (device counter, read at bfcg_group_exchange_bytes)
 	uint64_t batch_call[64];   // the context's call number after stage B of global batch t (t & 63): bfcg_group_progress
 	ncclComm_t comm;
 	uint8_t *d_seq, *d_qual; uint64_t in_cap; // staging of host batches
@@ -85,6 +125,9 @@ struct bfcg_group {
 	uint64_t kmer_limit;        // k-mers of a global batch one rank's regions take at full speed
 	int lazy_ok, lazy;          // the sizes reach the host AFTER exchange and stage B are enqueued: possible at all (slab mode, every context able to take its stage B from rows on the device -- in-process AND multi-process groups); for the current batch
 	uint64_t n_lazy;            // global batches taken that way
+	int push;                   // XP_PEER with the PUSH kernel for lazy batches (k_push_slabs: exact bytes); everything else of the peer-copy transport as it was
+	unsigned push_wgs;          // its persistent workgroups per rank
+	unsigned long long x_links, x_exact; // bytes the local ranks put on the links so far (whole blocks / messages as sent), and the bytes of the live records among them
 	std::vector<rank_t> r;
 	uint32_t *all_counts;       // [n_ranks][nb1 + 1], host (pinned): every rank's bucket sizes of the current batch and its failure word
 	pthread_barrier_t bar;      // local ranks
@@ -280,6 +323,16 @@ static int rank_batch(bfcg_group_t *g, int i)
 					GNCCL(ncclRecv(rin + (size_t)from * rw_, rw_, ncclUint32, from, R.comm, R.xs));
 				}
 				if (N > 1) GNCCL(ncclGroupEnd());
+			} else if (g->push && N > 1) {
+				PushDst D;
+				memset(&D, 0, sizeof(D));
+				for (int p = 0; p < N; ++p) { const rank_t &T = g->r[p - g->first]; D.recv[p] = T.recv[g->t & 1]; D.rows[p] = T.d_rows_in[g->t & 1]; }
+				const uint32_t per = (uint32_t)nb_loc * 8u;
+				unsigned wgs = g->push_wgs;
+				if (wgs > (unsigned)(N - 1) * per) wgs = (unsigned)(N - 1) * per;
+				if (wgs < (unsigned)(N - 1)) wgs = (unsigned)(N - 1);
+				hipLaunchKernelGGL(k_push_slabs, dim3(wgs), dim3(256), 0, R.xs, (const uint8_t *)send, (const uint32_t *)R.d_rows_out[sb], D, N, me, per, g->slab_cap, (uint32_t)rb, (uint32_t)rw_, R.d_moved);
+				GHIP(hipGetLastError());
 			} else {
 				for (int step = 1; step < N; ++step) {
 					const int to = (me + step) % N;
@@ -288,6 +341,7 @@ static int rank_batch(bfcg_group_t *g, int i)
 					GHIP(hipMemcpyPeerAsync(T.d_rows_in[g->t & 1] + (size_t)me * rw_, T.device, R.d_rows_out[sb] + (size_t)to * rw_, R.device, sizeof(uint32_t) * rw_, R.xs));
 				}
 			}
+			if (!(g->push && g->xp == XP_PEER)) __atomic_fetch_add(&g->x_links, (unsigned long long)(N - 1) * (g->blk * rb + sizeof(uint32_t) * rw_), __ATOMIC_RELAXED);
 			GHIP(hipEventRecord(R.ev_x, R.xs));
 		}
 		pthread_barrier_wait(&g->bar); // every sender's event is recorded: the owners may wait for them
@@ -306,6 +360,12 @@ static int rank_batch(bfcg_group_t *g, int i)
 		int ovf = 0;
 		if (a_ok && bfcg_mg_scatter_slabs_wait(R.ctx, R.counts, &ovf) != 0) { grp_err(g, "rank %d: %s", me, bfcg_last_error()); memset(R.counts, 0, sizeof(uint32_t) * cs); }
 		if (!a_ok) memset(R.counts, 0, sizeof(uint32_t) * cs);
+		if (post && N > 1) { // what of this rank's stage A belonged on the links: the live records of the other ranks' buckets
+			unsigned long long live = 0;
+			const size_t per = (size_t)nb_loc * 8;
+			for (int p = 0; p < N; ++p) if (p != me) for (size_t i2 = 0; i2 < per; ++i2) live += R.counts[(size_t)p * per + i2];
+			__atomic_fetch_add(&g->x_exact, live * rb, __ATOMIC_RELAXED);
+		}
 		R.counts[cs - 1] = ovf ? 1u : 0u;
 		R.counts[cs - 2] = g->failed ? 1u : 0u;
 		publish_sizes(g, R); // (between processes: the all-gather, behind this batch's exchange on the same stream)
@@ -385,6 +445,15 @@ static int rank_batch(bfcg_group_t *g, int i)
 			for (int s2 = 0; s2 < N; ++s2) for (int k = 0; k < nb_loc; ++k) q += C[(size_t)s2 * cs + (size_t)p * nb_loc + k];
 			if (q * rb > R.recv_cap) { grp_err(g, "rank %d receives %llu records of one global batch, its buffer holds %llu: smaller shares or a larger filter", p, (unsigned long long)q, (unsigned long long)(R.recv_cap / rb)); ok = 0; }
 		}
+	}
+	if (ok && N > 1) { // (the books: bytes as they are sent, and the live records among them)
+		unsigned long long links = 0, live = 0;
+		for (int p = 0; p < N; ++p) if (p != me) {
+			links += (s_off[p + 1] - s_off[p]) * rb;
+			if (slab) for (int i2 = 0; i2 < nb_loc * 8; ++i2) live += (unsigned long long)C[(size_t)me * cs + (size_t)p * nb_loc * 8 + i2] * rb;
+		}
+		__atomic_fetch_add(&g->x_links, links, __ATOMIC_RELAXED);
+		__atomic_fetch_add(&g->x_exact, slab ? live : links, __ATOMIC_RELAXED);
 	}
 	// ---- records
 	if (g->xp == XP_RCCL) {
@@ -505,7 +574,7 @@ extern "C" void bfcg_group_destroy(bfcg_group_t *g)
 		(void)hipSetDevice(R.device);
 		if (R.ctx) (void)bfcg_sync(R.ctx);
 		if (R.comm) { if (g->failed && g->mp) (void)ncclCommAbort(R.comm); else (void)ncclCommDestroy(R.comm); } // (peers of a failed run may never post what a clean destroy waits for)
-		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); if (!R.combined) { (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); } (void)hipFree(R.d_counts); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
+		(void)hipFree(R.send2[0]); (void)hipFree(R.send2[1]); if (!R.combined) { (void)hipFree(R.recv[0]); (void)hipFree(R.recv[1]); } (void)hipFree(R.d_counts); (void)hipFree(R.d_moved); (void)hipFree(R.d_seq); (void)hipFree(R.d_qual);
 		for (int b = 0; b < 2; ++b) { (void)hipFree(R.d_rows_out[b]); (void)hipFree(R.d_rows_in[b]); }
 		if (R.ev_x) (void)hipEventDestroy(R.ev_x);
 		for (int b = 0; b < 2; ++b) if (R.ev_sent[b]) (void)hipEventDestroy(R.ev_sent[b]);
@@ -533,6 +602,13 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 	if (g->mp) g->xp = XP_RCCL;
 	if (n_local == n_ranks && g->xp == XP_RCCL) // RCCL refuses two ranks on one device: repeated devices (emulation on a single GPU) take the peer-copy path
 		for (int i = 0; i < n_local; ++i) for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) g->xp = XP_PEER;
+	// transport 3, or by default wherever ranks share a device (RCCL is out there anyway): the peer-copy transport with lazy batches PUSHED by k_push_slabs
+	// (exact bytes).  Distinct devices keep RCCL unless 3 is asked for: the push kernel has never run over xGMI (no two-GPU box in six rounds).
+	g->push = 0; g->push_wgs = 64; g->x_links = g->x_exact = 0;
+	if (transport == XP_PUSH) { g->xp = XP_PEER; g->push = 1; }
+	else if (g->xp == XP_PEER && transport == 0) { const char *e = getenv("BFCG_MG_PUSH"); g->push = !(e && atoi(e) == 0); }
+	if (n_ranks > PUSH_MAX_RANKS) g->push = 0;
+	{ const char *e = getenv("BFCG_MG_PUSH_WGS"); if (e && atoi(e) > 0) g->push_wgs = (unsigned)atoi(e); }
 	if (g->xp == XP_PEER && n_local < n_ranks) { bfcg_set_error("peer copies need every rank in this process"); bfcg_group_destroy(g); return NULL; }
 	g->r.resize((size_t)n_local);
 	for (auto &R : g->r) memset(&R, 0, sizeof(R));
@@ -602,6 +678,7 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 			if (e == hipSuccess) e = hipMalloc(&R.d_rows_in[b], sizeof(uint32_t) * w);
 			if (e == hipSuccess) e = hipMemset(R.d_rows_in[b], 0, sizeof(uint32_t) * w);
 		}
+		if (g->push) { if (e == hipSuccess) e = hipMalloc(&R.d_moved, sizeof(unsigned long long)); if (e == hipSuccess) e = hipMemset(R.d_moved, 0, sizeof(unsigned long long)); }
 		R.in_cap = cap;
 		if (e == hipSuccess) e = hipMalloc(&R.d_seq, cap);
 		if (e == hipSuccess) e = hipMalloc(&R.d_qual, cap);
@@ -650,9 +727,23 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 	return g;
 }
 
+// out[0] bytes the local ranks have put on the links since creation / the last reset (whole blocks and messages as sent; the PUSH kernel's own count of
+// what it wrote), out[1] the bytes of the LIVE records among them (what an exact exchange moves), out[2] global batches, out[3] transport (1 RCCL, 2 peer
+// copies, 3 peer copies + push kernel).  Drains the exchange streams.
+extern "C" int bfcg_group_exchange_bytes(bfcg_group_t *g, uint64_t out[4])
+{
+	unsigned long long pushed = 0;
+	for (auto &R : g->r) if (R.d_moved) {
+		unsigned long long v = 0;
+		if (hipSetDevice(R.device) != hipSuccess || hipStreamSynchronize(R.xs) != hipSuccess || hipMemcpy(&v, R.d_moved, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) { bfcg_set_error("reading the push counter failed"); return -1; }
+		pushed += v;
+	}
+	out[0] = __atomic_load_n(&g->x_links, __ATOMIC_RELAXED) + pushed; out[1] = __atomic_load_n(&g->x_exact, __ATOMIC_RELAXED); out[2] = g->t; out[3] = g->push ? XP_PUSH : g->xp;
+	return 0;
+}
 extern "C" int bfcg_group_info(bfcg_group_t *g, int out[6])
 {
-	out[0] = g->n_ranks; out[1] = g->n_local; out[2] = g->xp; out[3] = g->rec_bytes; out[4] = g->nb1; out[5] = g->first;
+	out[0] = g->n_ranks; out[1] = g->n_local; out[2] = g->push ? XP_PUSH : g->xp; out[3] = g->rec_bytes; out[4] = g->nb1; out[5] = g->first;
 	return 0;
 }
 extern "C" int bfcg_group_slab_mode(bfcg_group_t *g) { return g->slabs; }
@@ -676,6 +767,8 @@ extern "C" int bfcg_group_reset(bfcg_group_t *g)
 	g->t = 0;
 	for (auto &R : g->r) memset(R.batch_call, 0, sizeof(R.batch_call));
 	g->slabs = g->slabs_ok;
+	g->x_links = g->x_exact = 0;
+	for (auto &R : g->r) if (R.d_moved && (hipSetDevice(R.device) != hipSuccess || hipMemset(R.d_moved, 0, sizeof(unsigned long long)) != hipSuccess)) { bfcg_set_error("clearing the push counter failed"); return -1; }
 	return 0;
 }
 // one rank per process: every process learns whether any of them has failed (one word per rank, all-gathered; the rank threads are idle)

@@ -175,7 +175,10 @@ typedef struct bfcg_group bfcg_group_t;
 int bfcg_group_unique_id(uint8_t uid[BFCG_UID_BYTES]);
 bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks, int first_rank, int n_local, const int *devices, const uint8_t *uid, int transport);
 void bfcg_group_destroy(bfcg_group_t *g);
-int bfcg_group_info(bfcg_group_t *g, int out[6]);     /* n_ranks, n_local, transport in use (1 RCCL, 2 peer copies), bytes per record, 2^F1, first rank */
+int bfcg_group_info(bfcg_group_t *g, int out[6]);     /* n_ranks, n_local, transport in use (1 RCCL, 2 peer copies, 3 peer copies with the PUSH kernel for exact sizes), bytes per record, 2^F1, first rank */
+/* out[0] bytes the local ranks put on the links since creation / the last reset (blocks and messages as sent), out[1] the bytes of the live records
+ * among them (what an exact exchange moves; transport 3 moves exactly these + the rows), out[2] global batches, out[3] transport.  Drains the exchange. */
+int bfcg_group_exchange_bytes(bfcg_group_t *g, uint64_t out[4]);
 bfcg_ctx_t *bfcg_group_ctx(bfcg_group_t *g, int i);  /* local rank i's context (statistics, exports of its slice); owned by the group */
 int bfcg_group_slab_mode(bfcg_group_t *g);           /* 1: stage A runs in one pass into slabs; 0: two passes (never possible, switched off, or a slab overflowed in this run) */
 uint64_t bfcg_group_lazy_batches(bfcg_group_t *g);   /* global batches since creation whose exchange and stage B were enqueued before the host saw any size (slab mode; in-process and multi-process groups alike -- the processes agree on it through the set-up's all-gather, bit 1 of its first word) */

@@ -48,8 +48,8 @@ if has bench; then
 fi
 if has ab; then
   for v in A B ${AB_MORE:-}; do
-    eval "envs=\$ENV_$v"
-    env $envs timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary ${AB_ARGS:---no-secondary} > gpurun_out/r6_ab_$v.json 2> gpurun_out/r6_ab_$v.log; echo "ab $v ($envs) rc=$?"
+    eval "envs=\$ENV_$v"; eval "xargs_=\$ARGS_$v"
+    env ${envs:-X=1} timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-boundary ${AB_ARGS:---no-secondary} $xargs_ > gpurun_out/r6_ab_$v.json 2> gpurun_out/r6_ab_$v.log; echo "ab $v ($envs $xargs_) rc=$?"
     summ gpurun_out/r6_ab_$v.json
   done
 fi

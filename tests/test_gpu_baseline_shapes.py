@@ -154,6 +154,19 @@ def test_c4_eighth_full_geometry(gpu_lib):
     g.close()
 
 
+@pytest.mark.skipif("c4e_k55" not in BASE, reason="tests/golden/baseline.json has no c4e_k55 entry (make_baseline_goldens.py c4e_k55)")
+def test_c4_eighth_at_the_published_k55(gpu_lib):
+    """The reference's one published command line, `bfc -s 3g -k55` (tex/README.md:26, tex/bfc.tex:189), on the eighth of 30x human: k=55, -b37, TABLE
+    mode -- 20-byte records, 2^24 sub-tables after the clamp (htab.c:19-34), the lossy key of k >= 38 (htab.c:45-58: different k-mers may share a
+    slot, their counts add).  Totals, distinct keys, both histograms and the filter equal the reference's (tests/golden/baseline.json[c4e_k55])."""
+    e = BASE["c4e_k55"]
+    rs = gen.ReadSet(**e["gen"])
+    g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 16_777_216)
+    assert g.mg_info()["rec_bytes"] == 20
+    _check_against(g, e, l1=False)
+    g.close()
+
+
 def test_c5_parameters(gpu_lib):
     """`-s 3g -k51 -1`: k=51, -b37, filter mode (two 16 GiB filters with both slices of a region in LDS, 20-byte records)."""
     e = BASE["c5s"]

@@ -47,12 +47,54 @@ def test_group_host_batches(gpu_lib, g1, n_ranks, k, b, fm):
     oc = _oracle(k, b, seq, qual, off, filter_mode=fm)
     n = rs.n_reads
     grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=(n // 3 + 2) * (rs.L + 1) // n_ranks + 4096, filter_mode=fm)
-    assert grp.info()["transport"] == ("peer" if n_ranks > 1 else "rccl")
+    assert grp.info()["transport"] == ("push" if n_ranks > 1 else "rccl")  # (ranks that share a device: peer copies, lazy batches by the push kernel)
     for a in range(0, n, n // 3 + 1):
         e = min(n, a + n // 3 + 1)
         grp.count_host(gen.to_stream(seq[a * rs.L:e * rs.L], rs.L, 10), gen.to_stream(qual[a * rs.L:e * rs.L], rs.L, 33))
     _compare(grp, oc, fm)
     grp.close(); oc.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_group_push_kernel_moves_exactly_the_records(gpu_lib, n_ranks, monkeypatch):
+    """Round 6: with the PUSH transport one kernel per rank and global batch writes the filled part of every slab into its
+    owner's receive buffer (k_push_slabs: the fills are read on the device, the host still knows no size) -- the bytes on the links are the live
+    records' + the rows, where the whole-block copies of round 5 (transport 2) carry the slabs' unfilled ends.  Same filter, statistics and table
+    as the oracle's either way; the books (bfcg_group_exchange_bytes) say what travelled: (N - 1) / N of the k-mers x the record size, exactly."""
+    rng = np.random.default_rng(4300 + n_ranks)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L, n = 150, 120_000
+    genome = rng.choice(acgt, 30_000_000 + L)
+    seq = genome[(rng.integers(0, 30_000_000, n)[:, None] + np.arange(L)[None, :])].astype(np.uint8).reshape(-1)
+    seq[rng.integers(0, len(seq), 300)] = ord("N")
+    qual = rng.integers(33, 74, len(seq)).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    k, b = 33, 30
+    oc = _oracle(k, b, seq, qual, off)
+    books = {}
+    for transport in (3, 2):
+        grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=60_000 * (L + 1) // n_ranks + 4096, transport=transport)
+        assert grp.info()["slab_mode"] and grp.info()["transport"] == {3: "push", 2: "peer"}[transport]
+        for t in range(2):
+            a, e = t * 60_000, (t + 1) * 60_000
+            grp.count_host(gen.to_stream(seq[a * L:e * L], L, 10), gen.to_stream(qual[a * L:e * L], L, 33))
+        grp.sync()
+        assert grp.info()["lazy_batches"] == 2
+        books[transport] = grp.exchange_bytes()
+        _compare(grp, oc, 0)
+        grp.reset()
+        assert grp.exchange_bytes()["links"] == 0
+        grp.close()
+    rb = 12
+    n_kmers = oc.stats()["n_kmers"]
+    ex = books[3]["exact"]
+    assert ex == books[2]["exact"] and ex % rb == 0
+    # the hash deals the k-mers evenly: (N - 1) / N of them leave their rank
+    assert abs(ex / rb - n_kmers * (n_ranks - 1) / n_ranks) < 0.02 * n_kmers
+    rows = 2 * n_ranks * (n_ranks - 1) * 4 * ((1 << 7) // n_ranks * 8 + 2)  # (2 batches; -b30: 2^7 level-1 buckets; a row = the fills of a destination's slabs + 2 words)
+    assert books[3]["links"] == ex + rows, (books[3], rows)
+    assert books[2]["links"] > 1.2 * ex, "whole blocks carry the slabs' unfilled ends"
+    oc.close()
 
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 4])
