@@ -380,7 +380,7 @@ int bfc_ingest_planes_digest(const char *fn, uint64_t chunk_size, uint64_t cap, 
 			const uint64_t nw = (b.n_pos + 31) / 32;
 			++out[0]; out[1] += b.n_pos; out[6] += (uint64_t)b.packed;
 			if (!b.packed) bfcg_pack_planes(b.seq, b.has_qual ? b.qual : 0, 0, b.n_pos, b.n_pos, q, pl, pw);
-			for (p = 0; p < (b.has_qual ? 4 : 3); ++p) for (w = 0; w < nw; ++w) {
+			if (!getenv("BFC_INGEST_NOHASH")) for (p = 0; p < (b.has_qual ? 4 : 3); ++p) for (w = 0; w < nw; ++w) {
 				const uint32_t v = pl[(uint64_t)p * pw + w];
 				int k;
 				for (k = 0; k < 4; ++k) h[p] = (h[p] ^ ((v >> (8 * k)) & 0xff)) * 0x100000001b3ULL;

@@ -513,12 +513,28 @@ bfc_ch_t *bfc_ch_restore(const char *fn)
 /* ---- bit planes of a byte-stream batch (include/bfc_gpu.h: bfcg_count_batch_planes) -- what count.c:72-89 reads of a position ---- */
 #include "bfc_planes.h"
 uint64_t bfcg_plane_words(uint64_t n_pos) { return (n_pos + 31) / 32 + 2; } /* (two spare words: the device reads a word ahead) */
+#if BFC_PLANES_HAVE_AVX2
+__attribute__((target("avx2"))) static uint64_t pack_words_avx2(const uint8_t *seq, const uint8_t *qual, uint64_t w, uint64_t hi, bfc_qthr_t t, uint32_t *planes, uint64_t plane_words)
+{
+	uint32_t m[4];
+	for (; ((w + 1) << 5) <= hi; ++w) { /* whole words: 32 positions a step, one store per plane */
+		bfc_planes32_avx2(seq + (w << 5), qual ? qual + (w << 5) : 0, t, 32, m);
+		planes[w] = m[0]; planes[plane_words + w] = m[1]; planes[2 * plane_words + w] = m[2];
+		if (qual) planes[3 * plane_words + w] = m[3];
+	}
+	return w;
+}
+#endif
 void bfcg_pack_planes(const uint8_t *seq, const uint8_t *qual, uint64_t lo, uint64_t hi, uint64_t n_pos, int q, uint32_t *planes, uint64_t plane_words)
 {
 	const bfc_qthr_t t = bfc_qthr(q);
 	uint64_t w;
 	if (hi > n_pos) hi = n_pos;
-	for (w = lo >> 5; (w << 5) < hi; ++w) {
+	w = lo >> 5;
+#if BFC_PLANES_HAVE_AVX2
+	if (bfc_planes_avx2_ok()) w = pack_words_avx2(seq, qual, w, hi, t, planes, plane_words);
+#endif
+	for (; (w << 5) < hi; ++w) {
 		const uint64_t p0 = w << 5;
 		const int n = hi - p0 < 32 ? (int)(hi - p0) : 32;
 		uint32_t m0 = 0, m1 = 0, mn = n < 32 && hi == n_pos ? ~0u << n : 0u, mq = 0, m[4]; /* beyond the batch's end: separators */

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ line reader over zlib */
 
@@ -314,6 +315,30 @@ static inline void bw_put(bitw_t *s, const uint32_t m[4], int n)
 	s->off += n;
 	if (s->off >= 32) bw_flush(s);
 }
+#if BFC_PLANES_HAVE_AVX2
+/* fq_pack's record loop, 32 positions a step (bfc_planes32_avx2); a read's tail is one masked step where 32 bytes are readable behind it */
+__attribute__((target("avx2"))) static void fq_pack_records_avx2(fq_job_t *j, bitw_t *s, bfc_qthr_t t, const uint32_t sep[4])
+{
+	const uint8_t *const wend = j->base + j->win_end;
+	uint64_t i;
+	for (i = 0; i < j->n_copy; ++i) {
+		const uint8_t *sq = j->base + j->rec[i].hdr + j->rec[i].seq_delta;
+		const uint32_t l = j->rec[i].len;
+		const uint8_t *pl = sq + l + (sq[l] == '\r' ? 2 : 1);
+		const uint8_t *ql = fq_eol(pl, wend) + 1;
+		uint32_t k = 0, m[4];
+		for (; k + 32 <= l; k += 32) { bfc_planes32_avx2(sq + k, ql + k, t, 32, m); bw_put(s, m, 32); }
+		if (k < l) {
+			if (ql + k + 32 <= wend) { bfc_planes32_avx2(sq + k, ql + k, t, (int)(l - k), m); bw_put(s, m, (int)(l - k)); }
+			else {
+				for (; k + 8 <= l; k += 8) { bfc_planes8(sq + k, ql + k, t, m); bw_put(s, m, 8); }
+				for (; k < l; ++k) { bfc_planes1(sq[k], ql + k, t, m); bw_put(s, m, 1); }
+			}
+		}
+		bw_put(s, sep, 1);
+	}
+}
+#endif
 static void *fq_pack(void *arg)
 {
 	fq_job_t *j = (fq_job_t*)arg;
@@ -325,6 +350,10 @@ static void *fq_pack(void *arg)
 	for (i = 0; i < j->n_copy; ++i) n_pos += j->rec[i].len + 1;
 	s.pl = j->pl; s.pw = j->pw; s.w = j->opos >> 5; s.w_first = s.w; s.w_last = (j->opos + n_pos - 1) >> 5; s.off = (int)(j->opos & 31);
 	s.a[0] = s.a[1] = s.a[2] = s.a[3] = 0;
+#if BFC_PLANES_HAVE_AVX2
+	if (bfc_planes_avx2_ok()) { fq_pack_records_avx2(j, &s, t, sep); i = j->n_copy; }
+	else
+#endif
 	for (i = 0; i < j->n_copy; ++i) {
 		const uint8_t *sq = j->base + j->rec[i].hdr + j->rec[i].seq_delta;
 		const uint32_t l = j->rec[i].len;
@@ -535,7 +564,9 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 			if (j->lo >= wend) { T = i; break; }
 		}
 		if (T == 0) return 1; /* nothing left: an empty batch */
+		{ struct timespec t0_, t1_; static int tm_ = -1; if (tm_ < 0) tm_ = getenv("BFC_INGEST_TIMING") != 0; if (tm_) clock_gettime(CLOCK_MONOTONIC, &t0_);
 		fq_run(f, fq_scan, T);
+		if (tm_) { clock_gettime(CLOCK_MONOTONIC, &t1_); fprintf(stderr, "[T::fq] scan of %.1f MB by %d threads: %.1f ms\n", (double)(wend - f->pos) / 1e6, T, (t1_.tv_sec - t0_.tv_sec) * 1e3 + (t1_.tv_nsec - t0_.tv_nsec) / 1e6); } }
 		/* chain the walks */
 		for (i = 0; i < T && !cut; ++i) { /* records before the first thing that is not strict are still one chained walk */
 			fq_job_t *j = &f->job[i];
@@ -599,7 +630,9 @@ static inline int fq_fill_batch(fq_fast_t *f, batch_t *b, uint64_t chunk_size)
 				if (j->n_copy) { lastj = j; last_hdr = j->rec[j->n_copy - 1].hdr; }
 			}
 			if (n_used == 0) f->job[0].n_copy = 0;
+			{ struct timespec t0_, t1_; const int tm_ = getenv("BFC_INGEST_TIMING") != 0; if (tm_) clock_gettime(CLOCK_MONOTONIC, &t0_);
 			fq_run(f, to_planes ? fq_pack : fq_copy, n_used > 0 ? n_used : 1);
+			if (tm_) { clock_gettime(CLOCK_MONOTONIC, &t1_); fprintf(stderr, "[T::fq] %s of %llu positions by %d threads: %.1f ms\n", to_planes ? "pack" : "copy", (unsigned long long)o, n_used, (t1_.tv_sec - t0_.tv_sec) * 1e3 + (t1_.tv_nsec - t0_.tv_nsec) / 1e6); } }
 			if (to_planes) {
 				if (o & 31) b->planes[2 * b->plane_words + (o >> 5)] |= ~0u << (o & 31); /* beyond the batch's end: separators */
 				b->packed = 1;

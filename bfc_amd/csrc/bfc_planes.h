@@ -5,6 +5,7 @@
 #define BFC_PLANES_H
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 static const uint8_t bfc_plane_code[256] = { /* A C G T (either case) = 0 1 2 3; 4 = not a base */
 	4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
@@ -44,6 +45,40 @@ static inline void bfc_planes8(const uint8_t *seq, const uint8_t *qual, bfc_qthr
 		} else { int b; for (b = 0; b < 8; ++b) m[3] |= (uint32_t)((int)(int8_t)qual[b] >= t.T) << b; }
 	}
 }
+/* Thirty-two positions at once (x86 with AVX2, chosen at run time; round 6): a byte compare per letter after folding case, and ONE instruction -- the
+ * byte mask -- delivers 32 bits of a plane, where the 64-bit code above spends a multiplication per plane on eight.  The same planes word for word
+ * (tests/test_planes.py, tests/test_ingest.py compare them with the serial parser's).  `n` < 32 keeps the low n positions: the load still reads 32
+ * bytes, so the caller guarantees them readable (a read's tail reads on into its '+' line; the ingest checks against the end of its window). */
+#if defined(__x86_64__) && !defined(BFC_PLANES_NO_AVX2)
+#include <immintrin.h>
+#define BFC_PLANES_HAVE_AVX2 1
+__attribute__((target("avx2"))) static inline void bfc_planes32_avx2(const uint8_t *seq, const uint8_t *qual, bfc_qthr_t t, int n, uint32_t m[4])
+{
+	const __m256i x = _mm256_loadu_si256((const __m256i*)seq), u = _mm256_and_si256(x, _mm256_set1_epi8((char)0xDF));
+	const __m256i a = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('A')), c = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('C'));
+	const __m256i g = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('G')), tt = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('T'));
+	const uint32_t keep = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+	const uint32_t lo = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(c, tt)), hi = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(g, tt));
+	const uint32_t ok = (uint32_t)_mm256_movemask_epi8(a) | lo | hi;
+	m[0] = lo & keep; m[1] = hi & keep; m[2] = ~ok & keep; m[3] = 0;
+	if (qual) {
+		const __m256i y = _mm256_loadu_si256((const __m256i*)qual);
+		/* (signed char)qual >= T  <=>  qual > T - 1 as signed bytes; T - 1 < -128: always, T - 1 >= 127: never */
+		if (t.T - 1 < -128) m[3] = keep;
+		else if (t.T - 1 >= 127) m[3] = 0;
+		else m[3] = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(y, _mm256_set1_epi8((char)(t.T - 1)))) & keep;
+	}
+}
+static inline int bfc_planes_avx2_ok(void)
+{
+	static int ok = -1;
+	if (ok < 0) ok = __builtin_cpu_supports("avx2") && !getenv("BFC_INGEST_NO_AVX2");
+	return ok;
+}
+#else
+#define BFC_PLANES_HAVE_AVX2 0
+#endif
+
 /* one position */
 static inline void bfc_planes1(uint8_t s, const uint8_t *qual, bfc_qthr_t t, uint32_t m[4])
 {

@@ -139,6 +139,22 @@ uint64_t bfcgen_fnv1a64_from(uint64_t h, const uint8_t *p, uint64_t n)
 	return h;
 }
 
+/* A digest of a bitmap that many threads can take (FNV-1a is a serial chain: 17 s for a 16 GiB filter, seven times in the GPU suite): the sum over the
+ * 64-bit little-endian words w_i of w_i * (i * 0x9E3779B97F4A7C15 | 1), modulo 2^64.  n must be a multiple of 8. */
+uint64_t bfcgen_mix64(const uint8_t *p, uint64_t n)
+{
+	const uint64_t nw = n / 8;
+	uint64_t sum = 0;
+	int64_t i;
+#pragma omp parallel for reduction(+:sum) schedule(static)
+	for (i = 0; i < (int64_t)nw; ++i) {
+		uint64_t w;
+		memcpy(&w, p + 8 * (uint64_t)i, 8);
+		sum += w * (((uint64_t)i * 0x9E3779B97F4A7C15ULL) | 1ULL);
+	}
+	return sum;
+}
+
 #ifdef BFCGEN_MAIN
 int main(int argc, char **argv)
 {

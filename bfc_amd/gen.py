@@ -37,6 +37,8 @@ def _L():
         L.bfcgen_popcount.argtypes = [C.c_void_p, C.c_uint64]
         L.bfcgen_fnv1a64.restype = C.c_uint64
         L.bfcgen_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
+        L.bfcgen_mix64.restype = C.c_uint64
+        L.bfcgen_mix64.argtypes = [C.c_void_p, C.c_uint64]
         L.bfcgen_fnv1a64_from.restype = C.c_uint64
         L.bfcgen_fnv1a64_from.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64]
         _lib = L
@@ -124,3 +126,9 @@ def bitmap_checksums(bits):
     """(popcount, FNV-1a/64) of a bitmap, as SURVEY App. B.3 defines the bloom goldens."""
     bits = np.ascontiguousarray(bits, dtype=np.uint8)
     return int(_L().bfcgen_popcount(bits.ctypes.data, len(bits))), int(_L().bfcgen_fnv1a64(bits.ctypes.data, len(bits)))
+
+
+def bitmap_mix64(bits):
+    """The parallel digest of a bitmap (bfcgen_mix64): sum of its 64-bit words times position-dependent odd constants, modulo 2^64."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    return int(_L().bfcgen_mix64(bits.ctypes.data, len(bits)))

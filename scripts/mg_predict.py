@@ -1,0 +1,68 @@
+"""the scaling curve that cannot be measured (one GPU per lease), PREDICTED from runs whose N ranks share device 0.
+
+    python scripts/mg_predict.py [c3 c4e] > gpurun_out/round6_mg_predicted.md
+
+Per workload and N in 1, 2, 4, 8: bench.py --gpus N with BFC_BENCH_DEVICES=0,0,... (all ranks in this process, records by the push kernel between ranks
+that share the device), strong scaling, verified against the reference's answers.  Reported: the sum of the ranks' kernel time per step (what N real GPUs
+would each spend 1/N of) against the 1-GPU run's -- the work inflation of owner-computes: N times smaller batches per rank, every rank sweeping its share
+of the filter per global batch --, the bytes a rank puts on its links per step (as sent, and the live records alone), the time those take on N - 1 xGMI links
+at 153 GB/s and at half of it, and the step time and efficiency that follow if the exchange overlaps the kernels as designed.  A model, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+wls = sys.argv[1:] or ["c3", "c4e"]
+out = []
+for wl in wls:
+    rows = []
+    base = None
+    for n in (1, 2, 4, 8):
+        env = dict(os.environ)
+        if n > 1:
+            env["BFC_BENCH_DEVICES"] = ",".join(["0"] * n)
+        else:
+            env["BFC_BENCH_FORCE_GROUP"] = "1"  # a group of one: the same code path
+        for tr in ((0,) if n == 1 else (0, 2)):  # default (push kernel: exact bytes) and whole-block peer copies
+            env["BFC_BENCH_TRANSPORT"] = str(tr)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                                "--no-boundary", "--no-secondary"], capture_output=True, text=True, env=env)
+            try:
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception:  # noqa: BLE001
+                print("run failed:", wl, n, tr, r.stderr[-400:], file=sys.stderr)
+                continue
+            if d.get("error"):
+                print("run failed:", wl, n, tr, d["error"], file=sys.stderr)
+                continue
+            st = d["config"]["stage_ms_per_step"]
+            m = d.get("multi_gpu_model") or {}
+            ksum = m.get("sum_of_kernel_ms_over_ranks_per_step", st["total"])
+            if n == 1:
+                base = ksum
+            rows.append(dict(n=n, transport=m.get("transport", "-"), ms=d["ms_per_step"], verified=d.get("verified"), ksum=ksum, stage={k: round(v * (n if n > 1 else 1), 1) for k, v in st.items()},
+                             links=(m.get("exchange_bytes_per_rank_per_step") or {}).get("links", 0), exact=(m.get("exchange_bytes_per_rank_per_step") or {}).get("exact", 0),
+                             x_ms=m.get("xgmi_ms_per_step_at_link_peak") or {}, batches=d["config"]["batches_per_step"], lib=d["config"]["library_batches_per_step"]))
+    out.append((wl, base, rows))
+    print("[mg_predict]", wl, "done", file=sys.stderr, flush=True)
+
+print("# Round 6 -- the scaling curve PREDICTED from ranks emulated on one MI355X (scripts/mg_predict.py; a model, not a measurement)\n")
+for wl, base, rows in out:
+    print("## %s, strong scaling (one read set, every global batch split over the ranks), every run verified against the reference's answers\n" % wl)
+    print("| N | transport | wall ms per step, all ranks on ONE device | verified | sum of the ranks' kernel ms | work inflation vs N = 1 | kernel ms per rank on N GPUs | bytes out per rank and step: as sent / live records | "
+          "their time on N - 1 links at 153 GB/s: as sent / live | predicted ms per step (exchange at half the link rate) | predicted speed-up over one GPU | efficiency |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        n = r["n"]
+        infl = r["ksum"] / base if base else float("nan")
+        kr = r["ksum"] / n
+        xl, xe = r["x_ms"].get("links", 0.0), r["x_ms"].get("exact", 0.0)
+        pred = max(kr, 2 * xl)
+        sp = base / pred if base else float("nan")
+        print("| %d | %s | %.1f | %s | %.1f | %.2f | %.1f | %.2f / %.2f GB | %.1f / %.1f ms | %.1f | %.2f | %.2f |" % (
+            n, r["transport"], r["ms"], r["verified"], r["ksum"], infl, kr, r["links"] / 1e9, r["exact"] / 1e9, xl, xe, pred, sp, sp / n))
+    print()
+    for r in rows:
+        print("* N = %d (%s): stage ms summed over the ranks %s; %d global batches, %.1f library batches per rank and step" % (r["n"], r["transport"], r["stage"], r["batches"], r["lib"]))
+    print()

@@ -53,3 +53,20 @@ if has ab; then
     summ gpurun_out/r6_ab_$v.json
   done
 fi
+if has e2e; then  # the boundary under the parser's phase clocks (BFC_INGEST_TIMING): the whole c3 file through bfc-dropin, from the file and from a pipe
+  python - <<PY
+import sys, time; sys.path.insert(0,'.')
+from bfc_amd import gen
+t=time.time(); rs = gen.ReadSet(seed=3, G=248_000_000, cov=30)
+rs.fastq_parallel('/dev/shm/c3e.fq', 0, min(${READS:-49600000}, rs.n_reads), threads=32); print('written in %.1f s' % (time.time()-t))
+PY
+  export BFC_GPU_TIMING=1
+  for t in ${E2E_TS:-64 64 32}; do echo "== file, -t$t"; ( time BFC_INGEST_TIMING=1 oracle/_ref/bfc-dropin -E -s 250m -k 33 -t$t /dev/shm/c3e.fq ) 2>&1 | grep -E "^real|T::|Real time" | tail -60; sleep 2; done > gpurun_out/r6_e2e.txt 2>&1
+  for t in 64 64; do echo "== pipe, -t$t"; ( time sh -c "cat /dev/shm/c3e.fq | oracle/_ref/bfc-dropin -E -s 250m -k 33 -t$t -" ) 2>&1 | grep -E "^real|T::bfc|Real time" | tail -12; sleep 2; done >> gpurun_out/r6_e2e.txt 2>&1
+  echo "== pipe, old serial path (BFC_INGEST_NO_PIPE=1), first 8 M reads" >> gpurun_out/r6_e2e.txt
+  ( time sh -c "head -c 2500000000 /dev/shm/c3e.fq | BFC_INGEST_NO_PIPE=1 oracle/_ref/bfc-dropin -E -s 250m -k 33 -t64 -" ) 2>&1 | grep -E "^real|T::bfc_count\] waited|Real time" >> gpurun_out/r6_e2e.txt
+  rm -f /dev/shm/c3e.fq; grep -E "==|Real time|^real|waited" gpurun_out/r6_e2e.txt; grep "T::fq" gpurun_out/r6_e2e.txt | head -12
+fi
+if has emu; then  # the predicted scaling table: ranks emulated on this one device
+  timeout 2400 python scripts/mg_predict.py ${EMU_W:-c3 c4e} > gpurun_out/round6_mg_predicted.md 2> gpurun_out/r6_emu.log; echo "emu rc=$?"; cat gpurun_out/round6_mg_predicted.md; tail -3 gpurun_out/r6_emu.log
+fi

@@ -41,13 +41,17 @@ def _count_fixed(gpu_lib, rs, k, b, batch_reads, filter_mode=0, **kw):
 def _check_against(g, e, l1=True):
     st = g.stats()
     assert (st["n_kmers"], st["n_high"], st["n_seen"]) == (e["n_kmers"], e["n_high"], e["n_seen"]), (st, e["name"] if "name" in e else e["fixture"])
-    pop, fnv = gen.bitmap_checksums(g.bloom_bytes())
-    want_fnv = e["bf_fnv1a64"] if isinstance(e["bf_fnv1a64"], int) else int(e["bf_fnv1a64"], 16)
-    assert (pop, fnv) == (e["bf_popcount"], want_fnv), "first bloom filter differs from the reference's (L0)"
+    def same_filter(bits, pfx):
+        # an entry that carries the parallel digest of the reference's filter (bf_mix64, round 6: bfcgen_mix64 -- every 64-bit word times a constant of its
+        # position, summed) is compared through it and the popcount: FNV-1a is one serial chain, 17 s of a core for a 16 GiB filter, and bench.py still
+        # takes it for the same read sets after every run
+        if pfx + "_mix64" in e:
+            return (gen._L().bfcgen_popcount(bits.ctypes.data, len(bits)), "%016x" % gen.bitmap_mix64(bits)) == (e[pfx + "_popcount"], e[pfx + "_mix64"])
+        want = e[pfx + "_fnv1a64"] if isinstance(e[pfx + "_fnv1a64"], int) else int(e[pfx + "_fnv1a64"], 16)
+        return gen.bitmap_checksums(bits) == (e[pfx + "_popcount"], want)
+    assert same_filter(g.bloom_bytes(), "bf"), "first bloom filter differs from the reference's (L0)"
     if e["filter_mode"]:
-        pop, fnv = gen.bitmap_checksums(g.bloom_bytes(1))
-        want_fnv = e["bf_high_fnv1a64"] if isinstance(e["bf_high_fnv1a64"], int) else int(e["bf_high_fnv1a64"], 16)
-        assert (pop, fnv) == (e["bf_high_popcount"], want_fnv), "second bloom filter (bfc -1) differs from the reference's"
+        assert same_filter(g.bloom_bytes(1), "bf_high"), "second bloom filter (bfc -1) differs from the reference's"
         return st
     t = g.export_table()
     assert t.count() == e["distinct"] == st["n_keys"]
@@ -114,10 +118,10 @@ def test_c3_full_read_set(gpu_lib):
 
 def test_c3_shape_host_layout(gpu_lib):
     """The same geometry with the table in the host's layout from the start (random-CAS upserts, STREAM decisions, table growth by
-    rehash) on the first 12 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
+    rehash) on the first 5 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
     e = dict(gen=dict(seed=3, G=248_000_000, cov=30.0), k=33, b=35)
     rs = gen.ReadSet(**e["gen"])
-    rs.n_reads = 12_000_000
+    rs.n_reads = 5_000_000  # (12 M until round 5: 43 s of the suite; two batches and a table growth are what the comparison needs)
     res = []
     for layout in (0, 1):
         g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584, table_layout=layout)
@@ -129,6 +133,7 @@ def test_c3_shape_host_layout(gpu_lib):
     assert res[0] == res[1]
 
 
+@pytest.mark.skipif("c4e" in BASE, reason="c4's geometry is held to the reference on an eighth of c4 itself (test_c4_eighth_full_geometry); this smaller read set only where that golden is absent")
 def test_c4_parameters(gpu_lib):
     """`-s 3g`: k=33, -b37 in table mode (16 GiB filter, 2^20 regions, 10+10 scatter levels) on a 20 Mbp genome at 30x."""
     e = BASE["c4s"]
@@ -167,6 +172,7 @@ def test_c4_eighth_at_the_published_k55(gpu_lib):
     g.close()
 
 
+@pytest.mark.skipif("c5e" in BASE, reason="c5's geometry is held to the reference on an eighth of c5 itself (test_c5_eighth_full_geometry_count_and_trim); this smaller read set only where that golden is absent")
 def test_c5_parameters(gpu_lib):
     """`-s 3g -k51 -1`: k=51, -b37, filter mode (two 16 GiB filters with both slices of a region in LDS, 20-byte records)."""
     e = BASE["c5s"]

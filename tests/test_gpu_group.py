@@ -75,6 +75,7 @@ def test_group_push_kernel_moves_exactly_the_records(gpu_lib, n_ranks, monkeypat
     for transport in (3, 2):
         grp = gpu_lib.GpuGroup(k, b, [0] * n_ranks, max_batch_pos=60_000 * (L + 1) // n_ranks + 4096, transport=transport)
         assert grp.info()["slab_mode"] and grp.info()["transport"] == {3: "push", 2: "peer"}[transport]
+        nb1 = grp.info()["nb1"]
         for t in range(2):
             a, e = t * 60_000, (t + 1) * 60_000
             grp.count_host(gen.to_stream(seq[a * L:e * L], L, 10), gen.to_stream(qual[a * L:e * L], L, 33))
@@ -91,7 +92,7 @@ def test_group_push_kernel_moves_exactly_the_records(gpu_lib, n_ranks, monkeypat
     assert ex == books[2]["exact"] and ex % rb == 0
     # the hash deals the k-mers evenly: (N - 1) / N of them leave their rank
     assert abs(ex / rb - n_kmers * (n_ranks - 1) / n_ranks) < 0.02 * n_kmers
-    rows = 2 * n_ranks * (n_ranks - 1) * 4 * ((1 << 7) // n_ranks * 8 + 2)  # (2 batches; -b30: 2^7 level-1 buckets; a row = the fills of a destination's slabs + 2 words)
+    rows = 2 * n_ranks * (n_ranks - 1) * 4 * (nb1 // n_ranks * 8 + 2)  # (2 batches; a row = the fills of a destination's nb1 / N x 8 slabs + 2 words)
     assert books[3]["links"] == ex + rows, (books[3], rows)
     assert books[2]["links"] > 1.2 * ex, "whole blocks carry the slabs' unfilled ends"
     oc.close()
