@@ -604,7 +604,7 @@ extern "C" bfcg_group_t *bfcg_group_create(const bfcg_params_t *prm, int n_ranks
 		for (int i = 0; i < n_local; ++i) for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) g->xp = XP_PEER;
 	// transport 3, or by default wherever ranks share a device (RCCL is out there anyway): the peer-copy transport with lazy batches PUSHED by k_push_slabs
 	// (exact bytes).  Distinct devices keep RCCL unless 3 is asked for: the push kernel has never run over xGMI (no two-GPU box in six rounds).
-	g->push = 0; g->push_wgs = 64; g->x_links = g->x_exact = 0;
+	g->push = 0; g->push_wgs = 32; g->x_links = g->x_exact = 0;
 	if (transport == XP_PUSH) { g->xp = XP_PEER; g->push = 1; }
 	else if (g->xp == XP_PEER && transport == 0) { const char *e = getenv("BFCG_MG_PUSH"); g->push = !(e && atoi(e) == 0); }
 	if (n_ranks > PUSH_MAX_RANKS) g->push = 0;

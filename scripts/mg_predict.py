@@ -3,9 +3,9 @@
     python scripts/mg_predict.py [c3 c4e] > gpurun_out/round6_mg_predicted.md
 
 Per workload and N in 1, 2, 4, 8: bench.py --gpus N with BFC_BENCH_DEVICES=0,0,... (all ranks in this process, records by the push kernel between ranks
-that share the device), strong scaling, verified against the reference's answers.  Reported: the sum of the ranks' kernel time per step (what N real GPUs
-would each spend 1/N of) against the 1-GPU run's -- the work inflation of owner-computes: N times smaller batches per rank, every rank sweeping its share
-of the filter per global batch --, the bytes a rank puts on its links per step (as sent, and the live records alone), the time those take on N - 1 xGMI links
+that share the device), strong scaling, verified against the reference's answers.  Reported: the step's wall time on the one device -- all N ranks' kernels side by side plus the copies that stand in for the links: what N real
+GPUs would each spend at most 1/N of (a rank's own HIP-event stage times are useless here: they contain the neighbours' kernels) -- against the 1-GPU
+run's: the work inflation of owner-computes (N times smaller batches per rank, every rank sweeping its share of the filter per global batch), the bytes a rank puts on its links per step (as sent, and the live records alone), the time those take on N - 1 xGMI links
 at 153 GB/s and at half of it, and the step time and efficiency that follow if the exchange overlaps the kernels as designed.  A model, not a measurement."""
 import json
 import os
@@ -14,6 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 wls = sys.argv[1:] or ["c3", "c4e"]
+EXTRA = {"c4e": ["--batch-reads", "8388608"]}  # (N contexts on ONE device: calls of 8.4 M reads instead of 16.8 M so that their buffers fit its 288 GB; the N = 1 row runs the same calls)
 out = []
 for wl in wls:
     rows = []
@@ -22,12 +23,10 @@ for wl in wls:
         env = dict(os.environ)
         if n > 1:
             env["BFC_BENCH_DEVICES"] = ",".join(["0"] * n)
-        else:
-            env["BFC_BENCH_FORCE_GROUP"] = "1"  # a group of one: the same code path
         for tr in ((0,) if n == 1 else (0, 2)):  # default (push kernel: exact bytes) and whole-block peer copies
             env["BFC_BENCH_TRANSPORT"] = str(tr)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                                "--no-boundary", "--no-secondary"], capture_output=True, text=True, env=env)
+                                "--no-boundary", "--no-secondary"] + EXTRA.get(wl, []), capture_output=True, text=True, env=env)
             try:
                 d = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception:  # noqa: BLE001
@@ -38,7 +37,7 @@ for wl in wls:
                 continue
             st = d["config"]["stage_ms_per_step"]
             m = d.get("multi_gpu_model") or {}
-            ksum = m.get("sum_of_kernel_ms_over_ranks_per_step", st["total"])
+            ksum = d["ms_per_step"]  # what ONE device needs for all N ranks' work (their kernels side by side + the copies that emulate the links): wall time
             if n == 1:
                 base = ksum
             rows.append(dict(n=n, transport=m.get("transport", "-"), ms=d["ms_per_step"], verified=d.get("verified"), ksum=ksum, stage={k: round(v * (n if n > 1 else 1), 1) for k, v in st.items()},
@@ -50,9 +49,9 @@ for wl in wls:
 print("# Round 6 -- the scaling curve PREDICTED from ranks emulated on one MI355X (scripts/mg_predict.py; a model, not a measurement)\n")
 for wl, base, rows in out:
     print("## %s, strong scaling (one read set, every global batch split over the ranks), every run verified against the reference's answers\n" % wl)
-    print("| N | transport | wall ms per step, all ranks on ONE device | verified | sum of the ranks' kernel ms | work inflation vs N = 1 | kernel ms per rank on N GPUs | bytes out per rank and step: as sent / live records | "
+    print("| N | transport | verified | wall ms per step, all N ranks on ONE device | work inflation vs N = 1 | device ms per rank on N GPUs (wall / N) | bytes out per rank and step: as sent / live records | "
           "their time on N - 1 links at 153 GB/s: as sent / live | predicted ms per step (exchange at half the link rate) | predicted speed-up over one GPU | efficiency |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         n = r["n"]
         infl = r["ksum"] / base if base else float("nan")
@@ -60,8 +59,8 @@ for wl, base, rows in out:
         xl, xe = r["x_ms"].get("links", 0.0), r["x_ms"].get("exact", 0.0)
         pred = max(kr, 2 * xl)
         sp = base / pred if base else float("nan")
-        print("| %d | %s | %.1f | %s | %.1f | %.2f | %.1f | %.2f / %.2f GB | %.1f / %.1f ms | %.1f | %.2f | %.2f |" % (
-            n, r["transport"], r["ms"], r["verified"], r["ksum"], infl, kr, r["links"] / 1e9, r["exact"] / 1e9, xl, xe, pred, sp, sp / n))
+        print("| %d | %s | %s | %.1f | %.2f | %.1f | %.2f / %.2f GB | %.1f / %.1f ms | %.1f | %.2f | %.2f |" % (
+            n, r["transport"], r["verified"], r["ksum"], infl, kr, r["links"] / 1e9, r["exact"] / 1e9, xl, xe, pred, sp, sp / n))
     print()
     for r in rows:
         print("* N = %d (%s): stage ms summed over the ranks %s; %d global batches, %.1f library batches per rank and step" % (r["n"], r["transport"], r["stage"], r["batches"], r["lib"]))

@@ -67,7 +67,9 @@ def test_gloo_two_ranks_equal_sequential(tmp_path):
     osz, osl = oc.export()
     assert np.array_equal(parts[0]["sizes"].astype(np.int64) + parts[1]["sizes"], osz)
     assert np.array_equal(np.sort(np.concatenate([parts[0]["slots"], parts[1]["slots"]])), np.sort(osl))
-    assert len(np.intersect1d(parts[0]["slots"] >> np.uint64(14), parts[1]["slots"] >> np.uint64(14))) >= 0  # keys may coincide across sub-tables only
+    # no (sub-table, key) pair is held by both owners: a key lives with the rank that owns its bloom region (keys alone may coincide, across sub-tables)
+    pairs = [np.repeat(np.arange(len(p["sizes"]), dtype=np.uint64), p["sizes"].astype(np.int64)) << np.uint64(50) | (p["slots"] >> np.uint64(14)) for p in parts]
+    assert len(pairs[0]) == len(parts[0]["slots"]) and len(np.intersect1d(pairs[0], pairs[1])) == 0
 
 
 @pytest.mark.gpu
