@@ -953,9 +953,14 @@ extern "C" bfc_ch_t *bfcg_group_export_table(bfcg_group_t *g)
 	if (g->n_local != g->n_ranks) { bfcg_set_error("bfcg_group_export_table needs every rank in this process (else: export per rank, bfc_ch_union)"); return NULL; }
 	std::vector<bfc_ch_t *> t;
 	bfc_ch_t *u = 0;
-	for (auto &R : g->r) { bfc_ch_t *x = bfcg_export_table(R.ctx); if (!x) break; t.push_back(x); }
+	char why[384] = "";
+	for (auto &R : g->r) {
+		bfc_ch_t *x = bfcg_export_table(R.ctx);
+		if (!x) { snprintf(why, sizeof(why), "rank %d's table could not be exported: %s", R.rank, bfcg_last_error()); break; } // (say which step failed: the union below used to hide it)
+		t.push_back(x);
+	}
 	if ((int)t.size() == g->n_local) u = g->n_local == 1 ? t[0] : bfc_ch_union((const bfc_ch_t *const *)t.data(), g->n_local);
-	if (!u) bfcg_set_error("union of the ranks' tables failed");
+	if (!u) bfcg_set_error(why[0] ? why : "union of the ranks' tables failed (tables of different geometry, or no host memory for the union)");
 	if (g->n_local > 1 || !u) for (auto x : t) bfc_ch_destroy(x);
 	return u;
 }

@@ -70,3 +70,19 @@ fi
 if has emu; then  # the predicted scaling table: ranks emulated on this one device
   timeout 2400 python scripts/mg_predict.py ${EMU_W:-c3 c4e} > gpurun_out/round6_mg_predicted.md 2> gpurun_out/r6_emu.log; echo "emu rc=$?"; cat gpurun_out/round6_mg_predicted.md; tail -3 gpurun_out/r6_emu.log
 fi
+if has prof; then  # traces + PMC passes of the headline workload on THIS build (bench.py's roofline.traffic reads profiles/round6_c3_pmc.json)
+  PMC=2 STEPS=1 bash scripts/prof_round2.sh c3 > gpurun_out/prof_c3.out 2>&1; tail -3 gpurun_out/prof_c3.out | cut -c1-200
+  ROUND=6 python tools/make_round_md.py gpurun_out/prof_c3 c3 > gpurun_out/round6_c3.md; cp profiles/round6_c3_pmc.json gpurun_out/ 2>/dev/null; head -20 gpurun_out/round6_c3.md | cut -c1-220
+fi
+if has prof2; then  # ... and of the secondaries the line carries
+  for w in ${PROF2_W:-c4e c2}; do
+    PMC=1 STEPS=${PROF2_STEPS:-2} BENCH_ARGS="--workload $w" bash scripts/prof_round2.sh $w > gpurun_out/prof_$w.out 2>&1; tail -2 gpurun_out/prof_$w.out | cut -c1-200
+    ROUND=6 python tools/make_round_md.py gpurun_out/prof_$w $w > gpurun_out/round6_$w.md; cp profiles/round6_${w}_pmc.json gpurun_out/ 2>/dev/null
+  done
+fi
+if has proftrim; then  # config c5's query pass as bench.py runs it (count pass of c5e, then the trim leg), under the kernel trace
+  export TMPDIR=/tmp; mkdir -p gpurun_out/prof_c5e_trim
+  timeout -k 5 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c5e_trim/t -o p -- python bench.py --workload c5e --steps 1 --warmup 0 --no-cpu-baseline --no-boundary --no-secondary > gpurun_out/prof_c5e_trim/t.log 2>&1; echo "proftrim rc=$?"
+  python tools/rocpd_stats.py gpurun_out/prof_c5e_trim/t/p_results.db | cut -c1-170 | head -14 | tee gpurun_out/round6_c5e_trim_kernels.txt
+  grep '"metric"' gpurun_out/prof_c5e_trim/t.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(d.get('trim')))" | tee -a gpurun_out/round6_c5e_trim_kernels.txt | cut -c1-600
+fi
