@@ -1340,9 +1340,10 @@ static int enqueue_batch(bfcg_ctx_t *c, const uint8_t *d_seq, const uint8_t *d_q
 	if (op) {
 		Bt.op_cursor = c->op_cursor[b]; Bt.op_seg = c->op_seg[b]; Bt.op_flags = c->op_flags + 4 * b; Bt.op_cap = c->op_cap;
 		Bt.cnt2 = c->cnt2; Bt.cap2 = c->cap2;
-		{ // level 2 on tiles of 8192 records where a tile of 4096 would leave as runs of four (2^10 regions per bucket); BFCG_L2_BIG=0: never, =1: from 2^9 on
+		{ // level 2 on tiles of 8192 records where a tile of 4096 would leave as runs of four (2^10 regions per bucket): BFCG_L2_BIG=2; =1: from 2^9 on.  OFF by default:
+		  // measured level with the small tile on c4e (64.9 against 62.3 ms per step: DESIGN 6b) -- the kernel's rate there is not set by the run length
 			const char *e = getenv("BFCG_L2_BIG");
-			const int want = e ? atoi(e) : 2;
+			const int want = e ? atoi(e) : 0;
 			Pt.l2_big = c->rw == 12 && c->cap2 && want > 0 && Pt.F2 >= (want == 1 ? 9 : 10);
 		}
 		run_stage_a_onepass(Pt, Bt, d_seq, d_qual, (int64_t)n_pos, Bt.recs1, sA, c->evt[b]);
