@@ -86,3 +86,14 @@ if has proftrim; then  # config c5's query pass as bench.py runs it (count pass 
   python tools/rocpd_stats.py gpurun_out/prof_c5e_trim/t/p_results.db | cut -c1-170 | head -14 | tee gpurun_out/round6_c5e_trim_kernels.txt
   grep '"metric"' gpurun_out/prof_c5e_trim/t.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(d.get('trim')))" | tee -a gpurun_out/round6_c5e_trim_kernels.txt | cut -c1-600
 fi
+if has d2h; then  # the table's way back with more copy threads (BFC_GPU_D2H_THREADS; default 8): the whole c3 file through bfc-dropin
+  python - <<PY
+import sys; sys.path.insert(0,'.')
+from bfc_amd import gen
+rs = gen.ReadSet(seed=3, G=248_000_000, cov=30)
+rs.fastq_parallel('/dev/shm/c3e.fq', 0, rs.n_reads, threads=32)
+PY
+  export BFC_GPU_TIMING=1
+  for t in 8 16 24 8 16 24; do echo "== BFC_GPU_D2H_THREADS=$t"; BFC_GPU_D2H_THREADS=$t oracle/_ref/bfc-dropin -E -s 250m -k 33 -t64 /dev/shm/c3e.fq 2>&1 | grep -E "Real time|export_table|left " | cut -c1-200; sleep 2; done > gpurun_out/r6_d2h.txt 2>&1
+  rm -f /dev/shm/c3e.fq; cat gpurun_out/r6_d2h.txt
+fi

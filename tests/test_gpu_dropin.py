@@ -148,6 +148,42 @@ def test_dropin_trim_mode_and_stdin(g1_fq):
 
 
 @needs_dropin
+@pytest.mark.parametrize("how", ["stdin_pipe", "fifo", "fifo_serial"])
+def test_dropin_reads_a_pipe(g1_fq, tmp_path, how):
+    """The published command line feeds bfc `<(seqtk mergepe ...)` (tex/README.md:26): a PIPE.  Through the reference's unmodified main(): `cat g1.fq | bfc-dropin ... -` and a named
+    FIFO take the ring + multi-threaded FASTQ path (round 6; `-t 4`), `fifo_serial` the old serial parser (BFC_INGEST_NO_PIPE=1) -- the same dump as from the file, L1-identical
+    to `bfc -t1 -d`, the same `# distinct k-mers` line."""
+    import threading
+    dump = str(tmp_path / "p.hash")
+    args = ["-E", "-k", "31", "-b", "26", "-t", "4", "-d", dump]
+    env = dict(os.environ, BFC_GPU_TIMING="1")
+    if how == "stdin_pipe":
+        cat = subprocess.Popen(["cat", g1_fq], stdout=subprocess.PIPE)
+        r = subprocess.run([DROPIN] + args + ["-"], stdin=cat.stdout, capture_output=True, timeout=600, env=env)
+        cat.wait()
+    else:
+        if how == "fifo_serial":
+            env["BFC_INGEST_NO_PIPE"] = "1"
+        fifo = str(tmp_path / "in.fifo")
+        os.mkfifo(fifo)
+        data = open(g1_fq, "rb").read()
+
+        def feed():
+            with open(fifo, "wb") as f:
+                for i in range(0, len(data), 50_000):
+                    f.write(data[i:i + 50_000])
+        th = threading.Thread(target=feed)
+        th.start()
+        r = subprocess.run([DROPIN] + args + [fifo], capture_output=True, timeout=600, env=env)
+        th.join()
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"# distinct k-mers: 99561" in r.stderr
+    assert (b"a pipe: reader thread into a ring" in r.stderr) == (how != "fifo_serial"), r.stderr.decode()[-1500:]
+    k, l_pre, sizes, slots = oracle.parse_dump(dump)
+    assert (k, l_pre) == (31, 20) and oracle.l1_digest(sizes, slots) == "237be10261b07ef0677f8136b0a327b6"
+
+
+@needs_dropin
 def test_dropin_dump_restores_in_reference(g1_fq, tmp_path):
     """-d dump written by this library: L1-identical to `bfc -t1 -d`, and the *reference* restores it (-r) and
     corrects with it to the same bytes."""
