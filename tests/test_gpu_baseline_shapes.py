@@ -118,10 +118,10 @@ def test_c3_full_read_set(gpu_lib):
 
 def test_c3_shape_host_layout(gpu_lib):
     """The same geometry with the table in the host's layout from the start (random-CAS upserts, STREAM decisions, table growth by
-    rehash) on the first 5 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
+    rehash) on the first 4 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
     e = dict(gen=dict(seed=3, G=248_000_000, cov=30.0), k=33, b=35)
     rs = gen.ReadSet(**e["gen"])
-    rs.n_reads = 5_000_000  # (12 M until round 5: 43 s of the suite; two batches and a table growth are what the comparison needs)
+    rs.n_reads = 4_000_000  # (12 M until round 5: 43 s of the suite; two batches and a table growth are what the comparison needs)
     res = []
     for layout in (0, 1):
         g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584, table_layout=layout)
@@ -375,7 +375,7 @@ def test_clean_batch_followed_by_an_overflowing_one(gpu_lib, monkeypatch, fm):
     rng = np.random.default_rng(4242 + fm)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     L, k, b = 150, 31, 30
-    n1, n2, n3 = 500_000, 150_000, 1_500
+    n1, n2, n3 = 300_000, 150_000, 1_500
     genome = rng.choice(acgt, 40_000_000 + L)
     small = rng.choice(acgt, 400 + L)
     p1 = rng.integers(0, 40_000_000, n1); p2 = rng.integers(0, 400, n2); p3 = rng.integers(0, 40_000_000, n3)

@@ -88,12 +88,12 @@ def _check(gpu_lib, prm, seq, qual, off, cuts, kw, planes=False):
     return info
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(90))
 def test_random_configuration(gpu_lib, seed):
     _check(gpu_lib, *_draw(1000 + seed))
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_configuration_through_bit_planes(gpu_lib, seed):
     """the same draws handed over as bit planes (bfcg_count_batch_planes: 4 bits per position over PCIe): any byte value in sequence and quality,
     thresholds from -50 to 100 (beyond what a signed char can reach on either side), records without qualities, pieces that begin at any bit"""
@@ -109,7 +109,7 @@ def test_bit_planes_oversized_batches_are_cut(gpu_lib, seed):
 
 
 @pytest.mark.parametrize("blk", ["3", "5", "7"])
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_configuration_segments_of_several_blocks(gpu_lib, seed, blk, monkeypatch):
     """table segments beyond what a CU's LDS holds are several BLOCKS, one workgroup each (KParams.seg_blk): with BFCG_SEG_BLOCK = 3 / 5 / 7 a block
     is 8 / 32 / 128 slots instead of 2^14, so these small draws grow their segments across the block boundary several times (rehash block by
@@ -158,7 +158,7 @@ def test_random_configuration_large_filters(gpu_lib, seed):
     _check(gpu_lib, *_draw(30000 + seed, scale=4, b_range=(28, 34)))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(30))
 def test_random_configuration_one_pass_partition(gpu_lib, seed, monkeypatch):
     """the one-pass partition (bucket slabs + cursors) on draws it would normally leave to the two-pass one: with
     BFCG_ONEPASS_MIN_TILES=1 every batch of a filter of 2^26 bits and more goes through it, however few records a slab expects -- slabs
@@ -169,7 +169,7 @@ def test_random_configuration_one_pass_partition(gpu_lib, seed, monkeypatch):
     _check(gpu_lib, *_draw(40000 + seed, scale=12, b_range=(26, 32)))
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(15))
 @pytest.mark.parametrize("chunk", [3, 32])
 def test_random_configuration_chunked_reservations(gpu_lib, seed, chunk, monkeypatch):
     """level 1 of the one-pass partition reserves room in its slabs in CHUNKS (round 3: a run goes into what is left of the workgroup's last
@@ -181,7 +181,7 @@ def test_random_configuration_chunked_reservations(gpu_lib, seed, chunk, monkeyp
     _check(gpu_lib, *_draw(45000 + seed, scale=12, b_range=(26, 32)))
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_configuration_k33_on_tiny_slabs(gpu_lib, seed, monkeypatch):
     """The default path's own geometry -- k > 32 with 12-byte records (k = 33 and 35 put onto the draws; where 35 needs 16-byte records the
     generic kernels run): K1 on 32-bit halves, the 32-bit decode of k_bloom3 with its block marks and worklists, the hand-over log -- forced
@@ -193,7 +193,7 @@ def test_random_configuration_k33_on_tiny_slabs(gpu_lib, seed, monkeypatch):
     _check(gpu_lib, prm, seq, qual, off, cuts, kw)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_configuration_write_combining_level1(gpu_lib, seed, monkeypatch):
     """k_scatter1_wc (round 5, bfcg_scatter1wc.hip): level 1 of the one-pass partition through write-combining buffers in LDS -- a buffer of 16 or 32
     records per bucket (8 or 16 with two workgroups of 512 threads per CU), full buffers leave as whole chunks into room reserved a group ahead, what finds its buffer full waits a round in
@@ -281,7 +281,7 @@ def test_random_medium_configuration(gpu_lib, seed):
     _check(gpu_lib, *_draw(20000 + seed, scale=int(os.environ.get("BFC_FUZZ_SCALE", "40"))))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(14))
 @pytest.mark.parametrize("base", [0, 21])
 def test_random_configuration_on_emulated_ranks(gpu_lib, seed, base, monkeypatch):
     """the same draws through the multi-GPU stages: 2 / 4 / 8 ranks emulated on one device (LocalCluster), ragged rank shares, ranks
@@ -322,7 +322,7 @@ def test_random_configuration_on_emulated_ranks(gpu_lib, seed, base, monkeypatch
     cl.close(); oc.close()
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_exact_dump(gpu_lib, seed, tmp_path):
     """Parity level L2 under random parameters: with order stamps (track_order) the dump file is byte for byte the oracle's, whose khash
     emulation is pinned to `bfc -E -t1 -d` by the md5 goldens (tests/test_oracle.py) -- any k, l_pre, batching, initial table size."""
@@ -345,7 +345,7 @@ def test_random_exact_dump(gpu_lib, seed, tmp_path):
 
 
 @pytest.mark.parametrize("q4", ["0", "1"])
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(14))
 def test_random_trim_pass(gpu_lib, seed, q4, monkeypatch):
     """`bfc -1` under random parameters: count in filter mode on the GPU, then the GPU trim pass; start / end of every read equal the
     oracle's max_streak + keep rule (correct.c:478-497, 557-569) on the oracle's second filter.  q4 = 1: through k_query4 (four lanes fetch the
