@@ -97,3 +97,6 @@ PY
   for t in 8 16 24 8 16 24; do echo "== BFC_GPU_D2H_THREADS=$t"; BFC_GPU_D2H_THREADS=$t oracle/_ref/bfc-dropin -E -s 250m -k 33 -t64 /dev/shm/c3e.fq 2>&1 | grep -E "Real time|export_table|left " | cut -c1-200; sleep 2; done > gpurun_out/r6_d2h.txt 2>&1
   rm -f /dev/shm/c3e.fq; cat gpurun_out/r6_d2h.txt
 fi
+if has morefuzz; then  # other draws of every fuzz family on this build (the suite itself runs fewer per family since round 6)
+  bash scripts/more_fuzz.sh ${FUZZ_BASES:-1} > gpurun_out/r6_more_fuzz.txt 2>&1; cat gpurun_out/r6_more_fuzz.txt | tail -6
+fi
