@@ -118,10 +118,10 @@ def test_c3_full_read_set(gpu_lib):
 
 def test_c3_shape_host_layout(gpu_lib):
     """The same geometry with the table in the host's layout from the start (random-CAS upserts, STREAM decisions, table growth by
-    rehash) on the first 4 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
+    rehash) on the first 3 M reads; compared with the region-owned layout run, which the test above pins to the reference."""
     e = dict(gen=dict(seed=3, G=248_000_000, cov=30.0), k=33, b=35)
     rs = gen.ReadSet(**e["gen"])
-    rs.n_reads = 4_000_000  # (12 M until round 5: 43 s of the suite; two batches and a table growth are what the comparison needs)
+    rs.n_reads = 3_000_000  # (12 M until round 5: 43 s of the suite; two batches and a table growth are what the comparison needs)
     res = []
     for layout in (0, 1):
         g = _count_fixed(gpu_lib, rs, e["k"], e["b"], 2_883_584, table_layout=layout)

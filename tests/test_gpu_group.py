@@ -55,7 +55,7 @@ def test_group_host_batches(gpu_lib, g1, n_ranks, k, b, fm):
     grp.close(); oc.close()
 
 
-@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+@pytest.mark.parametrize("n_ranks", [2, 8] + ([4] if os.environ.get("BFC_TEST_MORE") else []))
 def test_group_push_kernel_moves_exactly_the_records(gpu_lib, n_ranks, monkeypatch):
     """Round 6: with the PUSH transport one kernel per rank and global batch writes the filled part of every slab into its
     owner's receive buffer (k_push_slabs: the fills are read on the device, the host still knows no size) -- the bytes on the links are the live
@@ -98,7 +98,7 @@ def test_group_push_kernel_moves_exactly_the_records(gpu_lib, n_ranks, monkeypat
     oc.close()
 
 
-@pytest.mark.parametrize("n_ranks", [1, 2, 4])
+@pytest.mark.parametrize("n_ranks", [2, 4] + ([1] if os.environ.get("BFC_TEST_MORE") else []))  # (a group of one: bench.py through the group path, below)
 @pytest.mark.parametrize("lazy", [1, 0])
 def test_group_sizes_stay_on_the_device(gpu_lib, n_ranks, lazy, monkeypatch):
     """Round 5: with every rank in one process the slabs' fills travel beside the blocks as rows in device memory and the owner builds its
@@ -267,8 +267,7 @@ def test_group_level2_slab_overflow_is_replayed(gpu_lib, n_ranks, fm):
     grp.close(); oc.close()
 
 
-@pytest.mark.parametrize("n_ranks", [2, 4])
-@pytest.mark.parametrize("fm", [0, 1])
+@pytest.mark.parametrize("n_ranks,fm", [(2, 0), (4, 1)] + ([(4, 0), (2, 1)] if os.environ.get("BFC_TEST_MORE") else []))
 def test_group_level1_slab_overflow_falls_back_to_two_passes(gpu_lib, n_ranks, fm):
     """Stage A of a rank is one pass into slabs (round 4).  First a clean global batch (100 000 reads of a 50 Mbp genome: slab mode stays on), then
     200 000 reads of a 400-base genome -- few, often repeated k-mers overflow a level-1 slab on some rank: EVERY rank repeats its stage A of

@@ -283,19 +283,19 @@ def test_long_and_degenerate_reads(gpu_lib, k):
     g.close(); oc.close()
 
 
-@pytest.mark.parametrize("fm,l2_big", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("fm,l2_big", [(0, 0), (0, 1)] + ([(1, 0)] if os.environ.get("BFC_TEST_MORE") else []))  # (filter mode at -b37: the c5 shape tests run it on c5's own read set; BFC_TEST_MORE=1 adds it here)
 def test_largest_filter_b37(gpu_lib, g1, g42, fm, l2_big, monkeypatch):
     """`-s 3g` (bfc.c:42-53) gives -b37: a 16 GiB filter, 64 KiB regions, one 1024-thread workgroup per CU -- table mode and filter mode.
     Compared with the oracle through the set bits' positions (popcount + every word the oracle has set), statistics and the table."""
     rs, (seq, qual, off) = g42 if l2_big else g1
-    n = 120_000 if l2_big else 4000  # (l2_big: two batches of 9 M positions -- above the one-pass partition's minimum at 2^10 level-1 buckets, where the large tile applies)
+    n = 60_000 if l2_big else 4000  # (l2_big: one batch of 9 M positions -- above the one-pass partition's minimum at 2^10 level-1 buckets, where the large tile applies)
     seq, qual, off = seq[:n * rs.L], qual[:n * rs.L], off[:n + 1]
     k, b = 33, 37
     if l2_big:  # level 2 on tiles of 8192 records (KParams.l2_big: 12-byte records, 2^10 regions per bucket, one-pass partition; off by default since its A/B on c4e: DESIGN 6b)
         monkeypatch.setenv("BFCG_L2_BIG", "2")
     oc = oracle.Counter(k, b, filter_mode=fm)
     oc.count(seq, qual, off)
-    g = _gpu_count(gpu_lib, k, b, seq, qual, off, 2, filter_mode=fm)
+    g = _gpu_count(gpu_lib, k, b, seq, qual, off, 1 if l2_big else 2, filter_mode=fm)
     if l2_big:
         assert g.partition_info() == dict(one_pass=True, level2_one_pass=True, replayed_batches=0)
     ost, st = oc.stats(), g.stats()
