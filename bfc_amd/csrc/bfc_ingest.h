@@ -390,6 +390,8 @@ typedef struct psrc_s {
 static void *psrc_reader(void *arg)
 {
 	psrc_t *p = (psrc_t*)arg;
+	int old_state;
+	pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &old_state); /* (psrc_close cancels a reader blocked in read() -- and only there: never with the mutex held) */
 	for (;;) {
 		uint64_t t, space;
 		ssize_t n;
@@ -399,7 +401,9 @@ static void *psrc_reader(void *arg)
 		t = p->tail; space = p->cap - (p->tail - p->head);
 		pthread_mutex_unlock(&p->mu);
 		if (space > ((uint64_t)8 << 20)) space = (uint64_t)8 << 20;
+		pthread_setcancelstate(PTHREAD_CANCEL_ENABLE, &old_state);
 		do n = read(p->fd, p->ring + t % p->cap, (size_t)space); while (n < 0 && errno == EINTR);
+		pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &old_state);
 		pthread_mutex_lock(&p->mu);
 		if (n <= 0) { p->eof = 1; pthread_cond_broadcast(&p->cv_data); pthread_mutex_unlock(&p->mu); return 0; } /* (a read error ends the input, as gzread's does) */
 		p->tail += (uint64_t)n;
