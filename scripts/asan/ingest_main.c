@@ -38,8 +38,25 @@ int main(int argc, char **argv)
 	if (ingest_open(&in, argv[1], strtoull(argv[2], 0, 10), atoi(argv[4]), 1) != 0) return 3;
 	memset(&b, 0, sizeof(b));
 	b.cap = cap; b.seq = (uint8_t*)malloc(cap); b.qual = (uint8_t*)malloc(cap);
+	if (getenv("ASAN_INGEST_PLANES")) { /* round 6: the batch as bit planes -- the fast path packs them straight from the text (AVX2, 32 positions a step, masked tails) */
+		const uint64_t pw = (cap + 31) / 32 + 2;
+		b.planes = (uint32_t*)malloc(pw * 16); b.plane_words = pw; b.q = 20;
+		memset(b.planes, 0xa5, pw * 16);
+	}
 	for (;;) {
 		ingest_fill(&in, &b);
+		if (b.n_seqs && b.planes) { /* digest of the planes: packed directly, or (serial batches) from the byte streams by the same per-position rule */
+			const uint64_t nw = (b.n_pos + 31) / 32, pw = b.plane_words;
+			uint64_t w; int pl;
+			++out[0]; out[1] += (uint64_t)b.n_seqs; out[2] += b.n_pos;
+			if (!b.packed) {
+				const bfc_qthr_t t = bfc_qthr(b.q);
+				for (w = 0; w < nw; ++w) { int k; uint32_t m[4], a[4] = {0, 0, 0, 0}; for (k = 0; k < 32 && w * 32 + k < b.n_pos; ++k) { bfc_planes1(b.seq[w * 32 + k], b.has_qual ? b.qual + w * 32 + k : 0, t, m); a[0] |= m[0] << k; a[1] |= m[1] << k; a[2] |= m[2] << k; a[3] |= m[3] << k; }
+					if (b.n_pos - w * 32 < 32) a[2] |= ~0u << (b.n_pos - w * 32);
+					for (pl = 0; pl < 4; ++pl) b.planes[(uint64_t)pl * pw + w] = a[pl]; }
+			}
+			for (pl = 0; pl < (b.has_qual ? 4 : 3); ++pl) for (w = 0; w < nw; ++w) { const uint32_t v = b.planes[(uint64_t)pl * pw + w]; int k; for (k = 0; k < 4; ++k) hs = (hs ^ ((v >> (8 * k)) & 0xff)) * 0x100000001b3ULL; }
+		} else
 		if (b.n_seqs) {
 			++out[0]; out[1] += (uint64_t)b.n_seqs; out[2] += b.n_pos;
 			for (i = 0; i < b.n_pos; ++i) { hs = (hs ^ b.seq[i]) * 0x100000001b3ULL; hq = (hq ^ b.qual[i]) * 0x100000001b3ULL; }
@@ -48,7 +65,7 @@ int main(int argc, char **argv)
 		if (b.last) break;
 	}
 	printf("%llu %llu %llu %llx %llx %llx\n", (unsigned long long)out[0], (unsigned long long)out[1], (unsigned long long)out[2], (unsigned long long)hs, (unsigned long long)hq, (unsigned long long)hb);
-	free(b.seq); free(b.qual); free(b.kind_cut);
+	free(b.seq); free(b.qual); free(b.kind_cut); free(b.planes);
 	ingest_close(&in);
 	return 0;
 }

@@ -35,6 +35,30 @@ with tempfile.TemporaryDirectory() as d:
                     outs.append(r.stdout)
                 if len(set(outs)) != 1:
                     bad += 1; print("seed", seed, rep, chunk, cap, "parsers disagree", outs)
+                # round 6: the same text through a FIFO (reader thread + ring mapped twice, the chained walks on windows of it, the serial parser FROM the ring) ...
+                if cap > 20000:
+                    fifo = os.path.join(d, "in.fifo")
+                    if not os.path.exists(fifo):
+                        os.mkfifo(fifo)
+                    for threads, ms in ((3, None), (5, "64")):
+                        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+                        if ms: env["BFC_INGEST_MIN_SLICE"] = ms
+                        w = subprocess.Popen(["sh", "-c", "cat %s > %s" % (fn, fifo)])
+                        r = subprocess.run([exe, fifo, str(chunk), str(cap), str(threads)], capture_output=True, text=True, env=env)
+                        w.wait()
+                        if r.returncode != 0 or r.stderr.strip() or r.stdout != outs[0]:
+                            bad += 1; print("seed", seed, rep, chunk, cap, threads, "FIFO: rc", r.returncode, r.stdout, outs[0], r.stderr[:1500])
+                    # ... and the batches as bit planes (AVX2 packing with masked tails against the per-position rule on the serial parser's byte streams)
+                    pouts = []
+                    for threads, ms in ((0, None), (3, None), (5, "64")):
+                        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", ASAN_INGEST_PLANES="1")
+                        if ms: env["BFC_INGEST_MIN_SLICE"] = ms
+                        r = subprocess.run([exe, fn, str(chunk), str(cap), str(threads)], capture_output=True, text=True, env=env)
+                        if r.returncode != 0 or r.stderr.strip():
+                            bad += 1; print("seed", seed, rep, chunk, cap, threads, "planes: rc", r.returncode, r.stderr[:1500])
+                        pouts.append(r.stdout)
+                    if len(set(pouts)) != 1:
+                        bad += 1; print("seed", seed, rep, chunk, cap, "planes differ", pouts)
             r = subprocess.run([exe, fn, "0", "0", "0", "hdr"], capture_output=True, text=True, env=dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1"))
             if r.returncode != 0 or r.stderr.strip():
                 bad += 1; print("seed", seed, rep, "keep_hdr parse: rc", r.returncode, r.stderr[:1500])

@@ -51,6 +51,15 @@ def test_threaded_ingest_under_tsan(tmp_path):
             assert r.returncode == 0 and not r.stderr.strip(), (fn, chunk, r.stderr[:1500])
             outs.add((chunk, " ".join(r.stdout.split()[1:5])))
     assert len(outs) == 2  # the gzip'ed file parses into the plain file's batches
+    # round 6: the same text through a FIFO -- the pipe's reader thread, the ring's head / tail hand-over and the walks on its windows under ThreadSanitizer
+    fifo = str(tmp_path / "in.fifo")
+    os.mkfifo(fifo)
+    for chunk in ("200000", "100000000"):
+        w = subprocess.Popen(["sh", "-c", "cat %s > %s" % (fq, fifo)])
+        r = subprocess.run([exe, fifo, chunk, str(1 << 24), "8"], capture_output=True, text=True, env=dict(env, BFC_INGEST_RING=str(4 << 20)), timeout=600)
+        w.wait()
+        assert r.returncode == 0 and not r.stderr.strip(), (chunk, r.stderr[:1500])
+        assert (chunk, " ".join(r.stdout.split()[1:5])) in outs
 
 
 def test_host_api_under_asan(tmp_path):
