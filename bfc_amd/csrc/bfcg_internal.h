@@ -7,7 +7,7 @@
 /* records per scatter tile: 20-byte records (k > 47) take 3072 so that two workgroups' stages fit a CU's LDS */
 /* dwords per k-mer record: y0 (minus rec_n bucket bits), y1, the quality flag and the 32-bit file index in 96 or 128 bits, else 20 bytes */
 static inline int bfcg_rec_dwords(int k, int rec_n) { const int bits = 2 * k - rec_n + 33; return bits <= 96 ? 3 : bits <= 128 ? 4 : 5; }
-static inline int bfcg_tile_of_rw(int rw) { return rw == 5 ? 3072 : 4096; }
+static inline int bfcg_tile_of_rw(int rw) { return rw == 5 ? 2048 : rw == 4 ? 3072 : 4096; } /* level 2's tile: 48 / 48 / 40 KiB of stage for 12- / 16- / 20-byte records -- with the 2 - 4 KiB of counters three workgroups per CU each (round 6) */
 /* positions per tile of stage A (k_hist1 / k_scatter1: bfcg_kernels.hip, S1<RW>) */
 static inline int bfcg_tile1_of_rw(int rw) { return rw == 3 ? 4096 : 3072; }
 #define BFCG_MAXB 1024   /* most buckets one scatter level fans out to */

@@ -615,7 +615,10 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 	constexpr bool KEEP_BK = false;
 	unsigned short *sbk = reinterpret_cast<unsigned short *>(smem2 + (size_t)TILE * RW * 4); // bucket of each staged record
 	const int nb2 = 1 << P.F2;
-	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *gdelta = cnt + nb2; // 2 x nb2 counters behind the stage
+	// nb2 counters behind the stage -- ONE array (round 6): the runs' output offsets (gdelta) are written over the counters once the tile is staged.  With a second array the
+	// stage of 4096 12-byte records and 2 x 2^10 words was 56 KiB: TWO workgroups per CU where c3's 2^9 regions per bucket run three (52 KiB) -- config c4's level 2 at
+	// 7.0 ps per record against c3's 5.2 was an occupancy step, not its shorter runs (tiles of 8192 records, which doubled the runs, changed nothing: DESIGN 6b).
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(smem2 + (size_t)TILE * (RW * 4 + (KEEP_BK ? 2 : 0))), *gdelta = cnt;
 	__shared__ uint32_t wsum2[BT / WAVE];
 	const uint32_t n_rows = row_base[n_seg];
 	const int64_t row = xcd_tile(blockIdx.x, n_rows);
@@ -650,15 +653,20 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 		const uint32_t tot = block_scan_excl<BT>(cnt, nb2, wsum2);
 		n_live = tot;
 		__syncthreads();
-		if (!ONEPASS2) {
-			for (int i = threadIdx.x; i < nb2; i += BT) gdelta[i] = rowp[i] - cnt[i]; // global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
-		}
 	}
 	// One pass: a (tile, region) run reserves its place with a RETURNING atomic on the region's cursor -- executed at the memory side, a round trip of
 	// microseconds --, and nothing needs the answer before the copy-out: the atomics are issued here, the tile is put in region order in LDS
 	// meanwhile, and the answers are turned into gdelta behind that (round 6; they were awaited before the staging began).
 	constexpr int NQ = (BFCG_MAXB + BT - 1) / BT;
 	uint32_t q_base[NQ], q_ex[NQ], q_c[NQ];
+	if (!ONEPASS2) { // two passes: the run's place is its histogram row's; global record index = staged position + gdelta[bucket] (wraps are fine: u32 modular)
+#pragma unroll
+		for (int u = 0; u < NQ; ++u) {
+			const int i = threadIdx.x + u * BT;
+			q_base[u] = 0; q_ex[u] = 0; q_c[u] = 0;
+			if (i < nb2) q_base[u] = rowp[i] - cnt[i];
+		}
+	}
 	if (ONEPASS2) {
 		const uint32_t f0 = (uint32_t)(b1 / segs_per_bucket) << P.F2;
 #pragma unroll
@@ -671,7 +679,6 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 			}
 		}
 	}
-	if (!ONEPASS2) __syncthreads();
 #pragma unroll
 	for (int j = 0; j < S; ++j) {
 		if (br[j] != 0xffffffffu) {
@@ -681,15 +688,19 @@ __global__ __launch_bounds__(BT) void k_scatter2(KParams P, const uint32_t *__re
 			if (KEEP_BK) sbk[pos] = (unsigned short)b;
 		}
 	}
-	if (ONEPASS2) {
+	__syncthreads(); // (every record is staged: nobody reads the counters as offsets any more -- they become the runs' output offsets)
+	{
 		const uint32_t f0 = (uint32_t)(b1 / segs_per_bucket) << P.F2;
 #pragma unroll
 		for (int u = 0; u < NQ; ++u) {
 			const int i = threadIdx.x + u * BT;
 			if (i < nb2) {
 				uint32_t base = q_base[u];
-				if (q_c[u] && base + q_c[u] > O2.cap2) { O2.flags[2] = 1; base = 0; } // (the run then lands on records nobody will read: the buffer ends with a tile of slack)
-				gdelta[i] = (f0 + (uint32_t)i) * O2.cap2 + base - q_ex[u];
+				if (ONEPASS2) {
+					if (q_c[u] && base + q_c[u] > O2.cap2) { O2.flags[2] = 1; base = 0; } // (the run then lands on records nobody will read: the buffer ends with a tile of slack)
+					base = (f0 + (uint32_t)i) * O2.cap2 + base - q_ex[u];
+				}
+				gdelta[i] = base;
 			}
 		}
 	}
@@ -2192,7 +2203,7 @@ static inline bool scatter1_fast(const KParams &P)
 template <typename W, int RW>
 static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
 {
-	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
+	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 2048 : RW == 4 ? 3072 : TILE2;
 	const int nb1 = 1 << P.F1;
 	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
 	const int n_chunks = (int)((tiles1 + SCAN_CH - 1) / SCAN_CH);
@@ -2211,7 +2222,7 @@ static void run_stage_a_t(const KParams &P, const BatchBufs &B, const uint8_t *s
 template <typename W, int RW>
 static void run_stage_a_onepass_t(const KParams &P, const BatchBufs &B, const uint8_t *seq, const uint8_t *qual, int64_t n_pos, uint32_t *out1, hipStream_t st, hipEvent_t *ev)
 {
-	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
+	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 2048 : RW == 4 ? 3072 : TILE2;
 	const int nb1 = 1 << P.F1;
 	const int64_t tiles1 = (n_pos + T1 - 1) / T1;
 	if (ev) hipEventRecord(ev[0], st);
@@ -2318,7 +2329,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 	const int nb_loc = n_seg / segs_per_bucket, nfine = nb_loc << P.F2;
 	const uint32_t *fine_recs = in1; const uint32_t *fine_start = bucket_start;
 	if (P.F2 > 0) {
-		constexpr int T2 = RW == 5 ? 3072 : TILE2; // = bfcg_tile_of(k)
+		constexpr int T2 = RW == 5 ? 2048 : RW == 4 ? 3072 : TILE2; // = bfcg_tile_of(k)
 		// rows of level 2 <= records/T2 + one ragged row per segment; surplus blocks exit at once
 		const unsigned g2 = (unsigned)(((n_rec_bound / T2 + n_seg + 1 + 7) / 8) * 8);
 		bool big_done = false;
@@ -2326,7 +2337,7 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 			if (B.cap2 && P.l2_big && scatter2_fast(P)) { // (the segments' rows were counted in tiles of TILE2_BIG by this batch's k_seg_setup)
 				const unsigned g2b = (unsigned)(((n_rec_bound / TILE2_BIG + n_seg + 1 + 7) / 8) * 8);
 				hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
-				hipLaunchKernelGGL((k_scatter2<W, RW, TILE2_BIG, BT2_BIG, true, true>), dim3(g2b), dim3(BT2_BIG), (size_t)TILE2_BIG * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+				hipLaunchKernelGGL((k_scatter2<W, RW, TILE2_BIG, BT2_BIG, true, true>), dim3(g2b), dim3(BT2_BIG), (size_t)TILE2_BIG * (RW * 4) + ((size_t)4 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
 				                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
 				big_done = true;
 			}
@@ -2335,15 +2346,15 @@ static void run_stage_b_t(const KParams &P, const BatchBufs &B, const uint32_t *
 		else if (B.cap2) { // one pass: region slabs and cursors
 			hipMemsetAsync(B.cnt2, 0, sizeof(uint32_t) * (size_t)nfine, st);
 			if ((RW == 3 || RW == 4) && scatter2_fast(P)) // (round 5: 16-byte records too -- their first word holds the same low bits of y0)
-				hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true, RW == 3 || RW == 4>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+				hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true, RW == 3 || RW == 4>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)4 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
 				                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
 			else
-			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
+			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2, true>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)4 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base,
 			                   (const uint32_t *)nullptr, (uint32_t *)B.recs2, OnePass2{B.cnt2, B.cap2, B.op_flags});
 		} else {
 			hipLaunchKernelGGL((k_hist2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), 0, st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2);
 			hipLaunchKernelGGL(k_scan2, dim3(nb_loc), dim3((1 << P.F2) < 64 ? 64 : (1 << P.F2)), 0, st, P, bucket_start, segs_per_bucket, row_base, B.rows2, B.start2, B.cnt_live);
-			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)8 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2,
+			hipLaunchKernelGGL((k_scatter2<W, RW, T2, BT2>), dim3(g2), dim3(BT2), (size_t)T2 * (RW * 4) + ((size_t)4 << P.F2), st, P, in1, seg_beg, seg_end, n_seg, segs_per_bucket, row_base, B.rows2,
 			                   (uint32_t *)B.recs2, OnePass2{nullptr, 0u, nullptr});
 		}
 		fine_recs = (const uint32_t *)B.recs2; fine_start = B.start2;
@@ -2437,7 +2448,7 @@ void run_pack_rows(const KParams &P, const BatchBufs &B, int n_ranks, uint32_t r
 void run_seg_setup_mg(const KParams &P, int rw_dwords, const uint32_t *rows, uint32_t row_w, int n_ranks, int s_lo, int s_hi, uint32_t cap, uint32_t *seg, unsigned long long *total, hipStream_t st)
 {
 	const int nb1 = 1 << P.F1, nb_loc = nb1 / n_ranks, n_seg = nb1 * 8;
-	hipLaunchKernelGGL(k_seg_setup_mg, dim3(1), dim3(1024), 0, st, rows, row_w, n_ranks, s_lo, s_hi, nb_loc, cap, rw_dwords == 5 ? 3072 : TILE2, seg, seg + n_seg, seg + 2 * n_seg, seg + 3 * n_seg + 1, total);
+	hipLaunchKernelGGL(k_seg_setup_mg, dim3(1), dim3(1024), 0, st, rows, row_w, n_ranks, s_lo, s_hi, nb_loc, cap, rw_dwords == 5 ? 2048 : rw_dwords == 4 ? 3072 : TILE2, seg, seg + n_seg, seg + 2 * n_seg, seg + 3 * n_seg + 1, total);
 }
 
 void run_stage_b(const KParams &P, const BatchBufs &B, const uint64_t *in1, const uint32_t *seg_beg, const uint32_t *seg_end, int n_seg, int segs_per_bucket,
@@ -2462,7 +2473,7 @@ int bloom_lds_bytes(const KParams &P)
 template <typename W, int RW> static hipError_t set_attr_t(int lds)
 {
 	hipError_t e;
-	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 3072 : TILE2;
+	constexpr int T1 = S1<RW>::TILE, BTS1 = S1<RW>::BT, T2 = RW == 5 ? 2048 : RW == 4 ? 3072 : TILE2;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 8 * BFCG_MAXB); if (e != hipSuccess) return e;
 	e = hipFuncSetAttribute((const void *)k_scatter1<W, RW, T1, BTS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T1 * (RW * 4 + 2) + 16 * BFCG_MAXB); if (e != hipSuccess) return e;
 	if constexpr (RW == 3) {
