@@ -13,8 +13,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEAK = os.environ.get("MG_SCALING") == "weak"  # one read set PER RANK into one filter of 2^(b + log2 N) bits (capped at -b37): the work per GPU is fixed, a step should take what one GPU's takes
 wls = sys.argv[1:] or ["c3", "c4e"]
-EXTRA = {"c4e": ["--batch-reads", "8388608"]}  # (N contexts on ONE device: calls of 8.4 M reads instead of 16.8 M so that their buffers fit its 288 GB; the N = 1 row runs the same calls)
+EXTRA = {"c4e": ["--batch-reads", "8388608"]} if not WEAK else {"c3": ["--batch-reads", "2097152"]}  # (weak: N whole read sets and N full-size contexts on ONE device -- calls of 2.1 M reads per rank, the N = 1 row too)  # (N contexts on ONE device: calls of 8.4 M reads instead of 16.8 M so that their buffers fit its 288 GB; the N = 1 row runs the same calls)
 out = []
 for wl in wls:
     rows = []
@@ -26,7 +27,7 @@ for wl in wls:
         for tr in ((0,) if n == 1 else (0, 2)):  # default (push kernel: exact bytes) and whole-block peer copies
             env["BFC_BENCH_TRANSPORT"] = str(tr)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                                "--no-boundary", "--no-secondary"] + EXTRA.get(wl, []), capture_output=True, text=True, env=env)
+                                "--no-boundary", "--no-secondary"] + (["--scaling", "weak"] if WEAK and n > 1 else []) + EXTRA.get(wl, []), capture_output=True, text=True, env=env)
             try:
                 d = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception:  # noqa: BLE001
@@ -48,7 +49,8 @@ for wl in wls:
 
 print("# Round 6 -- the scaling curve PREDICTED from ranks emulated on one MI355X (scripts/mg_predict.py; a model, not a measurement)\n")
 for wl, base, rows in out:
-    print("## %s, strong scaling (one read set, every global batch split over the ranks), every run verified against the reference's answers\n" % wl)
+    print(("## %s, WEAK scaling (one read set per rank -- other genomes: seed + rank -- into ONE filter of 2^(b + log2 N) bits, at most -b37; no reference answers exist for the union: not verified; work inflation = wall over N x the one-GPU wall)\n" if WEAK else
+           "## %s, strong scaling (one read set, every global batch split over the ranks), every run verified against the reference's answers\n") % wl)
     print("| N | transport | verified | wall ms per step, all N ranks on ONE device | work inflation vs N = 1 | device ms per rank on N GPUs (wall / N) | bytes out per rank and step: as sent / live records | "
           "their time on N - 1 links at 153 GB/s: as sent / live | predicted ms per step (exchange at half the link rate) | predicted speed-up over one GPU | efficiency |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
@@ -58,7 +60,9 @@ for wl, base, rows in out:
         kr = r["ksum"] / n
         xl, xe = r["x_ms"].get("links", 0.0), r["x_ms"].get("exact", 0.0)
         pred = max(kr, 2 * xl)
-        sp = base / pred if base else float("nan")
+        sp = (n * base / pred if WEAK else base / pred) if base else float("nan")  # (weak: N GPUs do N times the work in `pred`)
+        if WEAK:
+            infl = r["ksum"] / (n * base) if base else float("nan")
         print("| %d | %s | %s | %.1f | %.2f | %.1f | %.2f / %.2f GB | %.1f / %.1f ms | %.1f | %.2f | %.2f |" % (
             n, r["transport"], r["verified"], r["ksum"], infl, kr, r["links"] / 1e9, r["exact"] / 1e9, xl, xe, pred, sp, sp / n))
     print()
